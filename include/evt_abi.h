@@ -1,0 +1,233 @@
+/*
+ * evt_abi.h -- C ABI of libevt_hip.so: hand-written gfx950 (CDNA4) HIP kernels for the Eventful
+ * Transformer gated-token inference path.
+ *
+ * The reference (WISION-Lab/eventful-transformer) has NO FFI boundary: its "plugin API" for this
+ * path is the Python class API of package `eventful_transformer` and everything below that is a
+ * stock ATen op.  This header is therefore the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md); each entry point cites the reference code (file:line under /root/reference)
+ * whose ATen op sequence it replaces.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors).  The library
+ *     never allocates, frees or retains device memory and keeps no global state.
+ *   - `stream` is a hipStream_t passed as void*.  Calls only enqueue work; they never synchronise.
+ *   - Return value: EVT_OK (0) or a negative evt_status.  Nothing throws or exits.  A failing call
+ *     leaves a message readable through evt_last_error_string() (thread-local).
+ *   - Tokens are row-major fp32: (B, N, D) with a token = one contiguous row.
+ *   - Index lists are int32, ASCENDING, laid out (B, kcap); `count` (nullable) holds the number of
+ *     valid entries per clip, on the device, for data-dependent selections (threshold policy).
+ *     count == NULL means every clip has exactly kcap entries (top-k).
+ *   - "store type" (evt_dtype) is the type the reference holds a tensor in after
+ *     `_cast_matmul_2` (blocks.py:183-189): fp32, or bf16/fp16 with round-to-nearest-even at
+ *     exactly the points where the reference rounds.
+ */
+#ifndef EVT_ABI_H
+#define EVT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVT_ABI_VERSION 1
+
+typedef enum evt_status {
+  EVT_OK = 0,
+  EVT_ERR_BAD_ARG = -1,     /* null pointer, non-positive size, unsupported combination       */
+  EVT_ERR_BAD_SHAPE = -2,   /* shape outside what the kernels support (see each entry point)  */
+  EVT_ERR_BAD_DTYPE = -3,
+  EVT_ERR_HIP = -4          /* hipGetLastError() after a launch; text in evt_last_error_string */
+} evt_status;
+
+typedef enum evt_dtype { EVT_F32 = 0, EVT_BF16 = 1, EVT_F16 = 2 } evt_dtype;
+
+typedef enum evt_act { EVT_ACT_NONE = 0, EVT_ACT_GELU_ERF = 1 } evt_act;
+
+int evt_version(void);
+const char* evt_last_error_string(void);
+/* Compile-time target of the embedded code object, e.g. "gfx950". */
+const char* evt_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K0/K1a  Row pass: [residual add] -> [LayerNorm] -> [delta-norm against a gate reference].
+ *
+ *   s = x (+ res)                         written to sum_out   if non-null
+ *   c = ln_w ? LN(s; ln_w, ln_b, eps) : s written to c_out     if non-null
+ *   norms[row] = || c - p[row] ||_2       written to norms     if p and norms non-null
+ *
+ * Replaces: nn.LayerNorm (blocks.py:460,444; eps 1e-6 at blocks.py:23), CountedAdd residual
+ * (blocks.py:436,448), and `c - self.p` + `vector_norm` of the gate/policy
+ * (modules.py:149, policies.py:63 / :28).  rows = B*N, D % 4 == 0, D <= 4096.
+ * ------------------------------------------------------------------------------------------ */
+int evt_row_pass(const float* x, const float* res, float* sum_out,
+                 const float* ln_w, const float* ln_b, float eps, float* c_out,
+                 const float* p, float* norms, int rows, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K1  Token selection from per-token delta norms.  One workgroup per clip; norms staged in LDS;
+ *     radix select of the k-th largest key, then wavefront-ballot compaction in index order.
+ *
+ * evt_select_topk: idx[b, 0..k) = the k tokens with the largest norms, ASCENDING; ties at the
+ *   k-th value go to the LOWEST index.  Replaces `vector_norm(...).topk(k, sorted=False)[1]`
+ *   (policies.py:63, :93-95), whose order and tie-break are implementation-defined.
+ * evt_select_threshold: idx[b, 0..count[b]) = tokens with norm > threshold, ascending;
+ *   count[b] written on the device (no host sync).  Replaces `.gt(thr).nonzero()`
+ *   (policies.py:28-32, a host sync in the reference).  kcap (row stride of idx) must be >= N.
+ * N <= 16384.
+ * ------------------------------------------------------------------------------------------ */
+int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, void* stream);
+int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap,
+                         int32_t* idx, int32_t* count, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K2  Gate gather + reference update for the selected tokens (rows):
+ *       c_tilde[b,i,:] = c[b, idx[b,i], :]            (if c_tilde non-null)
+ *       e_tilde[b,i,:] = c[b, idx[b,i], :] - p[...]   (if e_tilde non-null; TokenDeltaGate)
+ *       p[b, idx[b,i], :] = c[b, idx[b,i], :]         (if update_p)
+ * Replaces gather + scatter_ of TokenGate/TokenDeltaGate.forward_incremental
+ * (modules.py:150-152, 196-200).  c, p: (B,N,D); c_tilde/e_tilde: (B,kcap,D).  D % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int evt_gate_gather_update(const float* c, float* p, const int32_t* idx, const int32_t* count,
+                           int B, int N, int D, int kcap, float* c_tilde, float* e_tilde,
+                           int update_p, void* stream);
+
+/* TokenBuffer incremental update for callers that already hold compact rows:
+ *   b[b, idx[b,i], :] = x[b,i,:]   (modules.py:86-97, structure="row").  F % 4 == 0. */
+int evt_scatter_rows(const float* x, float* buf, const int32_t* idx, const int32_t* count,
+                     int B, int N, int F, int kcap, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K3  Gated linear:  out[orow(m), :] = act( A[arow(m), :] . W^T + bias )  for m = (b, i),
+ *     i < count[b], with fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products/accumulate).
+ *       arow(b,i) = b*a_rows + (a_idx ? a_idx[b*kcap+i] : i)
+ *       orow(b,i) = b*o_rows + (o_idx ? o_idx[b*kcap+i] : i)
+ *     A rows are gathered through a_idx while the A tile is staged into LDS (no compact copy);
+ *     output rows are scattered through o_idx in the epilogue (TokenBuffer update fused).
+ *     If p_upd is non-null the kernel also performs the gate reference update
+ *     p_upd[arow(m), :] = A[arow(m), :] (K2 fused; requires a_idx).
+ * Replaces CountedLinear.forward on the gathered rows (counting.py:156-162 called from
+ * blocks.py:462,433,244-245), the TokenBuffer scatter_ (modules.py:96) and nn.GELU (blocks.py:114).
+ * W: (Nout, K) row-major as in the reference state_dict; K % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_linear_desc {
+  const float* A;        int64_t lda;     /* row stride of A in elements                       */
+  const int32_t* a_idx;  int32_t a_rows;  /* rows per clip in A (N when gathered, kcap compact) */
+  const float* W;        const float* bias;
+  float* out;            int64_t ldo;
+  const int32_t* o_idx;  int32_t o_rows;
+  const int32_t* count;                    /* nullable: per-clip valid rows                     */
+  float* p_upd;                            /* nullable: gate reference to refresh (ld = lda)    */
+  int32_t B, kcap, K, Nout;
+  int32_t act;                             /* evt_act                                           */
+} evt_linear_desc;
+
+int evt_gated_linear(const evt_linear_desc* d, void* stream);
+
+/* K7  Gated MLP: hidden = GELU(A[rows].W1^T + b1) -> out[rows] = hidden.W2^T + b2, as two MFMA
+ * launches sharing one compact `hidden` scratch (B*kcap, Dh) provided by the caller.
+ * Replaces Block._forward_mlp on gated rows + mlp_accumulator scatter (blocks.py:242-246, 446-447). */
+typedef struct evt_mlp_desc {
+  const float* A;        int64_t lda;
+  const int32_t* idx;    int32_t rows;    /* idx gathers A rows and scatters out rows; N per clip */
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  float* hidden;                          /* (B*kcap, Dh) scratch                               */
+  float* out;            int64_t ldo;
+  const int32_t* count;
+  float* p_upd;
+  int32_t B, kcap, D, Dh;
+} evt_mlp_desc;
+
+int evt_gated_mlp(const evt_mlp_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K4  q.k^T product state.  qkv: (B, Nq, 3D) token buffer laid out [q heads | k heads | v heads]
+ *     (blocks.py:248-255); product: (B, H, Nq, Nk) fp32; scale = sqrt(D/H) applied to q.
+ *   evt_qk_full : product = (q/scale) k^T                       (MatmulBuffer.forward_first,
+ *                 modules.py:224-230)
+ *   evt_qk_delta: rows idx <- (q/scale)[idx] k^T, then columns idx <- (q/scale) k[idx]^T, both
+ *                 from the already-updated buffer (modules.py:232-248).
+ *   tok_map (nullable, (G, Nq)): window partition for windowed attention (blocks.py:257-301):
+ *     group g's token t is qkv row tok_map[g*Nq+t] of clip g / groups_per_clip, or the padding
+ *     row `pad_row` ((3D,) = qkv bias, blocks.py:280-281) when negative.  With a map, B counts
+ *     groups and Nk == Nq.
+ * D/H % 4 == 0, D/H <= 128.
+ * ------------------------------------------------------------------------------------------ */
+int evt_qk_full(const float* qkv, int B, int N, int D, int H, float scale, float* product,
+                const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
+                void* stream);
+int evt_qk_delta(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
+                 int H, int kcap, float scale, float* product, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K5  Row softmax over the product state with optional decomposed relative position terms,
+ *     fused with the attention ("A") delta gate in column structure.
+ *   logits[b,h,i,j] = product[b,h,i,j] + q_i.Ry[y_i, ky_j] + q_i.Rx[x_i, kx_j]   (utils.py:159-168,
+ *                     q UNSCALED, blocks.py:521)
+ *   a = softmax_j(logits)  (blocks.py:522), rounded to `store` (blocks.py:561)
+ *   mode FULL : a_state[b,h,i,:] = a                       (TokenDeltaGate.forward_first, modules.py:183-185)
+ *   mode GATED: for jj < count: j = idx[jj]
+ *                 a_new[b,h,i,jj]   = a[j]
+ *                 a_delta[b,h,i,jj] = round(a[j] - a_state[b,h,i,j])
+ *                 a_state[b,h,i,j]  = a[j]                  (modules.py:187-201, structure="col")
+ *   rel_y/rel_x: (gh, gh, dh) / (gw, gw, dh) tables (utils.py:151-156) or NULL; gh*gw == N.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_softmax_desc {
+  const float* product;                   /* (B,H,N,Nk)                                          */
+  const float* qkv;                       /* (B,N,3D) for the rel-pos terms; nullable if no rel  */
+  const float* rel_y; const float* rel_x; int32_t gh, gw;
+  const int32_t* tok_map; int32_t groups_per_clip, clip_rows; const float* pad_row;
+  void* a_state;                          /* (B,H,N,Nk) in `store` type                          */
+  void* a_new; void* a_delta;             /* (B,H,N,kcap) in `store` type (GATED only)           */
+  const int32_t* idx; const int32_t* count;
+  int32_t B, H, N, Nk, D, kcap;
+  int32_t store;                          /* evt_dtype                                           */
+  int32_t gated;                          /* 0 = FULL, 1 = GATED                                 */
+} evt_softmax_desc;
+
+int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K6a Value delta gate (rows, forced index; blocks.py:566-567, modules.py:187-201):
+ *   FULL : v_state[b,j,:] = round(v[b,j,:])  for all tokens
+ *   GATED: v_new = round(v[idx]); v_delta = round(v_new - v_state[idx]);
+ *          v_old = round(v_new - v_delta)   (the `v_n_tilde - v_delta_tilde` of modules.py:294)
+ *          v_state[idx] = v_new
+ *   v is the third D-slice of the qkv buffer.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D), all
+ *   in `store` type with heads side by side (h*dh + d).
+ * ------------------------------------------------------------------------------------------ */
+int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
+               int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated,
+               const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
+               void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K6  Attention-value product state, heads merged on write (blocks.py:328-344 fused):
+ *   FULL : pv[b,i,h*dh+d] = round( sum_j a_state[b,h,i,j] v_state[b,j,h*dh+d] )
+ *          (MatmulDeltaAccumulator.forward_first, modules.py:277-283)
+ *   GATED: pv += round( a_new . v_delta );  pv += round( a_delta . v_old )   each `+=` rounded
+ *          to `store` (modules.py:285-295)
+ *   out_f32 (nullable): pv converted back to fp32 (blocks.py:393-396), (B,N,D).
+ *   out_map (nullable): un-window on write (blocks.py:346-376): row (g,t) -> clip row
+ *   tok_map[g*N+t]; rows mapped to padding are dropped.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_av_desc {
+  const void* a1; const void* v1;         /* FULL: a_state (B,H,N,Nk), v_state (B,Nk,D)          */
+  const void* a2; const void* v2;         /* GATED second product (a_delta, v_old); FULL: NULL   */
+  int64_t lda;                            /* row stride of a1/a2 (Nk or kcap)                    */
+  const int32_t* count;                   /* GATED: valid K per clip                             */
+  void* pv;                               /* (B,N,D) in `store` type; nullable when FULL+out_f32 */
+  float* out_f32;
+  const int32_t* out_map; int32_t groups_per_clip, clip_rows;
+  int32_t B, H, N, K, D;
+  int32_t store;
+  int32_t gated;
+} evt_av_desc;
+
+int evt_av(const evt_av_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVT_ABI_H */

@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (read-only mount /root/reference).
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (the reference never travels to the GPU
+box).  For every case it (1) builds the reference module, loads the seeded parameters, injects
+`TokenNormTopK(save_status=True)` / `TokenNormThreshold` policies the way `utils/misc.py:140-143`
+does, (2) runs it, (3) runs `oracle/eventful_oracle.py` on the same inputs and asserts the two
+agree BIT-FOR-BIT (same ATen CPU kernels), and (4) stores inputs-by-seed + expected outputs.
+
+Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vitdet672|vitdet1024]
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+
+from _refimport import import_reference  # noqa: E402
+
+import_reference()
+from eventful_transformer import blocks as rblocks  # noqa: E402
+from eventful_transformer import modules as rmodules  # noqa: E402
+from eventful_transformer import policies as rpolicies  # noqa: E402
+from eventful_transformer.backbones import ViTBackbone as RefBackbone  # noqa: E402
+
+import eventful_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+GATE_CLASSES = (rmodules.SimpleSTGTGate, rmodules.TokenDeltaGate, rmodules.TokenGate)
+
+
+def ref_set_policies(model, factory):
+    # utils/misc.py:140-143
+    for cls in GATE_CLASSES:
+        for gate in model.modules_of_type(cls):
+            gate.policy = factory()
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def sorted_idx(index):
+    return None if index is None else index.sort(dim=-1)[0]
+
+
+def topk_margin(e, k):
+    n = torch.linalg.vector_norm(e.double(), dim=-1)
+    s = n.sort(dim=-1, descending=True)[0]
+    if k >= s.shape[-1]:
+        return 1.0
+    return float(((s[..., k - 1] - s[..., k]) / s[..., k - 1]).min())
+
+
+# ------------------------------------------------------------------------------------------------
+# (i) gate-level cases
+# ------------------------------------------------------------------------------------------------
+def gen_gates():
+    cases = []
+    # (B, N, D, k) top-k cases incl. the BASELINE shapes
+    topk_shapes = [(1, 197, 768, 128), (3, 197, 768, 128), (2, 197, 768, 64), (1, 1764, 768, 256),
+                   (1, 4096, 768, 512), (2, 64, 96, 17), (1, 37, 64, 1), (1, 50, 128, 50), (4, 16, 32, 8)]
+    seed = 1000
+    for (B, N, D, k) in topk_shapes:
+        while True:
+            seed += 1
+            c, p = O.make_gate_case(seed, B, N, D)
+            m = topk_margin(c - p, k)
+            if m >= 1e-4:
+                break
+        gate = rmodules.TokenGate()
+        gate.policy = rpolicies.TokenNormTopK(k)
+        gate(p.clone())
+        c_t, idx = gate(c.clone())
+        # oracle check
+        slot = O.Slot()
+        O.token_gate(slot, p.clone(), O.TopK(k))
+        c_o, idx_o = O.token_gate(slot, c.clone(), O.TopK(k))
+        assert torch.equal(idx, idx_o) and torch.equal(c_t, c_o) and torch.equal(slot.t, gate.p)
+        cases.append(dict(kind="topk", seed=seed, B=B, N=N, D=D, k=k, thr=0.0, margin=m,
+                          idx=sorted_idx(idx).numpy().astype(np.int32)))
+        print(f"gate topk B={B} N={N} D={D} k={k} seed={seed} margin={m:.2e}")
+    # threshold cases: exact counts r (batch 1, policies.py:25)
+    for (N, D, r) in [(197, 768, 0), (197, 768, 1), (197, 768, 63), (197, 768, 64), (197, 768, 65),
+                      (197, 768, 197), (4096, 768, 402), (1764, 768, 256)]:
+        seed += 1
+        c, p, thr = O.make_threshold_case(seed, N, D, r)
+        gate = rmodules.TokenGate()
+        gate.policy = rpolicies.TokenNormThreshold(thr)
+        gate(p.clone())
+        c_t, idx = gate(c.clone())
+        assert idx.shape == (1, r), (idx.shape, r)
+        slot = O.Slot()
+        O.token_gate(slot, p.clone(), O.Threshold(thr))
+        c_o, idx_o = O.token_gate(slot, c.clone(), O.Threshold(thr))
+        assert torch.equal(idx, idx_o) and torch.equal(c_t, c_o)
+        cases.append(dict(kind="threshold", seed=seed, B=1, N=N, D=D, k=r, thr=thr, margin=0.5,
+                          idx=idx.numpy().astype(np.int32)))
+        print(f"gate threshold N={N} r={r} seed={seed}")
+    pack = {"n_cases": np.int64(len(cases)), "torch_version": np.bytes_(torch.__version__)}
+    for i, cse in enumerate(cases):
+        for key, val in cse.items():
+            pack[f"c{i}_{key}"] = np.bytes_(val) if isinstance(val, str) else np.asarray(val)
+    np.savez_compressed(os.path.join(OUT, "gates.npz"), **pack)
+
+
+# ------------------------------------------------------------------------------------------------
+# (ii) block-level cases at reduced dims: full tensors
+# ------------------------------------------------------------------------------------------------
+SMALL = dict(dim=64, heads=4, mlp_ratio=4)
+
+
+def build_ref_block(kind, params, input_size, **kw):
+    blk = getattr(rblocks, kind)(input_size=input_size, **SMALL, **kw)
+    missing = blk.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return blk.eval()
+
+
+def small_cases():
+    """name -> (kind, input_size, has_cls, kwargs, policy spec, n_changed)"""
+    cs = {}
+    for kind in ("EventfulTokenwiseBlock", "EventfulMatmul1Block", "EventfulBlock"):
+        cs[f"{kind}_topk"] = (kind, (6, 6), True, {}, ("topk", 12))
+    cs["EventfulBlock_bf16"] = ("EventfulBlock", (6, 6), True, dict(matmul_2_cast="bfloat16"), ("topk", 12))
+    cs["EventfulBlock_fp16"] = ("EventfulBlock", (6, 6), True, dict(matmul_2_cast="float16"), ("topk", 12))
+    cs["EventfulBlock_k_all"] = ("EventfulBlock", (6, 6), True, {}, ("topk", 37))
+    cs["EventfulBlock_thr"] = ("EventfulBlock", (6, 6), False, {}, ("thr", 0.6))
+    cs["EventfulBlock_thr_none"] = ("EventfulBlock", (6, 6), False, {}, ("thr", 1e9))
+    cs["EventfulBlock_rel"] = ("EventfulBlock", (6, 6), False, dict(relative_embedding_size=(6, 6)), ("topk", 12))
+    cs["EventfulBlock_rel_resized_bf16"] = ("EventfulBlock", (6, 6), False,
+                                            dict(relative_embedding_size=(4, 4), matmul_2_cast="bfloat16"), ("topk", 12))
+    cs["EventfulTokenwiseBlock_win"] = ("EventfulTokenwiseBlock", (6, 6), False,
+                                        dict(window_size=(3, 3), relative_embedding_size=(8, 8)), ("topk", 12))
+    cs["EventfulTokenwiseBlock_winpad"] = ("EventfulTokenwiseBlock", (7, 5), False,
+                                           dict(window_size=(3, 3), relative_embedding_size=(8, 8)), ("topk", 12))
+    cs["EventfulTokenwiseBlock_stgt"] = ("EventfulTokenwiseBlock", (6, 6), True, dict(stgt=True), ("topk", 12))
+    cs["EventfulBlock_gate_before_ln"] = ("EventfulBlock", (6, 6), True, dict(gate_before_ln=True), ("topk", 12))
+    cs["Block_dense"] = ("Block", (6, 6), True, {}, None)
+    cs["Block_win_rel"] = ("Block", (7, 5), False, dict(window_size=(3, 3), relative_embedding_size=(8, 8)), None)
+    return cs
+
+
+def policy_factories(spec):
+    if spec is None:
+        return (lambda: None), (lambda: None)
+    if spec[0] == "topk":
+        return (lambda: rpolicies.TokenNormTopK(spec[1], save_status=True)), (lambda: O.TopK(spec[1]))
+    return (lambda: rpolicies.TokenNormThreshold(spec[1])), (lambda: O.Threshold(spec[1]))
+
+
+def gen_blocks():
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    names = []
+    steps, batch = 4, 2
+    for ci, (name, (kind, isz, has_cls, kw, pol)) in enumerate(small_cases().items()):
+        tokens = isz[0] * isz[1] + int(has_cls)
+        b = 1 if (pol is not None and pol[0] == "thr") else batch
+        rel = kw.get("relative_embedding_size")
+        if rel is not None and kw.get("window_size"):
+            rel = kw["window_size"]  # blocks.py:90-91: windowed blocks size the table by the window
+        seed = 4242
+        while True:
+            seed += 1
+            params = O.make_block_params(SMALL["dim"], SMALL["mlp_ratio"], seed=seed + ci, std=0.08,
+                                         rel_sizes=rel, head_dim=SMALL["dim"] // SMALL["heads"])
+            n_changed = pol[1] if (pol is not None and pol[0] == "topk") else 9
+            xs = O.make_token_stream(b, tokens, SMALL["dim"], steps, min(n_changed, tokens), seed=seed, small=0.02)
+            ref = build_ref_block(kind, params, isz, **kw)
+            rf, of = policy_factories(pol)
+            ref_set_policies(ref, rf)
+            ora = O.BlockOracle(kind, params, SMALL["dim"], SMALL["heads"], isz, **kw)
+            ora.set_policy(of)
+            outs, idxs, margins, ok = [], [], [], True
+            with torch.inference_mode():
+                for t in range(steps):
+                    y_ref = ref(xs[t].clone())
+                    y_ora = ora.forward(xs[t].clone())
+                    assert torch.equal(y_ref, y_ora), (name, t, (y_ref - y_ora).abs().max())
+                    outs.append(y_ref.clone())
+                    if kind != "Block" and t > 0:
+                        step_idx = []
+                        for gname, tkey in (("qkv_gate", "qkv_index"), ("projection_gate", "projection_index"),
+                                            ("mlp_gate", "mlp_index")):
+                            i_o = ora.trace[tkey]
+                            pol_obj = getattr(ref, gname).policy
+                            if pol[0] == "topk":
+                                assert torch.equal(pol_obj.last_output, i_o)
+                                margins.append(topk_margin(pol_obj.last_input, pol[1]))
+                            step_idx.append(sorted_idx(i_o))
+                        idxs.append(step_idx)
+            if pol is None or pol[0] != "topk" or min(margins) >= 1e-3:
+                break
+        names.append(name)
+        pack[f"{name}__seed"] = np.int64(seed)
+        pack[f"{name}__param_seed"] = np.int64(seed + ci)
+        pack[f"{name}__x"] = xs.numpy()
+        pack[f"{name}__y"] = torch.stack(outs).numpy()
+        if kind != "Block":
+            for t, step_idx in enumerate(idxs):
+                for g, i in zip(("qkv", "projection", "mlp"), step_idx):
+                    pack[f"{name}__idx_{g}_{t + 1}"] = i.numpy().astype(np.int32)
+            pack[f"{name}__min_margin"] = np.float64(min(margins) if margins else 1.0)
+        print(f"block {name}: seed={seed} min_margin={min(margins) if margins else 1.0:.2e} |y|max={float(outs[-1].abs().max()):.3f}")
+    pack["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "blocks_small.npz"), **pack)
+
+
+# ------------------------------------------------------------------------------------------------
+# (iii) full-size models: seeds + index sets + feature slices
+# ------------------------------------------------------------------------------------------------
+def backbone_params(depth, dim, mlp_ratio, seed, tokens, rel_for=None, std=0.02):
+    """Backbone-level parameters under the reference's state_dict names."""
+    rs = np.random.RandomState(seed)
+    sd = {"position_encoding.encoding": torch.from_numpy((rs.standard_normal((1, tokens, dim)) * std).astype(np.float32))}
+    for i in range(depth):
+        rel = None if rel_for is None else rel_for(i)
+        bp = O.make_block_params(dim, mlp_ratio, seed=seed * 100 + i, std=std, rel_sizes=rel, head_dim=64)
+        for k, v in bp.items():
+            sd[f"blocks.{i}.{k}"] = v
+    return sd
+
+
+def block_params_of(sd, i):
+    pre = f"blocks.{i}."
+    return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+
+
+def gen_vivit():
+    """ViViT-B spatial sub-model (BASELINE configs 1/2): 197 tokens, 12 EventfulBlocks, k=128."""
+    dim, depth, heads, N, k = 768, 12, 12, 196, 128
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    for mode, cast, steps in (("fp32", None, 6), ("bf16", "bfloat16", 6)):
+        seed = 77
+        sd = backbone_params(depth, dim, 4, seed, N + 1)
+        rs = np.random.RandomState(seed + 1)
+        cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
+        ln_w = torch.from_numpy((1 + rs.standard_normal(dim) * 0.05).astype(np.float32))
+        ln_b = torch.from_numpy((rs.standard_normal(dim) * 0.05).astype(np.float32))
+        cfg = dict(dim=dim, heads=heads, mlp_ratio=4)
+        if cast:
+            cfg["matmul_2_cast"] = cast
+        ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(14, 14),
+                          block_class="EventfulBlock", has_class_token=True).eval()
+        ref.load_state_dict(sd, strict=True)
+        ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
+        blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast=cast)
+                  for i in range(depth)]
+        ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
+        ob.set_policy(lambda: O.TopK(k))
+        model = O.ViViTSpatialOracle(ob, cls, ln_w, ln_b)
+        xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2, small=0.01)
+        feats, idx_all, margins = [], [], []
+        t0 = time.time()
+        with torch.inference_mode():
+            for t in range(steps):
+                # reference: vivit.py:293-303 restated inline around the REAL backbone
+                x = torch.concat([cls.expand(1, 1, dim), xs[t]], dim=1)
+                y = torch.nn.functional.layer_norm(ref(x), (dim,), ln_w, ln_b, 1e-6)[:, 0]
+                y_o = model.forward(xs[t])
+                assert torch.equal(y, y_o), (mode, t, float((y - y_o).abs().max()))
+                feats.append(y.clone())
+                if t > 0:
+                    for bi, blk in enumerate(ref.blocks):
+                        for g in ("qkv_gate", "projection_gate", "mlp_gate"):
+                            pol = getattr(blk, g).policy
+                            idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
+                            margins.append(topk_margin(pol.last_input, k))
+        print(f"vivit {mode}: {steps} steps {time.time() - t0:.1f}s min margin {min(margins):.2e} "
+              f"median {float(np.median(margins)):.2e}")
+        pack[f"{mode}__features"] = torch.stack(feats).numpy()
+        pack[f"{mode}__idx"] = np.stack(idx_all).reshape(steps - 1, depth, 3, 1, k)
+        pack[f"{mode}__margins"] = np.asarray(margins).reshape(steps - 1, depth, 3)
+        pack[f"{mode}__seed"] = np.int64(seed)
+        pack[f"{mode}__sha_qkv0"] = np.bytes_(sha(sd["blocks.0.qkv.weight"]))
+        pack[f"{mode}__sha_x"] = np.bytes_(sha(xs))
+    np.savez_compressed(os.path.join(OUT, "vivit_b.npz"), **pack)
+
+
+def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed):
+    dim, depth, heads = 768, 12, 12
+    window_indices = (0, 1, 3, 4, 6, 7, 9, 10)  # configs/models/vitdet_b_coco.yml:13
+    N = grid * grid
+
+    def rel_for(i):
+        return (14, 14) if i in window_indices else (64, 64)
+
+    sd = backbone_params(depth, dim, 4, seed, 14 * 14, rel_for=rel_for)
+    cfg = dict(dim=dim, heads=heads, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14))
+    if cast_global:
+        cfg["matmul_2_cast"] = cast_global
+    ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(grid, grid),
+                      block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
+                      window_indices=window_indices,
+                      windowed_overrides=(dict(matmul_2_cast=None) if cast_global else None)).eval()
+    ref.load_state_dict(sd, strict=True)
+    ref_set_policies(ref, policy_ref)
+    blocks = []
+    for i in range(depth):
+        if i in window_indices:
+            blocks.append(O.BlockOracle("EventfulTokenwiseBlock", block_params_of(sd, i), dim, heads, (grid, grid),
+                                        window_size=(14, 14), relative_embedding_size=(64, 64)))
+        else:
+            blocks.append(O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (grid, grid),
+                                        relative_embedding_size=(64, 64), matmul_2_cast=cast_global))
+    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (grid, grid), False)
+    ob.set_policy(policy_ora)
+    return ref, ob, sd, N
+
+
+def gen_vitdet672():
+    k, steps, seed = 256, 3, 91
+    ref, ob, sd, N = vitdet_ref_and_oracle(42, lambda: rpolicies.TokenNormTopK(k, save_status=True),
+                                           lambda: O.TopK(k), None, seed)
+    xs = O.make_token_stream(1, N, 768, steps, k, seed=seed + 2, small=0.01)
+    pack = {"torch_version": np.bytes_(torch.__version__), "seed": np.int64(seed)}
+    outs, idx_all, margins = [], [], []
+    with torch.inference_mode():
+        for t in range(steps):
+            t0 = time.time()
+            y = ref(xs[t].clone())
+            y_o = ob.forward(xs[t].clone())
+            assert torch.equal(y, y_o), (t, float((y - y_o).abs().max()))
+            outs.append(y[:, ::16].clone())
+            if t > 0:
+                for blk in ref.blocks:
+                    for g in ("qkv_gate", "projection_gate", "mlp_gate"):
+                        pol = getattr(blk, g).policy
+                        idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
+                        margins.append(topk_margin(pol.last_input, k))
+            print(f"vitdet672 step {t}: {time.time() - t0:.1f}s")
+    pack["y_slice"] = torch.stack(outs).numpy()
+    pack["idx"] = np.stack(idx_all).reshape(steps - 1, 12, 3, 1, k)
+    pack["margins"] = np.asarray(margins).reshape(steps - 1, 12, 3)
+    print("vitdet672 min margin", min(margins))
+    np.savez_compressed(os.path.join(OUT, "vitdet_672.npz"), **pack)
+
+
+def gen_vitdet1024():
+    thr, steps, seed = 1.0, 2, 93
+    ref, ob, sd, N = vitdet_ref_and_oracle(64, lambda: rpolicies.TokenNormThreshold(thr),
+                                           lambda: O.Threshold(thr), "bfloat16", seed)
+    xs = O.make_threshold_stream(N, 768, steps, seed + 2)
+    pack = {"torch_version": np.bytes_(torch.__version__), "seed": np.int64(seed), "threshold": np.float64(thr)}
+    outs, counts = [], []
+    with torch.inference_mode():
+        for t in range(steps):
+            t0 = time.time()
+            y = ref(xs[t].clone())
+            y_o = ob.forward(xs[t].clone())
+            assert torch.equal(y, y_o), (t, float((y - y_o).abs().max()))
+            outs.append(y[:, ::64].clone())
+            if t > 0:
+                for bi, blk in enumerate(ob.blocks):
+                    for key in ("qkv_index", "projection_index", "mlp_index"):
+                        i = blk.trace[key]
+                        counts.append(i.shape[-1])
+                        pack[f"idx_{t}_{bi}_{key}"] = i.numpy().astype(np.int16)
+            print(f"vitdet1024 step {t}: {time.time() - t0:.1f}s")
+    pack["y_slice"] = torch.stack(outs).numpy()
+    pack["counts"] = np.asarray(counts).reshape(steps - 1, 12, 3)
+    print("vitdet1024 counts", pack["counts"])
+    np.savez_compressed(os.path.join(OUT, "vitdet_1024.npz"), **pack)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vitdet672": gen_vitdet672,
+            "vitdet1024": gen_vitdet1024}
+    for name, fn in todo.items():
+        if args.only in (None, name):
+            fn()
