@@ -1,0 +1,495 @@
+// evt_attn.hip -- K4 (q.k^T product state), K5 (softmax + rel-pos + attention delta gate),
+// K6a (value delta gate), K6 (attention-value product state).
+//
+// All contractions here run on fp32-input MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).  Values the
+// reference holds in bf16/fp16 after `_cast_matmul_2` are widened exactly to fp32 when staged, so
+// products are exact and accumulation is fp32 -- the same arithmetic a bf16 MFMA would do --
+// and every point where the reference rounds to the cast dtype is reproduced by Store<T>::round.
+#include "evt_common.h"
+
+namespace {
+
+// =============================================================================================
+// K4: product[g,h,rm(m),cn(n)] = sum_d (q[rm(m)][d] / scale) * k[cn(n)][d]
+//   part 0 (FULL)      : rm, cn identity                         (modules.py:224-230)
+//   part 1 (DELTA rows): rm = idx_q, cn identity                  (modules.py:236-241)
+//   part 2 (DELTA cols): rm identity, cn = idx_k                  (modules.py:242-247)
+// 64x64 output tile per workgroup, one 32x32 MFMA accumulator per wave, K = dh in one LDS pass.
+// q / k are addressed as base + clip*bs + token*rs + head*hs so both the packed (B,N,3D) token
+// buffer of the blocks and free-standing (B,H,N,dh) tensors fit.
+// =============================================================================================
+struct QkArgs {
+  const float* q; int64_t q_bs, q_hs, q_rs;
+  const float* k; int64_t k_bs, k_hs, k_rs;
+  float* product;
+  const int32_t* idx_q; const int32_t* count_q; int kcap_q;
+  const int32_t* idx_k; const int32_t* count_k; int kcap_k;
+  const int32_t* tok_map; int groups_per_clip; const float* pad_q; const float* pad_k;
+  int G, H, Nq, Nk, dh;
+  float scale;
+  int delta;  // 0: full; 1: rows+cols delta (blockIdx.z selects the part)
+};
+
+__device__ __forceinline__ const float* qk_row(const float* base, int64_t bs, int64_t rs, const int32_t* tok_map,
+                                               int gpc, const float* pad, int g, int t, int n_per_group) {
+  if (tok_map == nullptr) return base + (int64_t)g * bs + (int64_t)t * rs;
+  const int r = tok_map[(int64_t)(g % gpc) * n_per_group + t];
+  if (r < 0) return pad;
+  return base + (int64_t)(g / gpc) * bs + (int64_t)r * rs;
+}
+
+__global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldt = a.dh + 4;
+  float* As = smem;
+  float* Bs = smem + 64 * ldt;
+  int* rmap = reinterpret_cast<int*>(Bs + 64 * ldt);  // 64 output rows
+  int* cmap = rmap + 64;                              // 64 output cols
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int z = blockIdx.z;
+  int part = 0;
+  if (a.delta) { part = 1 + (z & 1); z >>= 1; }
+  const int g = z / a.H, h = z - g * a.H;
+  const int b = a.tok_map ? g / a.groups_per_clip : g;
+  int m_lim, n_lim, m0, n0;
+  if (part == 2) {
+    m0 = blockIdx.x * 64; n0 = blockIdx.y * 64;
+    m_lim = a.Nq; n_lim = a.count_k ? a.count_k[b] : a.kcap_k;
+  } else {
+    m0 = blockIdx.y * 64; n0 = blockIdx.x * 64;
+    m_lim = (part == 1) ? (a.count_q ? a.count_q[b] : a.kcap_q) : a.Nq; n_lim = a.Nk;
+  }
+  if (m0 >= m_lim || n0 >= n_lim) return;
+
+  if (tid < 64) {
+    const int m = m0 + tid;
+    rmap[tid] = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m] : m) : -1;
+  } else if (tid < 128) {
+    const int n = n0 + tid - 64;
+    cmap[tid - 64] = (n < n_lim) ? ((part == 2) ? a.idx_k[(int64_t)b * a.kcap_k + n] : n) : -1;
+  }
+  __syncthreads();
+
+  const int v4 = a.dh >> 2;
+  for (int e = tid; e < 64 * v4; e += 256) {
+    const int r = e / v4, c4 = e - r * v4;
+    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), kb = qa;
+    const int tm = rmap[r], tn = cmap[r];
+    if (tm >= 0) {
+      const float* row = qk_row(a.q, a.q_bs, a.q_rs, a.tok_map, a.groups_per_clip, a.pad_q, g, tm, a.Nq);
+      qa = *reinterpret_cast<const float4*>(row + h * a.q_hs + c4 * 4);
+      qa.x /= a.scale; qa.y /= a.scale; qa.z /= a.scale; qa.w /= a.scale;  // q / self.scale, blocks.py:514
+    }
+    if (tn >= 0) {
+      const float* row = qk_row(a.k, a.k_bs, a.k_rs, a.tok_map, a.groups_per_clip, a.pad_k, g, tn, a.Nk);
+      kb = *reinterpret_cast<const float4*>(row + h * a.k_hs + c4 * 4);
+    }
+    *reinterpret_cast<float4*>(As + r * ldt + c4 * 4) = qa;
+    *reinterpret_cast<float4*>(Bs + r * ldt + c4 * 4) = kb;
+  }
+  __syncthreads();
+
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int half = a.dh >> 1;  // k-range per lane half (multiple of 4)
+  const float* pa = As + (wm * 32 + lr) * ldt + lh * half;
+  const float* pb = Bs + (wn * 32 + lr) * ldt + lh * half;
+  for (int q = 0; q < half; q += 4) {
+    const float4 fa = *reinterpret_cast<const float4*>(pa + q);
+    const float4 fb = *reinterpret_cast<const float4*>(pb + q);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+  }
+  float* out = a.product + ((int64_t)g * a.H + h) * a.Nq * a.Nk;
+  const int cn = cmap[wn * 32 + lr];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rm = rmap[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+    if (rm >= 0 && cn >= 0) out[(int64_t)rm * a.Nk + cn] = acc[r];
+  }
+}
+
+int launch_qk(const QkArgs& a, void* stream) {
+  const size_t lds = (size_t)(2 * 64 * (a.dh + 4)) * sizeof(float) + 128 * sizeof(int);
+  const int ntq = (a.Nq + 63) / 64, ntk = (a.Nk + 63) / 64;
+  dim3 grid;
+  if (a.delta) {
+    // part 1: x -> Nk tiles, y -> kcap_q tiles; part 2: x -> Nq tiles, y -> kcap_k tiles
+    const int gx = ntq > ntk ? ntq : ntk;
+    const int ky = ((a.kcap_q > a.kcap_k ? a.kcap_q : a.kcap_k) + 63) / 64;
+    grid = dim3(gx, ky, a.G * a.H * 2);
+  } else {
+    grid = dim3(ntk, ntq, a.G * a.H);
+  }
+  if (grid.x == 0 || grid.y == 0 || grid.z == 0) return EVT_OK;
+  hipLaunchKernelGGL(qk_kernel, grid, dim3(256), lds, evt_stream(stream), a);
+  return evt_check_launch("evt_qk");
+}
+
+// =============================================================================================
+// K5: one wavefront per attention row.
+// =============================================================================================
+struct SmArgs {
+  const float* product; const float* qkv; const float* rel_y; const float* rel_x;
+  const int32_t* tok_map; const float* pad_row; int groups_per_clip, clip_rows;
+  void* a_state; void* a_new; void* a_delta;
+  const int32_t* idx; const int32_t* count;
+  int G, H, N, Nk, D, dh, kcap, gh, gw, gated;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_gate_kernel(const SmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;      // (g*H + h)*N + i
+  const int64_t total = (int64_t)a.G * a.H * a.N;
+  if (row >= total) return;
+  const int i = (int)(row % a.N);
+  const int64_t gh_ = row / a.N;
+  const int h = (int)(gh_ % a.H), g = (int)(gh_ / a.H);
+  const int b = a.tok_map ? g / a.groups_per_clip : g;
+  const int per_wave = a.Nk + a.dh + a.gh + a.gw;
+  float* lg = smem + (size_t)wave * per_wave;  // logits, then exp
+  float* qs = lg + a.Nk;
+  float* ry = qs + a.dh;
+  float* rx = ry + a.gh;
+
+  const bool rel = a.rel_y != nullptr;
+  if (rel) {
+    const float* qrow = evt_token_row(a.qkv, 3 * (int64_t)a.D, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row,
+                                      g, i, a.N) + h * a.dh;
+    for (int d = lane; d < a.dh; d += 64) qs[d] = qrow[d];
+    // same-wave LDS visibility: wave-synchronous, but make the compiler keep the order
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    const int yi = i / a.gw, xi = i - yi * a.gw;
+    for (int e = lane; e < a.gh + a.gw; e += 64) {
+      const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * a.dh
+                                    : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * a.dh;
+      float s = 0.f;
+      for (int d = 0; d < a.dh; d += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(tab + d);
+        s += qs[d] * t.x + qs[d + 1] * t.y + qs[d + 2] * t.z + qs[d + 3] * t.w;
+      }
+      if (e < a.gh) ry[e] = s; else rx[e - a.gh] = s;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  const float* prow = a.product + row * a.Nk;
+  float mx = -INFINITY;
+  for (int j = lane; j < a.Nk; j += 64) {
+    float x = prow[j];
+    if (rel) {
+      const int ky = j / a.gw;
+      // (x + ty) + tx: the reference adds the y term first (utils.py:159-168)
+      x = (x + ry[ky]) + rx[j - ky * a.gw];
+    }
+    lg[j] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < a.Nk; j += 64) {
+    const float e = expf(lg[j] - mx);
+    lg[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+
+  T* st = reinterpret_cast<T*>(a.a_state) + row * a.Nk;
+  if (!a.gated) {
+    for (int j = lane; j < a.Nk; j += 64) Store<T>::store(st + j, lg[j] / sum);
+  } else {
+    const int cnt = a.count ? a.count[b] : a.kcap;
+    const int32_t* ix = a.idx + (int64_t)b * a.kcap;
+    T* an = reinterpret_cast<T*>(a.a_new) + row * a.kcap;
+    T* ad = reinterpret_cast<T*>(a.a_delta) + row * a.kcap;
+    for (int jj = lane; jj < cnt; jj += 64) {
+      const int j = ix[jj];
+      const float v = Store<T>::round(lg[j] / sum);
+      const float old = Store<T>::load(st + j);
+      Store<T>::store(an + jj, v);
+      Store<T>::store(ad + jj, v - old);
+      Store<T>::store(st + j, v);
+    }
+  }
+}
+
+// =============================================================================================
+// K6a: value delta gate, one thread per 4 channels of one (clip, token).
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ idx,
+                                                     const int32_t* __restrict__ count, int G, int N, int D, int kcap,
+                                                     T* __restrict__ v_state, T* __restrict__ v_delta,
+                                                     T* __restrict__ v_old, int gated, const int32_t* tok_map,
+                                                     int groups_per_clip, int clip_rows, const float* pad_row) {
+  const int v4 = D >> 2;
+  const int rows = gated ? kcap : N;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)G * rows * v4) return;
+  const int c4 = (int)(e % v4);
+  const int64_t r = e / v4;
+  const int g = (int)(r / rows), ii = (int)(r - (int64_t)g * rows);
+  int tok = ii;
+  if (gated) {
+    if (count != nullptr && ii >= count[g]) return;
+    tok = idx[(int64_t)g * kcap + ii];
+  }
+  const float* row = evt_token_row(qkv, 3 * (int64_t)D, tok_map, groups_per_clip, clip_rows, pad_row, g, tok, N);
+  const float4 v = *reinterpret_cast<const float4*>(row + 2 * D + c4 * 4);
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+  T* st = v_state + ((int64_t)g * N + tok) * D + c4 * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float nv = Store<T>::round(vv[q]);
+    if (gated) {
+      const float old = Store<T>::load(st + q);
+      const float dl = Store<T>::round(nv - old);
+      const int64_t o = ((int64_t)g * kcap + ii) * D + c4 * 4 + q;
+      Store<T>::store(v_delta + o, dl);
+      Store<T>::store(v_old + o, nv - dl);  // v_n_tilde - v_delta_tilde, modules.py:294
+    }
+    Store<T>::store(st + q, nv);
+  }
+}
+
+// =============================================================================================
+// K6: pv[g, i, h*dh + d] (+)= round(sum_j A1[g,h,i,j] V1[g,j,h*dh+d]) (+ round(A2 . V2))
+// 64 rows x dh columns per workgroup; each wave owns 16 rows x dh columns as dh/16 16x16x4 MFMA
+// accumulators; K streamed through LDS in chunks of 32.
+// =============================================================================================
+struct AvArgs {
+  const void* a1; const void* v1; const void* a2; const void* v2;
+  int64_t lda; const int32_t* count; void* pv; float* out_f32;
+  const int32_t* out_map; int groups_per_clip, clip_rows;
+  int G, H, N, K, D, dh, gated;
+};
+
+template <typename T, int NT>  // NT = dh / 16
+__global__ __launch_bounds__(256) void av_kernel(const AvArgs a) {
+  constexpr int KT = 32, LDA_S = KT + 4;
+  const int ldv = a.dh + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* A1s = smem;                      // [64][LDA_S]
+  float* A2s = A1s + 64 * LDA_S;
+  float* V1s = A2s + 64 * LDA_S;          // [KT][ldv]
+  float* V2s = V1s + KT * ldv;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gh_ = blockIdx.y, g = gh_ / a.H, h = gh_ - g * a.H;
+  const int i0 = blockIdx.x * 64;
+  const int b = a.out_map ? g / a.groups_per_clip : g;
+  const int K = (a.gated && a.count) ? a.count[b] : a.K;
+  const bool two = a.a2 != nullptr;
+
+  const T* A1 = reinterpret_cast<const T*>(a.a1) + ((int64_t)g * a.H + h) * a.N * a.lda;
+  const T* A2 = two ? reinterpret_cast<const T*>(a.a2) + ((int64_t)g * a.H + h) * a.N * a.lda : nullptr;
+  const int64_t vrows = a.gated ? (a.lda) : a.K;  // rows per group in V1/V2: kcap (== lda) or Nk
+  const T* V1 = reinterpret_cast<const T*>(a.v1) + (int64_t)g * vrows * a.D + h * a.dh;
+  const T* V2 = two ? reinterpret_cast<const T*>(a.v2) + (int64_t)g * vrows * a.D + h * a.dh : nullptr;
+
+  f32x4 acc1[NT], acc2[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc1[t][r] = 0.f; acc2[t][r] = 0.f; }
+
+  const int lr = lane & 15, lq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    // stage A tiles: 64 rows x 32 k
+    for (int e = tid; e < 64 * KT; e += 256) {
+      const int r = e >> 5, kk = e & 31;
+      const int i = i0 + r, k = k0 + kk;
+      const bool ok = (i < a.N) && (k < K);
+      A1s[r * LDA_S + kk] = ok ? Store<T>::load(A1 + (int64_t)i * a.lda + k) : 0.f;
+      if (two) A2s[r * LDA_S + kk] = ok ? Store<T>::load(A2 + (int64_t)i * a.lda + k) : 0.f;
+    }
+    // stage V tiles: 32 k x dh
+    for (int e = tid; e < KT * a.dh; e += 256) {
+      const int kk = e / a.dh, d = e - kk * a.dh;
+      const int k = k0 + kk;
+      const bool ok = k < K;
+      V1s[kk * ldv + d] = ok ? Store<T>::load(V1 + (int64_t)k * a.D + d) : 0.f;
+      if (two) V2s[kk * ldv + d] = ok ? Store<T>::load(V2 + (int64_t)k * a.D + d) : 0.f;
+    }
+    __syncthreads();
+    // lane quarter lq covers k in [8*lq, 8*lq+8) of this chunk (k-order is free inside a sum)
+    const float* pa1 = A1s + (wave * 16 + lr) * LDA_S + lq * 8;
+    const float* pa2 = A2s + (wave * 16 + lr) * LDA_S + lq * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float x1 = pa1[s];
+      const float x2 = two ? pa2[s] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float y1 = V1s[(lq * 8 + s) * ldv + t * 16 + lr];
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1, acc1[t], 0, 0, 0);
+        if (two) {
+          const float y2 = V2s[(lq * 8 + s) * ldv + t * 16 + lr];
+          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, y2, acc2[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+  T* pv = reinterpret_cast<T*>(a.pv);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + wave * 16 + lq * 4 + r;
+    if (i >= a.N) continue;
+    int64_t orow = (int64_t)g * a.N + i;
+    bool emit = true;
+    if (a.out_map != nullptr) {
+      const int tr = a.out_map[(int64_t)(g % a.groups_per_clip) * a.N + i];
+      emit = tr >= 0;
+      orow = (int64_t)(g / a.groups_per_clip) * a.clip_rows + tr;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = h * a.dh + t * 16 + lr;
+      float v = Store<T>::round(acc1[t][r]);
+      if (a.gated) {
+        const float prev = Store<T>::load(pv + ((int64_t)g * a.N + i) * a.D + col);
+        v = Store<T>::round(prev + v);                                   // product += a_n~ @ dv~
+        if (two) v = Store<T>::round(v + Store<T>::round(acc2[t][r]));    // product += da~ @ v_old
+      }
+      if (pv != nullptr) Store<T>::store(pv + ((int64_t)g * a.N + i) * a.D + col, v);
+      if (a.out_f32 != nullptr && emit) a.out_f32[orow * a.D + col] = v;
+    }
+  }
+}
+
+template <typename T>
+int launch_av(const AvArgs& a, void* stream) {
+  const int nt = a.dh / 16;
+  const size_t lds = (size_t)(2 * 64 * 36 + 2 * 32 * (a.dh + 4)) * sizeof(float);
+  const dim3 grid((a.N + 63) / 64, a.G * a.H), block(256);
+  if (grid.x == 0 || grid.y == 0) return EVT_OK;
+  hipStream_t s = evt_stream(stream);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((av_kernel<T, 1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((av_kernel<T, 2>), grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((av_kernel<T, 4>), grid, block, lds, s, a); break;
+    case 8: hipLaunchKernelGGL((av_kernel<T, 8>), grid, block, lds, s, a); break;
+    default: return evt_fail(EVT_ERR_BAD_SHAPE, "evt_av: head dim %d must be 16, 32, 64 or 128", a.dh);
+  }
+  return evt_check_launch("evt_av");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static int check_heads(const char* who, int D, int H, int* dh) {
+  if (H <= 0 || D <= 0 || D % H != 0) return evt_fail(EVT_ERR_BAD_SHAPE, "%s: D=%d not divisible by H=%d", who, D, H);
+  *dh = D / H;
+  if ((*dh % 8) != 0 || *dh > 128) return evt_fail(EVT_ERR_BAD_SHAPE, "%s: head dim %d must be a multiple of 8, <= 128", who, *dh);
+  return EVT_OK;
+}
+
+extern "C" int evt_qk(const evt_qk_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_qk: null descriptor");
+  EVT_REQUIRE(d->q && d->k && d->product, EVT_ERR_BAD_ARG, "evt_qk: null q/k/product");
+  EVT_REQUIRE(d->G >= 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0 && d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_qk: bad sizes");
+  EVT_REQUIRE(d->dh > 0 && (d->dh % 8) == 0 && d->dh <= 128, EVT_ERR_BAD_SHAPE,
+              "evt_qk: head dim %d must be a multiple of 8, <= 128", d->dh);
+  EVT_REQUIRE((d->q_rs & 3) == 0 && (d->q_hs & 3) == 0 && (d->q_bs & 3) == 0 && (d->k_rs & 3) == 0 &&
+              (d->k_hs & 3) == 0 && (d->k_bs & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_qk: strides must be multiples of 4 elements");
+  EVT_REQUIRE(d->tok_map == nullptr || (d->groups_per_clip > 0 && d->pad_q && d->pad_k && !d->delta && d->Nq == d->Nk),
+              EVT_ERR_BAD_ARG, "evt_qk: tok_map needs groups_per_clip, pad rows, full mode and Nq == Nk");
+  if (d->delta) {
+    EVT_REQUIRE(d->idx_q && d->idx_k && d->kcap_q >= 0 && d->kcap_k >= 0, EVT_ERR_BAD_ARG, "evt_qk: delta mode needs idx_q/idx_k");
+    if (d->kcap_q == 0 && d->kcap_k == 0) return EVT_OK;
+  }
+  QkArgs a{d->q, d->q_bs, d->q_hs, d->q_rs, d->k, d->k_bs, d->k_hs, d->k_rs, d->product,
+           d->idx_q, d->count_q, d->kcap_q, d->idx_k, d->count_k, d->kcap_k,
+           d->tok_map, d->tok_map ? d->groups_per_clip : 1, d->pad_q, d->pad_k,
+           d->G, d->H, d->Nq, d->Nk, d->dh, d->scale, d->delta};
+  return launch_qk(a, stream);
+}
+
+extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_gate: null descriptor");
+  EVT_REQUIRE(d->product && d->a_state, EVT_ERR_BAD_ARG, "evt_softmax_gate: null product/a_state");
+  EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->Nk > 0, EVT_ERR_BAD_ARG, "evt_softmax_gate: bad sizes");
+  EVT_REQUIRE((d->rel_y == nullptr) == (d->rel_x == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_gate: rel_y/rel_x must come together");
+  int dh = 0;
+  if (d->rel_y) {
+    EVT_REQUIRE(d->qkv != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_gate: rel-pos needs qkv");
+    EVT_REQUIRE(d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N && d->Nk == d->N, EVT_ERR_BAD_SHAPE,
+                "evt_softmax_gate: rel-pos grid %dx%d does not match N=%d/Nk=%d", d->gh, d->gw, d->N, d->Nk);
+    int rc = check_heads("evt_softmax_gate", d->D, d->H, &dh);
+    if (rc) return rc;
+  }
+  EVT_REQUIRE(d->tok_map == nullptr || (d->groups_per_clip > 0 && d->clip_rows > 0 && d->pad_row), EVT_ERR_BAD_ARG,
+              "evt_softmax_gate: tok_map needs groups_per_clip, clip_rows and pad_row");
+  if (d->gated) {
+    EVT_REQUIRE(d->a_new && d->a_delta && d->idx && d->kcap >= 0, EVT_ERR_BAD_ARG, "evt_softmax_gate: gated mode needs a_new/a_delta/idx");
+  }
+  SmArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row,
+           d->tok_map ? d->groups_per_clip : 1, d->clip_rows,
+           d->a_state, d->a_new, d->a_delta, d->idx, d->count,
+           d->B, d->H, d->N, d->Nk, d->D, dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->gated};
+  const int64_t rows = (int64_t)d->B * d->H * d->N;
+  if (rows == 0) return EVT_OK;
+  const size_t lds = (size_t)4 * (a.Nk + a.dh + a.gh + a.gw) * sizeof(float);
+  EVT_REQUIRE(lds <= 160 * 1024, EVT_ERR_BAD_SHAPE, "evt_softmax_gate: row of %d keys does not fit LDS", d->Nk);
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t s = evt_stream(stream);
+  EVT_DISPATCH_STORE(d->store, T, {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_gate_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(softmax_gate_kernel<T>, grid, block, lds, s, a);
+  });
+  return evt_check_launch("evt_softmax_gate");
+}
+
+extern "C" int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D, int kcap,
+                          void* v_state, void* v_delta, void* v_old, int store, int gated, const int32_t* tok_map,
+                          int groups_per_clip, int clip_rows, const float* pad_row, void* stream) {
+  EVT_REQUIRE(qkv && v_state, EVT_ERR_BAD_ARG, "evt_v_gate: null pointer");
+  EVT_REQUIRE(B >= 0 && N > 0 && D > 0 && (D & 3) == 0, EVT_ERR_BAD_ARG, "evt_v_gate: bad sizes");
+  if (gated) EVT_REQUIRE(idx && v_delta && v_old && kcap >= 0 && tok_map == nullptr, EVT_ERR_BAD_ARG, "evt_v_gate: gated mode needs idx/v_delta/v_old and no tok_map");
+  EVT_REQUIRE(tok_map == nullptr || (groups_per_clip > 0 && clip_rows > 0 && pad_row), EVT_ERR_BAD_ARG,
+              "evt_v_gate: tok_map needs groups_per_clip, clip_rows and pad_row");
+  const int64_t n = (int64_t)B * (gated ? kcap : N) * (D / 4);
+  if (n == 0) return EVT_OK;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = evt_stream(stream);
+  EVT_DISPATCH_STORE(store, T, {
+    hipLaunchKernelGGL(v_gate_kernel<T>, grid, block, 0, s, qkv, idx, count, B, N, D, kcap, (T*)v_state, (T*)v_delta,
+                       (T*)v_old, gated, tok_map, tok_map ? groups_per_clip : 1, clip_rows, pad_row);
+  });
+  return evt_check_launch("evt_v_gate");
+}
+
+extern "C" int evt_av(const evt_av_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_av: null descriptor");
+  EVT_REQUIRE(d->a1 && d->v1, EVT_ERR_BAD_ARG, "evt_av: null a1/v1");
+  EVT_REQUIRE((d->a2 == nullptr) == (d->v2 == nullptr), EVT_ERR_BAD_ARG, "evt_av: a2/v2 must come together");
+  EVT_REQUIRE(d->pv || d->out_f32, EVT_ERR_BAD_ARG, "evt_av: no output");
+  EVT_REQUIRE(!d->gated || d->pv, EVT_ERR_BAD_ARG, "evt_av: gated mode accumulates into pv");
+  EVT_REQUIRE(d->B >= 0 && d->N > 0 && d->K >= 0 && d->lda >= d->K, EVT_ERR_BAD_ARG, "evt_av: bad sizes");
+  EVT_REQUIRE(d->out_map == nullptr || (d->groups_per_clip > 0 && d->clip_rows > 0 && d->out_f32), EVT_ERR_BAD_ARG,
+              "evt_av: out_map needs groups_per_clip, clip_rows and out_f32");
+  int dh;
+  int rc = check_heads("evt_av", d->D, d->H, &dh);
+  if (rc) return rc;
+  AvArgs a{d->a1, d->v1, d->a2, d->v2, d->lda, d->count, d->pv, d->out_f32, d->out_map,
+           d->out_map ? d->groups_per_clip : 1, d->clip_rows, d->B, d->H, d->N, d->K, d->D, dh, d->gated};
+  EVT_DISPATCH_STORE(d->store, T, { return launch_av<T>(a, stream); });
+  return EVT_OK;
+}

@@ -1,0 +1,94 @@
+// evt_common.h -- shared device/host helpers for libevt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/evt_abi.h"
+
+#define EVT_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host side: error reporting (thread-local, no allocation)
+// ---------------------------------------------------------------------------------------------
+char* evt_err_buf();
+int evt_fail(int code, const char* fmt, ...);
+int evt_check_launch(const char* what);
+
+#define EVT_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) return evt_fail((code), __VA_ARGS__); \
+  } while (0)
+
+static inline hipStream_t evt_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Storage types for tensors the reference keeps in the `matmul_2_cast` dtype (blocks.py:183-189).
+// Round-to-nearest-even on store, exact widening on load.
+struct bf16_t { uint16_t u; };
+struct f16_t { _Float16 h; };
+
+__device__ __forceinline__ float bf16_round_bits(float x, uint16_t* out) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) {  // NaN: keep quiet NaN
+    *out = (uint16_t)((u >> 16) | 0x40);
+    return x;
+  }
+  u += 0x7fffu + ((u >> 16) & 1u);
+  *out = (uint16_t)(u >> 16);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
+template <typename T> struct Store;
+template <> struct Store<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct Store<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return __uint_as_float(((uint32_t)p->u) << 16); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { uint16_t b; bf16_round_bits(v, &b); p->u = b; }
+  static __device__ __forceinline__ float round(float v) { uint16_t b; return bf16_round_bits(v, &b); }
+};
+template <> struct Store<f16_t> {
+  static __device__ __forceinline__ float load(const f16_t* p) { return (float)p->h; }
+  static __device__ __forceinline__ void store(f16_t* p, float v) { p->h = (_Float16)v; }
+  static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+};
+
+// Dispatch a callable templated on the storage type.
+#define EVT_DISPATCH_STORE(store, T, ...)                                  \
+  switch (store) {                                                          \
+    case EVT_F32: { typedef float T; __VA_ARGS__; } break;                  \
+    case EVT_BF16: { typedef bf16_t T; __VA_ARGS__; } break;                \
+    case EVT_F16: { typedef f16_t T; __VA_ARGS__; } break;                  \
+    default: return evt_fail(EVT_ERR_BAD_DTYPE, "unsupported store dtype %d", (int)(store)); \
+  }
+
+// Resolve a (group, token) pair of a window partition to a qkv-buffer row pointer (blocks.py:257-301).
+// tok_map == nullptr: identity (group == clip).  Negative map entry: padding row (qkv bias).
+__device__ __forceinline__ const float* evt_token_row(const float* qkv, int64_t row_stride, const int32_t* tok_map,
+                                                      int groups_per_clip, int clip_rows, const float* pad_row,
+                                                      int g, int t, int n_per_group) {
+  if (tok_map == nullptr) return qkv + ((int64_t)g * n_per_group + t) * row_stride;
+  int r = tok_map[(int64_t)(g % groups_per_clip) * n_per_group + t];
+  if (r < 0) return pad_row;
+  return qkv + ((int64_t)(g / groups_per_clip) * clip_rows + r) * row_stride;
+}

@@ -1,0 +1,222 @@
+// evt_linear.hip -- K3/K7: gated linear and gated MLP on the matrix cores.
+//
+//   out[orow(m), n] = act( sum_k A[arow(m), k] * W[n, k] + bias[n] )
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate; bitwise an fmaf chain), so fp32
+// activations agree with the reference's fp32 `addmm` to rounding-order noise (~1e-6).
+//
+// Tiling (64-wide wavefronts): 128x128 output tile per 256-thread workgroup, BK = 32; the four
+// waves form a 2x2 grid of 64x64 wave tiles, each a 2x2 grid of 32x32 MFMA accumulators
+// (64 accumulator registers per lane).  Both operands are K-contiguous in HBM (A rows are token
+// rows, W rows are output features), so both tiles are staged with 16-byte loads of whole 128-byte
+// row segments; the A row pointers go through the gate's index list, i.e. the gather of active
+// tokens happens while the tile is written into LDS and no compact copy of the rows ever exists.
+// LDS rows are padded to 36 floats: the 16 rows a ds_read_b128 lane group touches then start 36
+// banks apart and tile all 64 banks (conflict-free).  The MFMA k-index is permuted -- lane half
+// h reads k in [16h, 16h+16) as four b128 reads instead of sixteen strided b32 reads; a sum over k
+// does not care which k goes with which MFMA step as long as A and B agree.
+// Global->register prefetch of tile t+1 is issued before the MFMAs of tile t (one barrier per
+// k-tile, two LDS buffers).  The epilogue adds bias, applies exact-erf GELU if asked, and scatters
+// rows through o_idx (TokenBuffer update fused); column-block 0 also refreshes the gate reference
+// rows (p_upd) from the A tile it already holds.
+#include "evt_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDT: padded LDS row (floats)
+constexpr int GEMM_THREADS = 256;
+
+struct LinArgs {
+  const float* A; int64_t lda; const int32_t* a_idx; int a_rows;
+  const float* W; const float* bias;
+  float* out; int64_t ldo; const int32_t* o_idx; int o_rows;
+  const int32_t* count; float* p_upd;
+  int B, kcap, K, Nout, act;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int ACT>
+__global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
+  auto As = [&](int buf) { return lds + buf * (BM + BN) * LDT; };
+  auto Bs = [&](int buf) { return lds + buf * (BM + BN) * LDT + BM * LDT; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = g.B * g.kcap;
+
+  // ---- staging assignment: thread -> (row r0 + 32*j, 16-byte column c4) for j = 0..3
+  const int r0 = tid >> 3, c4 = tid & 7;
+  const float* a_ptr[4];
+  const float* w_ptr[4];
+  bool a_ok[4], w_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 32 * j;
+    a_ok[j] = false;
+    a_ptr[j] = g.A;
+    if (m < M) {
+      const int b = m / g.kcap, i = m - b * g.kcap;
+      if (g.count == nullptr || i < g.count[b]) {
+        const int src = (g.a_idx != nullptr) ? g.a_idx[m] : i;
+        a_ptr[j] = g.A + ((int64_t)b * g.a_rows + src) * g.lda;
+        a_ok[j] = true;
+      }
+    }
+    const int n = n0 + r0 + 32 * j;
+    w_ok[j] = n < g.Nout;
+    w_ptr[j] = g.W + (int64_t)(w_ok[j] ? n : 0) * g.K;
+  }
+
+  float4 ra[4], rw[4];
+  auto fetch = [&](int k0) {
+    const int kc = k0 + c4 * 4;
+    const bool kin = kc < g.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = (a_ok[j] && kin) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[j] = (w_ok[j] && kin) ? *reinterpret_cast<const float4*>(w_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<float4*>(As(buf) + (r0 + 32 * j) * LDT + c4 * 4) = ra[j];
+      *reinterpret_cast<float4*>(Bs(buf) + (r0 + 32 * j) * LDT + c4 * 4) = rw[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  fetch(0);
+  // Gate reference refresh (K2 fused): column-block 0 owns the full A rows over the k loop.
+  const bool do_upd = (g.p_upd != nullptr) && (blockIdx.x == 0);
+  float* u_ptr[4];
+  if (do_upd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
+  }
+  stage(0);
+  if (do_upd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (a_ok[j] && c4 * 4 < g.K) *reinterpret_cast<float4*>(u_ptr[j] + c4 * 4) = ra[j];
+  }
+  __syncthreads();
+
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) fetch((t + 1) * BK);
+    // fragments: 16 k-values per lane-half for 2 row-tiles of A and 2 row-tiles of B
+    float4 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* pa = As(cur) + (wm * 64 + i * 32 + lr) * LDT + lh * 16;
+      const float* pb = Bs(cur) + (wn * 64 + i * 32 + lr) * LDT + lh * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        fa[i][q] = *reinterpret_cast<const float4*>(pa + q * 4);
+        fb[i][q] = *reinterpret_cast<const float4*>(pb + q * 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = (e == 0) ? fa[i][q].x : (e == 1) ? fa[i][q].y : (e == 2) ? fa[i][q].z : fa[i][q].w;
+            const float bv = (e == 0) ? fb[j][q].x : (e == 1) ? fb[j][q].y : (e == 2) ? fb[j][q].z : fb[j][q].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    if (t + 1 < nk) {
+      stage(cur ^ 1);
+      if (do_upd) {
+        const int kc = (t + 1) * BK + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      const int b = m / g.kcap, ii = m - b * g.kcap;
+      if (g.count != nullptr && ii >= g.count[b]) continue;
+      const int dst = (g.o_idx != nullptr) ? g.o_idx[m] : ii;
+      float* orow = g.out + ((int64_t)b * g.o_rows + dst) * g.ldo;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lr;
+        if (n < g.Nout) {
+          float v = acc[i][j][r] + g.bias[n];
+          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+          orow[n] = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_linear(const LinArgs& a, void* stream) {
+  const int M = a.B * a.kcap;
+  if (M == 0) return EVT_OK;
+  const dim3 grid((a.Nout + BN - 1) / BN, (M + BM - 1) / BM), block(GEMM_THREADS);
+  if (a.act == EVT_ACT_GELU_ERF)
+    hipLaunchKernelGGL(gated_linear_kernel<EVT_ACT_GELU_ERF>, grid, block, 0, evt_stream(stream), a);
+  else
+    hipLaunchKernelGGL(gated_linear_kernel<EVT_ACT_NONE>, grid, block, 0, evt_stream(stream), a);
+  return evt_check_launch("evt_gated_linear");
+}
+
+}  // namespace
+
+extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_gated_linear: null descriptor");
+  EVT_REQUIRE(d->A && d->W && d->bias && d->out, EVT_ERR_BAD_ARG, "evt_gated_linear: null A/W/bias/out");
+  EVT_REQUIRE(d->B >= 0 && d->kcap >= 0 && d->K > 0 && d->Nout > 0, EVT_ERR_BAD_ARG, "evt_gated_linear: bad sizes");
+  EVT_REQUIRE((d->K & 3) == 0 && (d->lda & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_gated_linear: K=%d and lda must be multiples of 4", d->K);
+  EVT_REQUIRE(d->lda >= d->K && d->ldo >= d->Nout, EVT_ERR_BAD_ARG, "evt_gated_linear: leading dimension too small");
+  EVT_REQUIRE(d->act == EVT_ACT_NONE || d->act == EVT_ACT_GELU_ERF, EVT_ERR_BAD_ARG, "evt_gated_linear: act=%d", d->act);
+  EVT_REQUIRE(d->p_upd == nullptr || d->a_idx != nullptr, EVT_ERR_BAD_ARG, "evt_gated_linear: p_upd needs a_idx");
+  EVT_REQUIRE(d->a_rows > 0 && d->o_rows > 0, EVT_ERR_BAD_ARG, "evt_gated_linear: a_rows/o_rows must be positive");
+  LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
+            d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act};
+  return launch_linear(a, stream);
+}
+
+extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_gated_mlp: null descriptor");
+  EVT_REQUIRE(d->A && d->W1 && d->b1 && d->W2 && d->b2 && d->hidden && d->out, EVT_ERR_BAD_ARG, "evt_gated_mlp: null pointer");
+  EVT_REQUIRE(d->B >= 0 && d->kcap >= 0 && d->D > 0 && d->Dh > 0 && d->rows > 0, EVT_ERR_BAD_ARG, "evt_gated_mlp: bad sizes");
+  EVT_REQUIRE((d->D & 3) == 0 && (d->Dh & 3) == 0 && (d->lda & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_gated_mlp: D, Dh, lda must be multiples of 4");
+  EVT_REQUIRE(d->p_upd == nullptr || d->idx != nullptr, EVT_ERR_BAD_ARG, "evt_gated_mlp: p_upd needs idx");
+  LinArgs fc1{d->A, d->lda, d->idx, d->idx ? d->rows : d->kcap, d->W1, d->b1, d->hidden, (int64_t)d->Dh, nullptr,
+              d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF};
+  int rc = launch_linear(fc1, stream);
+  if (rc != EVT_OK) return rc;
+  LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, d->b2, d->out, d->ldo, d->idx,
+              d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE};
+  return launch_linear(fc2, stream);
+}

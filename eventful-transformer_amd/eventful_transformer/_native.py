@@ -1,0 +1,266 @@
+"""ctypes binding of libevt_hip.so (C ABI in include/evt_abi.h) + the scratch-tensor pool.
+
+PyTorch-ROCm is plumbing here: it owns device memory and the HIP stream; every kernel on the
+gated-token path is a hand-written gfx950 kernel reached through this module.  There is no CPU
+or ATen fallback for that path: if the library cannot be loaded, or a tensor is not on a HIP
+device, the call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevt_hip.so")
+
+EVT_F32, EVT_BF16, EVT_F16 = 0, 1, 2
+ACT_NONE, ACT_GELU = 0, 1
+
+_STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
+
+# Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
+ABI_SYMBOLS = (
+    "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
+    "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
+    "evt_gated_mlp", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av",
+)
+
+
+class LinearDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("a_idx", c_void_p), ("a_rows", c_int32),
+        ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
+        ("o_idx", c_void_p), ("o_rows", c_int32), ("count", c_void_p), ("p_upd", c_void_p),
+        ("B", c_int32), ("kcap", c_int32), ("K", c_int32), ("Nout", c_int32), ("act", c_int32),
+    ]
+
+
+class MlpDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("idx", c_void_p), ("rows", c_int32),
+        ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
+        ("hidden", c_void_p), ("out", c_void_p), ("ldo", c_int64), ("count", c_void_p),
+        ("p_upd", c_void_p), ("B", c_int32), ("kcap", c_int32), ("D", c_int32), ("Dh", c_int32),
+    ]
+
+
+class QkDesc(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("q_bs", c_int64), ("q_hs", c_int64), ("q_rs", c_int64),
+        ("k", c_void_p), ("k_bs", c_int64), ("k_hs", c_int64), ("k_rs", c_int64),
+        ("product", c_void_p),
+        ("idx_q", c_void_p), ("count_q", c_void_p), ("kcap_q", c_int32),
+        ("idx_k", c_void_p), ("count_k", c_void_p), ("kcap_k", c_int32),
+        ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("pad_q", c_void_p), ("pad_k", c_void_p),
+        ("G", c_int32), ("H", c_int32), ("Nq", c_int32), ("Nk", c_int32), ("dh", c_int32),
+        ("scale", c_float), ("delta", c_int32),
+    ]
+
+
+class SoftmaxDesc(Structure):
+    _fields_ = [
+        ("product", c_void_p), ("qkv", c_void_p), ("rel_y", c_void_p), ("rel_x", c_void_p),
+        ("gh", c_int32), ("gw", c_int32), ("tok_map", c_void_p), ("groups_per_clip", c_int32),
+        ("clip_rows", c_int32), ("pad_row", c_void_p), ("a_state", c_void_p), ("a_new", c_void_p),
+        ("a_delta", c_void_p), ("idx", c_void_p), ("count", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("Nk", c_int32), ("D", c_int32),
+        ("kcap", c_int32), ("store", c_int32), ("gated", c_int32),
+    ]
+
+
+class AvDesc(Structure):
+    _fields_ = [
+        ("a1", c_void_p), ("v1", c_void_p), ("a2", c_void_p), ("v2", c_void_p), ("lda", c_int64),
+        ("count", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("out_map", c_void_p),
+        ("groups_per_clip", c_int32), ("clip_rows", c_int32),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("K", c_int32), ("D", c_int32),
+        ("store", c_int32), ("gated", c_int32),
+    ]
+
+
+_lib = None
+
+
+def _bind(lib):
+    P, I, F = c_void_p, c_int, c_float
+    lib.evt_version.restype = c_int
+    lib.evt_last_error_string.restype = c_char_p
+    lib.evt_target_arch.restype = c_char_p
+    sigs = {
+        "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
+        "evt_select_topk": [P, I, I, I, P, P],
+        "evt_select_threshold": [P, I, I, F, I, P, P, P],
+        "evt_gate_gather_update": [P, P, P, P, I, I, I, I, P, P, I, P],
+        "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
+        "evt_gated_linear": [POINTER(LinearDesc), P],
+        "evt_gated_mlp": [POINTER(MlpDesc), P],
+        "evt_qk": [POINTER(QkDesc), P],
+        "evt_softmax_gate": [POINTER(SoftmaxDesc), P],
+        "evt_v_gate": [P, P, P, I, I, I, I, P, P, P, I, I, P, I, I, P, P],
+        "evt_av": [POINTER(AvDesc), P],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+
+
+def load():
+    """Loads libevt_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python eventful-transformer_amd/build.py` "
+                "(hipcc --offload-arch=gfx950).  The gated-token path has no non-HIP fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        _bind(lib)
+        _lib = lib
+    return _lib
+
+
+def is_loaded():
+    return _lib is not None
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().evt_last_error_string().decode()
+        raise RuntimeError(f"libevt_hip: {msg} (status {rc})")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_hip(*tensors):
+    """The product path only runs on a HIP device; fail loudly otherwise."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "eventful_transformer (MI355X build): tensors must live on a HIP device; there is no "
+                "CPU path in this package (the CPU oracle under oracle/ is test infrastructure only)."
+            )
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def store_code(dtype):
+    return _STORE_OF[dtype]
+
+
+# --------------------------------------------------------------------------------------------------
+# scratch pool: fixed-address work buffers shared by all blocks on a device (blocks run one after
+# another on one stream, so the hidden/ã/Δã/... scratch never needs to exist per block).
+# --------------------------------------------------------------------------------------------------
+_pool = {}
+
+
+def scratch(name, shape, dtype, device):
+    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device())
+    t = _pool.get(key)
+    if t is None:
+        t = torch.empty(tuple(shape), dtype=dtype, device=device)
+        _pool[key] = t
+    return t
+
+
+def clear_scratch():
+    _pool.clear()
+
+
+# --------------------------------------------------------------------------------------------------
+# thin wrappers (argument checking beyond dtype/contiguity lives in the C library)
+# --------------------------------------------------------------------------------------------------
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} strides {t.stride()}")
+    return t
+
+
+def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=None, eps=1e-6, c_out=None, p=None,
+             norms=None):
+    _check(load().evt_row_pass(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
+                               _p(norms), rows, D, _stream()))
+
+
+def select_topk(norms, B, N, k, idx):
+    _check(load().evt_select_topk(_p(norms), B, N, k, _p(idx), _stream()))
+
+
+def select_threshold(norms, B, N, threshold, kcap, idx, count):
+    _check(load().evt_select_threshold(_p(norms), B, N, float(threshold), kcap, _p(idx), _p(count), _stream()))
+
+
+def gate_gather_update(c, p, idx, count, B, N, D, kcap, c_tilde=None, e_tilde=None, update_p=True):
+    _check(load().evt_gate_gather_update(_p(c), _p(p), _p(idx), _p(count), B, N, D, kcap, _p(c_tilde), _p(e_tilde),
+                                         int(update_p), _stream()))
+
+
+def scatter_rows(x, buf, idx, count, B, N, F, kcap):
+    _check(load().evt_scatter_rows(_p(x), _p(buf), _p(idx), _p(count), B, N, F, kcap, _stream()))
+
+
+def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE):
+    d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
+                   _p(p_upd), B, kcap, K, Nout, act)
+    _check(load().evt_gated_linear(ctypes.byref(d), _stream()))
+
+
+def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh):
+    d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
+                _p(p_upd), B, kcap, D, Dh)
+    _check(load().evt_gated_mlp(ctypes.byref(d), _stream()))
+
+
+def _ptr_off(t, elems):
+    return c_void_p(t.data_ptr() + 4 * elems)
+
+
+def qk_packed(qkv, B, N, D, H, scale, product, idx=None, count=None, kcap=0, tok_map=None, groups_per_clip=1,
+              clip_rows=0, pad_row=None):
+    """K4 on the packed (B, rows, 3D) token buffer; idx given -> delta update of rows+columns idx."""
+    dh = D // H
+    rows = clip_rows if tok_map is not None else N
+    G = B
+    d = QkDesc(_p(qkv), rows * 3 * D, dh, 3 * D, _ptr_off(qkv, D), rows * 3 * D, dh, 3 * D, _p(product),
+               _p(idx), _p(count), kcap, _p(idx), _p(count), kcap, _p(tok_map), groups_per_clip,
+               _p(pad_row), None if pad_row is None else _ptr_off(pad_row, D), G, H, N, N, dh, float(scale),
+               int(idx is not None))
+    _check(load().evt_qk(ctypes.byref(d), _stream()))
+
+
+def qk_strided(q, k, product, scale, idx_q=None, count_q=None, kcap_q=0, idx_k=None, count_k=None, kcap_k=0):
+    """K4 on free-standing contiguous q (B,H,Nq,dh) and k (B,H,Nk,dh) tensors."""
+    B, H, Nq, dh = q.shape
+    Nk = k.shape[2]
+    d = QkDesc(_p(q), H * Nq * dh, Nq * dh, dh, _p(k), H * Nk * dh, Nk * dh, dh, _p(product),
+               _p(idx_q), _p(count_q), kcap_q, _p(idx_k), _p(count_k), kcap_k, None, 1, None, None,
+               B, H, Nq, Nk, dh, float(scale), int(idx_q is not None))
+    _check(load().evt_qk(ctypes.byref(d), _stream()))
+
+
+def softmax_gate(product, a_state, B, H, N, Nk, D, store, qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, tok_map=None,
+                 groups_per_clip=1, clip_rows=0, pad_row=None, a_new=None, a_delta=None, idx=None, count=None, kcap=0,
+                 gated=False):
+    d = SoftmaxDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(tok_map), groups_per_clip, clip_rows,
+                    _p(pad_row), _p(a_state), _p(a_new), _p(a_delta), _p(idx), _p(count), B, H, N, Nk, D, kcap, store,
+                    int(gated))
+    _check(load().evt_softmax_gate(ctypes.byref(d), _stream()))
+
+
+def v_gate(qkv, idx, count, B, N, D, kcap, v_state, v_delta, v_old, store, gated, tok_map=None, groups_per_clip=1,
+           clip_rows=0, pad_row=None):
+    _check(load().evt_v_gate(_p(qkv), _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta), _p(v_old), store,
+                             int(gated), _p(tok_map), groups_per_clip, clip_rows, _p(pad_row), _stream()))
+
+
+def av(a1, v1, lda, B, H, N, K, D, store, pv=None, out_f32=None, a2=None, v2=None, count=None, gated=False,
+       out_map=None, groups_per_clip=1, clip_rows=0):
+    d = AvDesc(_p(a1), _p(v1), _p(a2), _p(v2), lda, _p(count), _p(pv), _p(out_f32), _p(out_map), groups_per_clip,
+               clip_rows, B, H, N, K, D, store, int(gated))
+    _check(load().evt_av(ctypes.byref(d), _stream()))

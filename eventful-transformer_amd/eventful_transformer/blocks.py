@@ -1,0 +1,465 @@
+"""Transformer blocks (API of the reference's blocks.py) driving the gfx950 kernels.
+
+Class names, constructor kwargs, sub-module attribute names and state_dict keys are the
+reference's (blocks.py:35-47,404), because `ViTBackbone` instantiates blocks by
+class NAME from a config string (backbones.py:46-59) and checkpoints are loaded by key.
+
+Each forward is a fixed sequence of C-ABI calls on the current HIP stream -- no host sync, no
+shape-dependent allocation after the first frame of a clip except the returned tensor:
+
+  frame t >= 1, EventfulBlock                                        kernel
+  ---------------------------------------------------------------   -------------------------------
+  [+pos-enc] LN1 + ||c - p||                                          K1a  evt_row_pass
+  top-k / threshold                                                   K1   evt_select_*
+  QKV on gathered rows -> qkv buffer rows, refresh p                  K3   evt_gated_linear
+  q.k^T state: rows + cols idx                                        K4   evt_qk
+  [rel-pos] softmax, gather cols idx, A delta gate                    K5   evt_softmax_gate
+  v delta gate                                                        K6a  evt_v_gate
+  A.v state += a~.dv~ + da~.v_old ; merge heads                       K6   evt_av
+  ||attn - p||, select, projection -> buffer rows                     K1a, K1, K3
+  +skip, LN2 + ||c - p||, select                                      K1a, K1
+  MLP on gathered rows -> buffer rows                                 K7   evt_gated_mlp
+  +skip                                                               K1a
+
+Per-clip state lives on the gate / buffer sub-modules under the reference's attribute names
+(`qkv_gate.p`, `qkv_accumulator.b`, `matmul_accumulator_1.product`, ...), so `reset()` and state
+inspection work as in the reference.  Not implemented yet (SURVEY.md §8f "next"): `ats_fraction`
+(adaptive token sampling) and `pool_size` (K/V pooling); both raise at construction.
+"""
+from math import prod, sqrt
+
+import torch
+import torch.nn as nn
+
+from eventful_transformer import _native
+from eventful_transformer.base import ExtendedModule, numeric_tuple
+from eventful_transformer.counting import CountedAdd, CountedLinear, CountedMatmul
+from eventful_transformer.modules import (
+    MatmulBuffer,
+    MatmulDeltaAccumulator,
+    SimpleSTGTGate,
+    TokenBuffer,
+    TokenDeltaGate,
+    TokenGate,
+)
+from eventful_transformer.policies import _NormPolicy
+from eventful_transformer.utils import DropPath, RelativePositionEmbedding
+
+LN_EPS = 1e-6
+
+
+def _window_map(input_size, window_size, device):
+    """(windows, window_len) int32: clip-row index of each window token, -1 for padding.
+
+    Window order and in-window order follow Block._partition_windows of the reference
+    (blocks.py:257-301): windows row-major over the padded grid, tokens row-major inside a window."""
+    h, w = input_size
+    d0, d1 = window_size
+    th, tw = h + (-h % d0), w + (-w % d1)
+    ys = torch.arange(th).view(th // d0, 1, d0, 1)
+    xs = torch.arange(tw).view(1, tw // d1, 1, d1)
+    rows = torch.where((ys < h) & (xs < w), ys * w + xs, torch.full((1,), -1, dtype=torch.long))
+    return rows.reshape(-1, d0 * d1).to(device=device, dtype=torch.int32).contiguous()
+
+
+class Block(ExtendedModule):
+    """Dense pre-LN Transformer block (blocks.py:26-137): LN -> QKV -> MHSA (optionally windowed
+    and/or with decomposed relative position) -> projection -> +skip -> LN -> MLP(GELU) -> +skip."""
+
+    def __init__(self, dim, heads, input_size, mlp_ratio, ats_fraction=None, drop_path_rate=0.0,
+                 relative_embedding_size=None, matmul_2_cast=None, pool_size=None, window_size=None):
+        super().__init__()
+        if ats_fraction is not None:
+            raise NotImplementedError("ats_fraction (adaptive token sampling) is not built yet in the MI355X path")
+        if pool_size is not None:
+            raise NotImplementedError("pool_size (K/V token pooling) is not built yet in the MI355X path")
+        assert not (drop_path_rate < 0.0 or drop_path_rate > 1.0)
+        assert matmul_2_cast in [None, "float16", "bfloat16"]
+        self.dim = dim
+        self.heads = heads
+        self.input_size = tuple(input_size)
+        self.ats_fraction = None
+        self.last_ats_indices = None
+        self.matmul_2_cast = matmul_2_cast
+        self.pool_size = None
+        if window_size is None:
+            self.window_size = None
+            attention_size = self.input_size
+        else:
+            self.window_size = numeric_tuple(window_size, length=2)
+            attention_size = self.window_size
+            if relative_embedding_size is not None:
+                relative_embedding_size = self.window_size  # blocks.py:90-91
+        self.scale = sqrt(dim // heads)
+
+        self.input_layer_norm = nn.LayerNorm(dim, eps=LN_EPS)
+        self.qkv = CountedLinear(in_features=dim, out_features=dim * 3)
+        self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
+        if relative_embedding_size is not None:
+            self.relative_position = RelativePositionEmbedding(attention_size, relative_embedding_size, dim // heads,
+                                                               pool_size=None)
+        else:
+            self.relative_position = None
+        self.matmul = CountedMatmul()
+        self.projection = CountedLinear(in_features=dim, out_features=dim)
+        self.add = CountedAdd()
+        self.mlp_layer_norm = nn.LayerNorm(dim, eps=LN_EPS)
+        self.mlp_1 = CountedLinear(in_features=dim, out_features=dim * mlp_ratio)
+        self.gelu = nn.GELU()
+        self.mlp_2 = CountedLinear(in_features=dim * mlp_ratio, out_features=dim)
+        self._wmap = None
+
+    # ---------------------------------------------------------------------------------------------
+    # helpers shared by all block classes
+    # ---------------------------------------------------------------------------------------------
+    def reset_self(self):
+        self.last_ats_indices = None
+
+    def _store_dtype(self):
+        return torch.float32 if self.matmul_2_cast is None else getattr(torch, self.matmul_2_cast)
+
+    def _check_input(self, x):
+        _native.require_hip(x)
+        if self.training and isinstance(self.drop_path, DropPath):
+            raise RuntimeError("MI355X path is inference-only: call .eval() (DropPath is train-time only)")
+        if x.ndim != 3 or x.shape[-1] != self.dim:
+            raise RuntimeError(f"block input must be (batch, tokens, {self.dim}), got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"block input must be float32, got {x.dtype}")
+        return x if x.is_contiguous() else x.contiguous()
+
+    def _compute_window_padding(self):
+        return (-self.input_size[0] % self.window_size[0], -self.input_size[1] % self.window_size[1])
+
+    def _windows(self, device):
+        if self._wmap is None or self._wmap.device != device:
+            self._wmap = _window_map(self.input_size, self.window_size, device)
+        return self._wmap
+
+    def _rel_tables(self):
+        if self.relative_position is None:
+            return None, None, 0, 0
+        ry, rx = self.relative_position.tables()
+        return ry, rx, ry.shape[0], rx.shape[0]
+
+    def _ws(self, name, shape, dtype, x):
+        return _native.scratch(name, shape, dtype, x.device)
+
+    def _count_add(self, n):
+        if self.add.count_mode:
+            self.add.counts["add_flops"] += n
+
+    def _ln(self, which):
+        ln = self.input_layer_norm if which == 1 else self.mlp_layer_norm
+        return ln.weight, ln.bias
+
+    # -- dense attention (also the windowed attention of ViTDet's EventfulTokenwiseBlocks) -----------
+    def _attention_dense(self, qkv, B, N, out):
+        """qkv (B,N,3D) -> out (B,N,D) fp32.  Block._forward_attention (blocks.py:205-240)."""
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        ry, rx, gh, gw = self._rel_tables()
+        if self.window_size is None:
+            G, n, tok_map, gpc, pad = B, N, None, 1, None
+        else:
+            tok_map = self._windows(qkv.device)
+            gpc, n = tok_map.shape
+            G, pad = B * gpc, self.qkv.bias
+            assert prod(self.input_size) == N, "windowed attention needs tokens == prod(input_size)"
+        prod_s = self._ws("attn_scores", (G, H, n, n), torch.float32, qkv)
+        a_s = self._ws("attn_probs", (G, H, n, n), sdt, qkv)
+        v_s = self._ws("attn_values", (G, n, D), sdt, qkv)
+        _native.qk_packed(qkv, G, n, D, H, self.scale, prod_s, tok_map=tok_map, groups_per_clip=gpc, clip_rows=N,
+                          pad_row=pad)
+        self.matmul.count_product(G * H * n * n, dh)
+        if self.relative_position is not None:
+            self.relative_position.count_fused(G, H)
+        _native.softmax_gate(prod_s, a_s, G, H, n, n, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
+                             tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
+        _native.v_gate(qkv, None, None, G, n, D, 0, v_s, None, None, store, False, tok_map=tok_map,
+                       groups_per_clip=gpc, clip_rows=N, pad_row=pad)
+        _native.av(a_s, v_s, n, G, H, n, n, D, store, out_f32=out, out_map=tok_map, groups_per_clip=gpc, clip_rows=N)
+        self.matmul.count_product(G * H * n * dh, n)
+
+    def _dense_tail(self, attn, skip, B, N):
+        """projection + skip + LN2 + MLP + skip over all tokens (Block.forward, blocks.py:127-137)."""
+        D, rows = self.dim, B * N
+        proj = self._ws("dense_proj", (B, N, D), torch.float32, attn)
+        _native.gated_linear(attn, D, None, rows, self.projection.weight, self.projection.bias, proj, D, None, rows,
+                             None, None, 1, rows, D, D)
+        self.projection.count_rows(rows)
+        x2 = self._ws("x_mid", (B, N, D), torch.float32, attn)
+        c = self._ws("gate_in", (B, N, D), torch.float32, attn)
+        w, b = self._ln(2)
+        _native.row_pass(proj, rows, D, res=skip, sum_out=x2, ln_w=w, ln_b=b, eps=LN_EPS, c_out=c)
+        self._count_add(rows * D)
+        Dh = self.mlp_1.out_features
+        hidden = self._ws("mlp_hidden", (rows, Dh), torch.float32, attn)
+        mlp = self._ws("dense_mlp", (B, N, D), torch.float32, attn)
+        _native.gated_mlp(c, D, None, rows, self.mlp_1.weight, self.mlp_1.bias, self.mlp_2.weight, self.mlp_2.bias,
+                          hidden, mlp, D, None, None, 1, rows, D, Dh)
+        self.mlp_1.count_rows(rows)
+        self.mlp_2.count_rows(rows)
+        out = torch.empty((B, N, D), dtype=torch.float32, device=attn.device)
+        _native.row_pass(mlp, rows, D, res=x2, sum_out=out)
+        self._count_add(rows * D)
+        return out
+
+    def forward(self, x):
+        x = self._check_input(x)
+        B, N, D = x.shape
+        rows = B * N
+        c = self._ws("gate_in", (B, N, D), torch.float32, x)
+        w, b = self._ln(1)
+        _native.row_pass(x, rows, D, ln_w=w, ln_b=b, eps=LN_EPS, c_out=c)
+        qkv = self._ws("dense_qkv", (B, N, 3 * D), torch.float32, x)
+        _native.gated_linear(c, D, None, rows, self.qkv.weight, self.qkv.bias, qkv, 3 * D, None, rows, None, None, 1,
+                             rows, D, 3 * D)
+        self.qkv.count_rows(rows)
+        attn = self._ws("attn_out", (B, N, D), torch.float32, x)
+        self._attention_dense(qkv, B, N, attn)
+        return self._dense_tail(attn, x, B, N)
+
+
+class EventfulTokenwiseBlock(Block):
+    """Block with gated token-wise operations: three gate -> op -> buffer groups around QKV,
+    projection and MLP (blocks.py:399-463).  Attention itself stays dense (and may be windowed)."""
+
+    def __init__(self, gate_before_ln=False, stgt=False, **super_kwargs):
+        super().__init__(**super_kwargs)
+        self.gate_before_ln = gate_before_ln
+        token_gate_class = SimpleSTGTGate if stgt else TokenGate
+        self.qkv_gate = token_gate_class()
+        self.qkv_accumulator = TokenBuffer()
+        self.projection_gate = token_gate_class()
+        self.projection_accumulator = TokenBuffer()
+        self.mlp_gate = token_gate_class()
+        self.mlp_accumulator = TokenBuffer()
+
+    # ---------------------------------------------------------------------------------------------
+    # one gate -> linear(s) -> buffer group
+    # ---------------------------------------------------------------------------------------------
+    def _select(self, gate, c, norms, B, N, tag):
+        """Runs the gate's policy on the norms already produced by the row pass."""
+        policy = gate.policy
+        if isinstance(policy, _NormPolicy):
+            cap = policy.capacity(N)
+            idx = self._ws("idx_" + tag, (B, cap), torch.int32, c)
+            count = None if policy.fixed_count(N) is not None else self._ws("cnt_" + tag, (B,), torch.int32, c)
+            policy.select_into(norms, B, N, idx, count)
+            return idx, count, cap
+        # Any other callable gets the delta tensor like in the reference (modules.py:149).
+        index = policy(c - gate.p, dim=-1)
+        idx = index.reshape(B, -1).to(torch.int32).contiguous()
+        return idx, None, idx.shape[1]
+
+    def _count_gate(self, gate, n):
+        if gate.count_mode:
+            gate.counts["gate_flops"] += n
+
+    def _n_rows(self, B, cap, count):
+        """Gated row total for MAC accounting (one readback, counting mode only)."""
+        return B * cap if count is None else int(count.sum().item())
+
+    def _group(self, gate, buffer, src, res, ln, linear_fn, out_features, tag, sum_out=None):
+        """Generic gate group.  src (+res) -> [LN] -> gate -> linear_fn on gated rows -> buffer rows.
+
+        Returns (buffer state, idx, count, cap); idx is None on the first frame of a clip."""
+        B, N, D = src.shape
+        rows = B * N
+        stgt = isinstance(gate, SimpleSTGTGate)
+        ln_w, ln_b = (None, None) if ln is None else self._ln(ln)
+        if res is not None:
+            self._count_add(rows * D)
+        if gate.first:
+            gate.first = False
+            buffer.first = False
+            gate.p = torch.empty((B, N, D), dtype=torch.float32, device=src.device)
+            buffer.b = torch.empty((B, N, out_features), dtype=torch.float32, device=src.device)
+            if self.gate_before_ln and ln is not None:
+                # reference: p = x (pre-LN), the linear sees LN(x)
+                c = self._ws("gate_in", (B, N, D), torch.float32, src)
+                _native.row_pass(src, rows, D, res=res, sum_out=gate.p)
+                if sum_out is not None:
+                    sum_out.copy_(gate.p)
+                _native.row_pass(gate.p, rows, D, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c)
+                a = c
+            else:
+                _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=gate.p)
+                a = gate.p
+            linear_fn(a, None, None, buffer.b, None, B, N)
+            return buffer.b, None, None, N
+
+        c = self._ws("gate_in", (B, N, D), torch.float32, src)
+        norms = self._ws("gate_norms", (B, N), torch.float32, src)
+        self._count_gate(gate, rows * D)
+        if self.gate_before_ln and ln is not None:
+            raw = self._ws("gate_raw", (B, N, D), torch.float32, src)
+            _native.row_pass(src, rows, D, res=res, sum_out=sum_out, c_out=raw, p=gate.p, norms=norms)
+            idx, count, cap = self._select(gate, raw, norms, B, N, tag)
+            _native.row_pass(raw, rows, D, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c)
+            if stgt:
+                _native.row_pass(raw, rows, D, c_out=gate.p)
+            else:
+                _native.gate_gather_update(raw, gate.p, idx, count, B, N, D, cap, update_p=True)
+            linear_fn(c, idx, count, buffer.b, None, B, cap)
+        else:
+            if ln is None and res is None:
+                c = src  # the gate input already exists in HBM: only the norms are new
+                _native.row_pass(src, rows, D, p=gate.p, norms=norms)
+            else:
+                _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
+                                 p=gate.p, norms=norms)
+            idx, count, cap = self._select(gate, c, norms, B, N, tag)
+            linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap)
+            if stgt:
+                _native.row_pass(c, rows, D, c_out=gate.p)
+        return buffer.b, idx, count, cap
+
+    def _linear_fn(self, layer):
+        def run(a, idx, count, out, p_upd, B, cap):
+            N = out.shape[1]
+            _native.gated_linear(a, layer.in_features, idx, N if idx is not None else cap, layer.weight, layer.bias,
+                                 out, layer.out_features, idx, N if idx is not None else cap, count, p_upd, B, cap,
+                                 layer.in_features, layer.out_features)
+            if layer.count_mode:
+                layer.count_rows(self._n_rows(B, cap, count))
+        return run
+
+    def _mlp_fn(self, a, idx, count, out, p_upd, B, cap):
+        N = out.shape[1]
+        D, Dh = self.dim, self.mlp_1.out_features
+        hidden = self._ws("mlp_hidden", (B * cap, Dh), torch.float32, a)
+        _native.gated_mlp(a, D, idx, N if idx is not None else cap, self.mlp_1.weight, self.mlp_1.bias,
+                          self.mlp_2.weight, self.mlp_2.bias, hidden, out, D, count, p_upd, B, cap, D, Dh)
+        if self.mlp_1.count_mode:
+            n = self._n_rows(B, cap, count)
+            self.mlp_1.count_rows(n)
+            self.mlp_2.count_rows(n)
+
+    # ---------------------------------------------------------------------------------------------
+    def _forward_pre_attention(self, x):
+        """LN1 -> qkv gate -> QKV -> qkv buffer (blocks.py:452-463 + :491)."""
+        return self._group(self.qkv_gate, self.qkv_accumulator, x, None, 1, self._linear_fn(self.qkv), 3 * self.dim,
+                           "qkv")
+
+    def _forward_post_attention(self, attn, skip):
+        """projection group, +skip, LN2, mlp group, +skip (blocks.py:430-450)."""
+        B, N, D = attn.shape
+        proj, _, _, _ = self._group(self.projection_gate, self.projection_accumulator, attn, None, None,
+                                    self._linear_fn(self.projection), D, "projection")
+        x2 = self._ws("x_mid", (B, N, D), torch.float32, attn)
+        mlp, _, _, _ = self._group(self.mlp_gate, self.mlp_accumulator, proj, skip, 2, self._mlp_fn, D, "mlp",
+                                   sum_out=x2)
+        out = torch.empty((B, N, D), dtype=torch.float32, device=attn.device)
+        _native.row_pass(mlp, B * N, D, res=x2, sum_out=out)
+        self._count_add(B * N * D)
+        return out
+
+    def _forward_attention(self, qkv, idx, count, cap, B, N):
+        attn = self._ws("attn_out", (B, N, self.dim), torch.float32, qkv)
+        self._attention_dense(qkv, B, N, attn)
+        return attn
+
+    def forward(self, x):
+        x = self._check_input(x)
+        B, N, _ = x.shape
+        qkv, idx, count, cap = self._forward_pre_attention(x)
+        attn = self._forward_attention(qkv, idx, count, cap, B, N)
+        return self._forward_post_attention(attn, x)
+
+
+class EventfulMatmul1Block(EventfulTokenwiseBlock):
+    """EventfulTokenwiseBlock + gated query-key product (blocks.py:466-540)."""
+
+    def __init__(self, **super_kwargs):
+        super().__init__(**super_kwargs)
+        assert self.window_size is None  # blocks.py:485
+        self.matmul_accumulator_1 = MatmulBuffer()
+
+    def _scores(self, qkv, idx, count, cap, B, N):
+        """q.k^T state update (K4).  Returns the (B,H,N,N) fp32 product state."""
+        D, H = self.dim, self.heads
+        acc = self.matmul_accumulator_1
+        if acc.first:
+            acc.first = False
+            acc.product = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product)
+            acc.matmul.count_product(B * H * N * N, D // H)
+        else:
+            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, idx=idx, count=count, kcap=cap)
+            if acc.matmul.count_mode:
+                acc.matmul.count_product(2 * H * N * self._n_rows(B, cap, count), D // H)
+        if self.relative_position is not None:
+            self.relative_position.count_fused(B, H)
+        return acc.product
+
+    def _forward_attention(self, qkv, idx, count, cap, B, N):
+        D, H = self.dim, self.heads
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        product = self._scores(qkv, idx, count, cap, B, N)
+        ry, rx, gh, gw = self._rel_tables()
+        a_s = self._ws("attn_probs", (B, H, N, N), sdt, qkv)
+        v_s = self._ws("attn_values", (B, N, D), sdt, qkv)
+        _native.softmax_gate(product, a_s, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
+        _native.v_gate(qkv, None, None, B, N, D, 0, v_s, None, None, store, False)
+        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+        _native.av(a_s, v_s, N, B, H, N, N, D, store, out_f32=attn)
+        self.matmul.count_product(B * H * N * (D // H), N)
+        return attn
+
+
+class EventfulBlock(EventfulMatmul1Block):
+    """EventfulMatmul1Block + gated attention-value product (blocks.py:543-575)."""
+
+    def __init__(self, **super_kwargs):
+        super().__init__(**super_kwargs)
+        self.v_gate = TokenDeltaGate()
+        self.matmul_gate = TokenDeltaGate(structure="col")
+        self.matmul_accumulator_2 = MatmulDeltaAccumulator()
+
+    def _forward_attention(self, qkv, idx, count, cap, B, N):
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        product = self._scores(qkv, idx, count, cap, B, N)
+        ry, rx, gh, gw = self._rel_tables()
+        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+        vg, ag, acc = self.v_gate, self.matmul_gate, self.matmul_accumulator_2
+        if acc.first:
+            vg.first = ag.first = acc.first = False
+            ag.p = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
+            vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            acc._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            # head-split views with the reference's logical shapes (B,H,N,dh)
+            vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
+            _native.v_gate(qkv, None, None, B, N, D, 0, vg._state, None, None, store, False)
+            _native.av(ag.p, vg._state, N, B, H, N, N, D, store, pv=acc._state, out_f32=attn)
+            acc.matmul.count_product(B * H * N * dh, N)
+            return attn
+        a_new = self._ws("a_new", (B, H, N, cap), sdt, qkv)
+        a_delta = self._ws("a_delta", (B, H, N, cap), sdt, qkv)
+        v_delta = self._ws("v_delta", (B, cap, D), sdt, qkv)
+        v_old = self._ws("v_old", (B, cap, D), sdt, qkv)
+        _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
+                             a_new=a_new, a_delta=a_delta, idx=idx, count=count, kcap=cap, gated=True)
+        _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True)
+        _native.av(a_new, v_delta, cap, B, H, N, cap, D, store, pv=acc._state, out_f32=attn, a2=a_delta, v2=v_old,
+                   count=count, gated=True)
+        if self.count_mode or acc.count_mode or vg.count_mode:
+            n = self._n_rows(B, cap, count)
+            self._count_gate(vg, B * N * D)
+            self._count_gate(ag, B * H * N * N)
+            if acc.count_mode:
+                acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
+            acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+        return attn
+
+    def reset_self(self):
+        super().reset_self()

@@ -33,6 +33,13 @@ extern "C" {
 
 #define EVT_ABI_VERSION 1
 
+/* Exported symbols (the library is built with -fvisibility=hidden). */
+#if defined(__GNUC__)
+#define EVT_API __attribute__((visibility("default")))
+#else
+#define EVT_API
+#endif
+
 typedef enum evt_status {
   EVT_OK = 0,
   EVT_ERR_BAD_ARG = -1,     /* null pointer, non-positive size, unsupported combination       */
@@ -45,25 +52,26 @@ typedef enum evt_dtype { EVT_F32 = 0, EVT_BF16 = 1, EVT_F16 = 2 } evt_dtype;
 
 typedef enum evt_act { EVT_ACT_NONE = 0, EVT_ACT_GELU_ERF = 1 } evt_act;
 
-int evt_version(void);
-const char* evt_last_error_string(void);
+EVT_API int evt_version(void);
+EVT_API const char* evt_last_error_string(void);
 /* Compile-time target of the embedded code object, e.g. "gfx950". */
-const char* evt_target_arch(void);
+EVT_API const char* evt_target_arch(void);
 
 /* ------------------------------------------------------------------------------------------ *
  * K0/K1a  Row pass: [residual add] -> [LayerNorm] -> [delta-norm against a gate reference].
  *
- *   s = x (+ res)                         written to sum_out   if non-null
+ *   s = x (+ res[row % res_rows])         written to sum_out   if non-null  (res_rows == 0: res[row];
+ *                                         res_rows == N broadcasts a (1,N,D) position encoding)
  *   c = ln_w ? LN(s; ln_w, ln_b, eps) : s written to c_out     if non-null
- *   norms[row] = || c - p[row] ||_2       written to norms     if p and norms non-null
+ *   norms[row] = || c - p[row] ||_2       written to norms     if non-null  (p == NULL: || c ||_2)
  *
  * Replaces: nn.LayerNorm (blocks.py:460,444; eps 1e-6 at blocks.py:23), CountedAdd residual
- * (blocks.py:436,448), and `c - self.p` + `vector_norm` of the gate/policy
+ * (blocks.py:436,448; position encoding utils.py:66), and `c - self.p` + `vector_norm` of the gate/policy
  * (modules.py:149, policies.py:63 / :28).  rows = B*N, D % 4 == 0, D <= 4096.
  * ------------------------------------------------------------------------------------------ */
-int evt_row_pass(const float* x, const float* res, float* sum_out,
-                 const float* ln_w, const float* ln_b, float eps, float* c_out,
-                 const float* p, float* norms, int rows, int D, void* stream);
+EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* sum_out,
+                         const float* ln_w, const float* ln_b, float eps, float* c_out,
+                         const float* p, float* norms, int rows, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K1  Token selection from per-token delta norms.  One workgroup per clip; norms staged in LDS;
@@ -77,8 +85,8 @@ int evt_row_pass(const float* x, const float* res, float* sum_out,
  *   (policies.py:28-32, a host sync in the reference).  kcap (row stride of idx) must be >= N.
  * N <= 16384.
  * ------------------------------------------------------------------------------------------ */
-int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, void* stream);
-int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap,
+EVT_API int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, void* stream);
+EVT_API int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap,
                          int32_t* idx, int32_t* count, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
@@ -89,13 +97,13 @@ int evt_select_threshold(const float* norms, int B, int N, float threshold, int 
  * Replaces gather + scatter_ of TokenGate/TokenDeltaGate.forward_incremental
  * (modules.py:150-152, 196-200).  c, p: (B,N,D); c_tilde/e_tilde: (B,kcap,D).  D % 4 == 0.
  * ------------------------------------------------------------------------------------------ */
-int evt_gate_gather_update(const float* c, float* p, const int32_t* idx, const int32_t* count,
+EVT_API int evt_gate_gather_update(const float* c, float* p, const int32_t* idx, const int32_t* count,
                            int B, int N, int D, int kcap, float* c_tilde, float* e_tilde,
                            int update_p, void* stream);
 
 /* TokenBuffer incremental update for callers that already hold compact rows:
  *   b[b, idx[b,i], :] = x[b,i,:]   (modules.py:86-97, structure="row").  F % 4 == 0. */
-int evt_scatter_rows(const float* x, float* buf, const int32_t* idx, const int32_t* count,
+EVT_API int evt_scatter_rows(const float* x, float* buf, const int32_t* idx, const int32_t* count,
                      int B, int N, int F, int kcap, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
@@ -123,7 +131,7 @@ typedef struct evt_linear_desc {
   int32_t act;                             /* evt_act                                           */
 } evt_linear_desc;
 
-int evt_gated_linear(const evt_linear_desc* d, void* stream);
+EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
 
 /* K7  Gated MLP: hidden = GELU(A[rows].W1^T + b1) -> out[rows] = hidden.W2^T + b2, as two MFMA
  * launches sharing one compact `hidden` scratch (B*kcap, Dh) provided by the caller.
@@ -139,26 +147,38 @@ typedef struct evt_mlp_desc {
   int32_t B, kcap, D, Dh;
 } evt_mlp_desc;
 
-int evt_gated_mlp(const evt_mlp_desc* d, void* stream);
+EVT_API int evt_gated_mlp(const evt_mlp_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
- * K4  q.k^T product state.  qkv: (B, Nq, 3D) token buffer laid out [q heads | k heads | v heads]
- *     (blocks.py:248-255); product: (B, H, Nq, Nk) fp32; scale = sqrt(D/H) applied to q.
- *   evt_qk_full : product = (q/scale) k^T                       (MatmulBuffer.forward_first,
- *                 modules.py:224-230)
- *   evt_qk_delta: rows idx <- (q/scale)[idx] k^T, then columns idx <- (q/scale) k[idx]^T, both
- *                 from the already-updated buffer (modules.py:232-248).
- *   tok_map (nullable, (G, Nq)): window partition for windowed attention (blocks.py:257-301):
- *     group g's token t is qkv row tok_map[g*Nq+t] of clip g / groups_per_clip, or the padding
- *     row `pad_row` ((3D,) = qkv bias, blocks.py:280-281) when negative.  With a map, B counts
- *     groups and Nk == Nq.
- * D/H % 4 == 0, D/H <= 128.
+ * K4  q.k^T product state: product (G, H, Nq, Nk) fp32, q divided by `scale` (= sqrt(D/H),
+ *     blocks.py:92,514) before the contraction, fp32 MFMA.
+ *   delta == 0: product = (q/scale) k^T                         (MatmulBuffer.forward_first,
+ *               modules.py:224-230)
+ *   delta == 1: rows idx_q <- (q/scale)[idx_q] k^T, then columns idx_k <- (q/scale) k[idx_k]^T,
+ *               both from the already-updated operands (modules.py:232-248) in ONE launch.
+ *   Addressing: element (clip c, head h, token t, channel d) of q is q[c*q_bs + t*q_rs + h*q_hs + d]
+ *   (same for k), so the packed (B,N,3D) token buffer of the blocks (q = buf, k = buf + D,
+ *   rs = 3D, hs = dh, bs = N*3D; blocks.py:248-255) and free-standing (B,H,N,dh) tensors both fit.
+ *   tok_map (nullable, (groups_per_clip, Nq)): window partition for windowed attention
+ *     (blocks.py:257-301), identical for every clip: token t of group g is token
+ *     tok_map[(g % groups_per_clip)*Nq + t] of clip g / groups_per_clip, or the padding vector
+ *     pad_q / pad_k (slices of the qkv bias, blocks.py:280-281) when negative.  With a map, G counts
+ *     groups (clips x windows), Nq == Nk == window length, delta must be 0.
+ * dh % 8 == 0, dh <= 128; strides multiples of 4 elements.
  * ------------------------------------------------------------------------------------------ */
-int evt_qk_full(const float* qkv, int B, int N, int D, int H, float scale, float* product,
-                const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
-                void* stream);
-int evt_qk_delta(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
-                 int H, int kcap, float scale, float* product, void* stream);
+typedef struct evt_qk_desc {
+  const float* q; int64_t q_bs, q_hs, q_rs;
+  const float* k; int64_t k_bs, k_hs, k_rs;
+  float* product;
+  const int32_t* idx_q; const int32_t* count_q; int32_t kcap_q;   /* delta only                  */
+  const int32_t* idx_k; const int32_t* count_k; int32_t kcap_k;
+  const int32_t* tok_map; int32_t groups_per_clip; const float* pad_q; const float* pad_k;
+  int32_t G, H, Nq, Nk, dh;
+  float scale;
+  int32_t delta;
+} evt_qk_desc;
+
+EVT_API int evt_qk(const evt_qk_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K5  Row softmax over the product state with optional decomposed relative position terms,
@@ -186,7 +206,7 @@ typedef struct evt_softmax_desc {
   int32_t gated;                          /* 0 = FULL, 1 = GATED                                 */
 } evt_softmax_desc;
 
-int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
+EVT_API int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K6a Value delta gate (rows, forced index; blocks.py:566-567, modules.py:187-201):
@@ -197,7 +217,7 @@ int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
  *   v is the third D-slice of the qkv buffer.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D), all
  *   in `store` type with heads side by side (h*dh + d).
  * ------------------------------------------------------------------------------------------ */
-int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
+EVT_API int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
                int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated,
                const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
                void* stream);
@@ -225,7 +245,7 @@ typedef struct evt_av_desc {
   int32_t gated;
 } evt_av_desc;
 
-int evt_av(const evt_av_desc* d, void* stream);
+EVT_API int evt_av(const evt_av_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

