@@ -205,16 +205,31 @@ def scatter_rows(x, buf, idx, count, B, N, F, kcap):
     _check(load().evt_scatter_rows(_p(x), _p(buf), _p(idx), _p(count), B, N, F, kcap, _stream()))
 
 
+# bench.py sets this to a list to bracket every launch of the dominant kernel with HIP events on the
+# launch stream: entries are (start_event, end_event, algorithmic_flops).
+GEMM_EVENTS = None
+
+
+def _timed(flops, fn):
+    if GEMM_EVENTS is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    GEMM_EVENTS.append((s, e, flops))
+
+
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE):
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
                    _p(p_upd), B, kcap, K, Nout, act)
-    _check(load().evt_gated_linear(ctypes.byref(d), _stream()))
+    _timed(2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh):
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
                 _p(p_upd), B, kcap, D, Dh)
-    _check(load().evt_gated_mlp(ctypes.byref(d), _stream()))
+    _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())))
 
 
 def _ptr_off(t, elems):
