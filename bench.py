@@ -152,6 +152,32 @@ def cpu_baseline(sd, extra, cast, k, frames, budget_s=20.0):
                       f"{threads} threads, {el:.1f}s"}
 
 
+def broadcast_weights(sd, extra, device, rank):
+    """Rank 0's weights -> every rank, as ONE flat-buffer broadcast (RCCL over xGMI on the GPU box; the
+    same code runs on gloo/CPU in tests/test_dist_cpu.py).  Non-zero ranks' values are overwritten."""
+    flat = torch.cat([v.reshape(-1) for v in list(sd.values()) + list(extra.values())]).to(device)
+    if rank != 0:
+        flat.zero_()
+    dist.broadcast(flat, src=0)
+    off = 0
+    for d in (sd, extra):
+        for key in d:
+            n = d[key].numel()
+            d[key] = flat[off:off + n].view_as(d[key]).cpu().clone()
+            off += n
+
+
+def max_over_ranks(seconds, device):
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def clips_for_rank(total_clips, world, rank):
+    """Clip i -> rank i mod world; used when a FIXED clip set is split (strong scaling)."""
+    return list(range(rank, total_clips, world))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,16 +209,7 @@ def main():
     # Weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective).
     sd, extra = seeded_state_dict()
     if world > 1:
-        flat = torch.cat([v.reshape(-1) for v in list(sd.values()) + list(extra.values())]).to(device)
-        if rank != 0:
-            flat.zero_()
-        dist.broadcast(flat, src=0)
-        off = 0
-        for d in (sd, extra):
-            for key in d:
-                n = d[key].numel()
-                d[key] = flat[off:off + n].view_as(d[key]).cpu()
-                off += n
+        broadcast_weights(sd, extra, device, rank)
     model = SpatialModel(sd, extra, cast, args.k, device)
     clips = synthetic_clips(args.clips, args.frames, args.k, 1000 + rank, device)
 
@@ -215,9 +232,7 @@ def main():
         _native.GEMM_EVENTS = None
 
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed, device)
 
     frames_total = world * args.clips * args.frames * args.steps
     value = frames_total / elapsed
