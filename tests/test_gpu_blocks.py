@@ -182,3 +182,49 @@ def test_vivit_b_gate_sets_teacher_forced(golden_dir):
                             mismatched += (not same)
                 x = y_ref
     assert checked >= 40 and mismatched == 0, (checked, mismatched)
+
+
+def _vitdet_run(golden_dir, fixture, grid, policy_cls, policy_kw, cast, stream_fn, stride, tol):
+    from eventful_transformer import policies
+    g = H.load_npz(os.path.join(golden_dir, fixture))
+    seed = int(g["seed"])
+
+    def rel_for(i):
+        return (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
+
+    sd = H.backbone_params(12, 768, 4, seed, 14 * 14, rel_for=rel_for)
+    bb = H.product_vitdet(grid, sd, cast)
+    H.set_policies(bb, getattr(policies, policy_cls), **policy_kw)
+    want = torch.from_numpy(g["y_slice"])
+    xs = stream_fn(want.shape[0], seed)
+    worst = []
+    with torch.inference_mode():
+        for t in range(want.shape[0]):
+            y = bb(xs[t].to(DEV))[:, ::stride].cpu()
+            worst.append(float((y - want[t]).abs().max()))
+    assert max(worst) <= tol, worst
+    return g, bb
+
+
+def test_vitdet_672_topk(golden_dir):
+    """BASELINE config 3: ViTDet-B backbone 672^2 (N=1764; 8 windowed EventfulTokenwiseBlocks with 14x14
+    windows + rel-pos, 4 global EventfulBlocks with rel-pos resized 64->42), top-k 256, fp32, free-running
+    against the reference's golden output slices."""
+    _vitdet_run(golden_dir, "vitdet_672.npz", 42, "TokenNormTopK", dict(k=256), None,
+                lambda steps, seed: O.make_token_stream(1, 42 * 42, 768, steps, 256, seed=seed + 2, small=0.01),
+                16, 1e-3)
+
+
+def test_vitdet_1024_threshold(golden_dir):
+    """BASELINE config 5: ViTDet-B backbone 1024^2 (N=4096, windows padded 64->70), threshold policy with
+    data-dependent r per gate (409 / 0 / 409 here) kept on the device, global blocks bf16 A.v cast."""
+    from eventful_transformer import _native
+    g, bb = _vitdet_run(golden_dir, "vitdet_1024.npz", 64, "TokenNormThreshold", dict(threshold=1.0), "bfloat16",
+                        lambda steps, seed: O.make_threshold_stream(64 * 64, 768, steps, seed + 2), 64, 2e-3)
+    # the last block's three gate counts are still in scratch: compare with the reference's counts
+    dev0 = torch.device(DEV, 0)
+    want = g["counts"][-1, -1]
+    got = [int(_native.scratch(f"cnt_{n}", (1,), torch.int32, dev0).cpu()[0]) for n in ("qkv", "projection", "mlp")]
+    assert got == want.tolist(), (got, want)
+    idx = _native.scratch("idx_mlp", (1, 4096), torch.int32, dev0).cpu()[0, : got[2]].numpy()
+    assert np.array_equal(idx.astype(np.int64), g[f"idx_1_11_mlp_index"].reshape(-1).astype(np.int64))
