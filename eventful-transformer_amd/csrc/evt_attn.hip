@@ -231,8 +231,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ idx,
                                                      const int32_t* __restrict__ count, int G, int N, int D, int kcap,
                                                      T* __restrict__ v_state, T* __restrict__ v_delta,
-                                                     T* __restrict__ v_old, int gated, const int32_t* tok_map,
-                                                     int groups_per_clip, int clip_rows, const float* pad_row) {
+                                                     T* __restrict__ v_old, int gated, int transposed, int H,
+                                                     const int32_t* tok_map, int groups_per_clip, int clip_rows,
+                                                     const float* pad_row) {
   const int v4 = D >> 2;
   const int rows = gated ? kcap : N;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -255,11 +256,62 @@ __global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ q
     if (gated) {
       const float old = Store<T>::load(st + q);
       const float dl = Store<T>::round(nv - old);
-      const int64_t o = ((int64_t)g * kcap + ii) * D + c4 * 4 + q;
+      // token-major (B,kcap,D) for evt_av, or k-contiguous (B,H,dh,kcap) for evt_softmax_av_gated
+      const int64_t o = transposed ? ((int64_t)g * D + c4 * 4 + q) * kcap + ii
+                                   : ((int64_t)g * kcap + ii) * D + c4 * 4 + q;
       Store<T>::store(v_delta + o, dl);
       Store<T>::store(v_old + o, nv - dl);  // v_n_tilde - v_delta_tilde, modules.py:294
     }
     Store<T>::store(st + q, nv);
+  }
+}
+
+// K6a, transposed outputs through an LDS tile: a workgroup owns 64 selected tokens x 64 channels, reads
+// v / v_state with whole-row-segment accesses, and writes v_delta^T / v_old^T (B, D, kcap) as 128-byte
+// k-contiguous segments (the operand layout of evt_softmax_av_gated).
+template <typename T>
+__global__ __launch_bounds__(256) void v_gate_t_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ count, int N, int D, int kcap,
+                                                       T* __restrict__ v_state, T* __restrict__ v_delta_t,
+                                                       T* __restrict__ v_old_t) {
+  constexpr int TP = 64 + 8;  // LDS pitch in elements (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) T td[64 * TP];
+  __shared__ __attribute__((aligned(16))) T to[64 * TP];
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int cnt = count ? count[b] : kcap;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4, ii = k0 + r;
+    float dl[4] = {0.f, 0.f, 0.f, 0.f}, vo[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ii < cnt) {
+      const int tok = idx[(int64_t)b * kcap + ii];
+      const float4 v = *reinterpret_cast<const float4*>(qkv + ((int64_t)b * N + tok) * 3 * D + 2 * D + c0 + c4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      T* st = v_state + ((int64_t)b * N + tok) * D + c0 + c4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float nv = Store<T>::round(vv[q]);
+        const float old = Store<T>::load(st + q);
+        dl[q] = Store<T>::round(nv - old);
+        vo[q] = Store<T>::round(nv - dl[q]);  // v_n_tilde - v_delta_tilde, modules.py:294
+        Store<T>::store(st + q, nv);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Store<T>::store(td + (c4 + q) * TP + r, dl[q]);
+      Store<T>::store(to + (c4 + q) * TP + r, vo[q]);
+    }
+  }
+  __syncthreads();
+  constexpr int VEC = 16 / (int)sizeof(T);
+  for (int e = tid; e < 64 * (64 / VEC); e += 256) {
+    const int ch = e / (64 / VEC), kk = (e - ch * (64 / VEC)) * VEC;
+    if (k0 + kk >= kcap) continue;  // kcap % VEC == 0 is required by the launcher
+    const int64_t o = ((int64_t)b * D + c0 + ch) * kcap + k0 + kk;
+    *reinterpret_cast<uint4*>(v_delta_t + o) = *reinterpret_cast<const uint4*>(td + ch * TP + kk);
+    *reinterpret_cast<uint4*>(v_old_t + o) = *reinterpret_cast<const uint4*>(to + ch * TP + kk);
   }
 }
 
@@ -458,8 +510,9 @@ extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
 }
 
 extern "C" int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D, int kcap,
-                          void* v_state, void* v_delta, void* v_old, int store, int gated, const int32_t* tok_map,
-                          int groups_per_clip, int clip_rows, const float* pad_row, void* stream) {
+                          void* v_state, void* v_delta, void* v_old, int store, int gated, int transposed,
+                          const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
+                          void* stream) {
   EVT_REQUIRE(qkv && v_state, EVT_ERR_BAD_ARG, "evt_v_gate: null pointer");
   EVT_REQUIRE(B >= 0 && N > 0 && D > 0 && (D & 3) == 0, EVT_ERR_BAD_ARG, "evt_v_gate: bad sizes");
   if (gated) EVT_REQUIRE(idx && v_delta && v_old && kcap >= 0 && tok_map == nullptr, EVT_ERR_BAD_ARG, "evt_v_gate: gated mode needs idx/v_delta/v_old and no tok_map");
@@ -469,9 +522,17 @@ extern "C" int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* c
   if (n == 0) return EVT_OK;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   hipStream_t s = evt_stream(stream);
+  if (gated && transposed && (D % 64) == 0 && (kcap % 8) == 0 && kcap > 0) {
+    const dim3 tgrid((kcap + 63) / 64, D / 64, B);
+    EVT_DISPATCH_STORE(store, T, {
+      hipLaunchKernelGGL(v_gate_t_kernel<T>, tgrid, block, 0, s, qkv, idx, count, N, D, kcap, (T*)v_state,
+                         (T*)v_delta, (T*)v_old);
+    });
+    return evt_check_launch("evt_v_gate");
+  }
   EVT_DISPATCH_STORE(store, T, {
     hipLaunchKernelGGL(v_gate_kernel<T>, grid, block, 0, s, qkv, idx, count, B, N, D, kcap, (T*)v_state, (T*)v_delta,
-                       (T*)v_old, gated, tok_map, tok_map ? groups_per_clip : 1, clip_rows, pad_row);
+                       (T*)v_old, gated, transposed, 0, tok_map, tok_map ? groups_per_clip : 1, clip_rows, pad_row);
   });
   return evt_check_launch("evt_v_gate");
 }

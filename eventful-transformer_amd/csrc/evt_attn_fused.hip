@@ -1,0 +1,380 @@
+// evt_attn_fused.hip -- K5+K6 fused for the gated frames of EventfulBlock:
+//
+//   row softmax statistics over the q.k^T state (+ rel-pos terms)             blocks.py:518-522
+//   -> gather the k selected columns, A delta gate (a~, da~, reference update) modules.py:187-201 ("col")
+//   -> state[i,:] += round(a~ . dv~) ; += round(da~ . v_old), heads merged     modules.py:285-295
+//
+// One workgroup owns 32 attention rows of one (clip, head).  The N x N state row is streamed from
+// HBM for the max / sum statistics only (never staged whole), the k gathered probabilities go
+// straight into LDS tiles that feed the matrix cores, so a~ / da~ (H*N*k per clip) never touch
+// HBM.  The selected-column axis is processed in chunks of 128, so any k (incl. the threshold
+// policy's device-side count up to N) fits in the same 60 KB of LDS.
+//
+// Arithmetic per store type T (= the reference's `matmul_2_cast` dtype):
+//   bf16 / fp16 : operands ARE bf16/fp16 values (the reference rounded them), so the products are
+//                 exact on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate -- what a bf16 matmul is;
+//   fp32        : v_mfma_f32_32x32x2_f32.
+// Every rounding point of the reference is kept: a~, da~ = round(a~ - ref), each matmul result, each +=.
+//
+// v operands come TRANSPOSED from K6a (evt_v_gate transposed=1): (B, D, kcap), k contiguous, so both
+// MFMA operands are staged with 16-byte copies and read from LDS as 16-byte k-contiguous fragments.
+// For N <= 256 the exponentials of the workgroup's 32 rows live in an LDS tile, so the gather of the
+// selected columns is an LDS lookup; larger N re-reads the (L2-hot) state row and recomputes k exps.
+#include "evt_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int FR = 32;    // rows per workgroup
+constexpr int FKC = 128;  // selected columns per chunk
+
+template <typename T> struct Tile;  // LDS row pitch (elements) and the MFMA sweep over one chunk
+template <> struct Tile<bf16_t> {
+  static constexpr int PITCH = FKC + 8;
+  static __device__ __forceinline__ f32x16 sweep(const bf16_t* a, const bf16_t* b, int lh, f32x16 acc) {
+#pragma unroll
+    for (int kk = 0; kk < FKC; kk += 16) {
+      const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(a + kk + 8 * lh);
+      const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(b + kk + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct Tile<f16_t> {
+  static constexpr int PITCH = FKC + 8;
+  static __device__ __forceinline__ f32x16 sweep(const f16_t* a, const f16_t* b, int lh, f32x16 acc) {
+#pragma unroll
+    for (int kk = 0; kk < FKC; kk += 16) {
+      const f16x8_t fa = *reinterpret_cast<const f16x8_t*>(a + kk + 8 * lh);
+      const f16x8_t fb = *reinterpret_cast<const f16x8_t*>(b + kk + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct Tile<float> {
+  static constexpr int PITCH = FKC + 4;
+  static __device__ __forceinline__ f32x16 sweep(const float* a, const float* b, int lh, f32x16 acc) {
+    // permuted k: lane half lh covers k in [64*lh, 64*lh + 64)
+#pragma unroll
+    for (int q = 0; q < FKC / 2; q += 4) {
+      const float4 fa = *reinterpret_cast<const float4*>(a + lh * (FKC / 2) + q);
+      const float4 fb = *reinterpret_cast<const float4*>(b + lh * (FKC / 2) + q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+// exp via v_exp_f32 (2^x): |rel err| ~ 1e-7 * (1 + |x|), far inside the 1e-3 activation tolerance and
+// applied to BOTH the normaliser and the gathered numerators, so rows still sum to one.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+struct FusedArgs {
+  const float* product; const float* qkv; const float* rel_y; const float* rel_x;
+  void* a_state; const int32_t* idx; const int32_t* count;
+  const void* v_delta_t; const void* v_old_t; void* pv; float* out_f32;
+  int B, H, N, D, dh, kcap, gh, gw;
+};
+
+// TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
+// in registers (one HBM pass, all 8*NREG loads in flight together); NREG == 0: any N, two streamed passes.
+template <typename T, int TPW, int NREG>
+__global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a) {
+  constexpr int P = Tile<T>::PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* An = reinterpret_cast<T*>(smem_raw);              // [FR][P]
+  T* Ad = An + FR * P;                                 // [FR][P]
+  T* Vd = Ad + FR * P;                                 // [dh][P]
+  T* Vo = Vd + a.dh * P;                               // [dh][P]
+  float* relv = reinterpret_cast<float*>(Vo + a.dh * P);  // [FR][gh+gw] rel-pos terms per row
+  float* qs = relv + FR * (a.gh + a.gw);               // [4][dh]     per-wave q row
+  float* et = qs + 4 * a.dh;                           // [FR][EP] exp(x - max) (NREG > 0), later the
+  float* red1 = et;                                    // [FR][dh] round(a~ . dv~)   (aliases et)
+  float* red2 = et + FR * a.dh;                        // [FR][dh] round(da~ . v_old)
+  const int EP = a.N | 1;                              // odd pitch: row-strided LDS access conflict-free
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int i0 = blockIdx.x * FR;
+  const int cnt = a.count ? a.count[b] : a.kcap;
+  const bool rel = a.rel_y != nullptr;
+  const int nrel = a.gh + a.gw;
+  const float* prod = a.product + (int64_t)bh * a.N * a.N;
+  T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.N;
+  const int32_t* ix = a.idx + (int64_t)b * a.kcap;
+
+  // ---- phase 1: per-row softmax statistics; wave w owns rows w*8 .. w*8+7 -----------------------
+  float rmax[8], rsum[8];
+  if (rel) {
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
+      if (i >= a.N) break;  // wave-uniform
+      float* rv = relv + r * nrel;
+      const float* qrow = a.qkv + ((int64_t)b * a.N + i) * 3 * a.D + h * a.dh;
+      for (int d = lane; d < a.dh; d += 64) qs[wave * a.dh + d] = qrow[d];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      const int yi = i / a.gw, xi = i - yi * a.gw;
+      for (int e = lane; e < nrel; e += 64) {
+        const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * a.dh
+                                      : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * a.dh;
+        float s = 0.f;
+        for (int d = 0; d < a.dh; d += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(tab + d);
+          const float* q = qs + wave * a.dh + d;
+          s += q[0] * t.x + q[1] * t.y + q[2] * t.z + q[3] * t.w;
+        }
+        rv[e] = s;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (NREG > 0) {
+    float xv[8][NREG > 0 ? NREG : 1];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
+      const float* prow = prod + (int64_t)(i < a.N ? i : 0) * a.N;
+      const float* rv = relv + r * nrel;
+#pragma unroll
+      for (int u = 0; u < NREG; ++u) {
+        const int j = lane + 64 * u;
+        float x = -INFINITY;
+        if (j < a.N) {
+          x = prow[j];
+          if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+        }
+        xv[rr][u] = x;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float mx = xv[rr][0];
+#pragma unroll
+      for (int u = 1; u < NREG; ++u) mx = fmaxf(mx, xv[rr][u]);
+      rmax[rr] = wave_max(mx);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < NREG; ++u) {
+        const float e = fast_exp(xv[rr][u] - rmax[rr]);  // exp(-inf) == 0 past N
+        if (lane + 64 * u < a.N) et[(wave * 8 + rr) * EP + lane + 64 * u] = e;
+        sum += e;
+      }
+      rsum[rr] = wave_sum(sum);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();  // each wave only ever reads back its own 8 rows
+  } else {
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
+      rmax[rr] = 0.f; rsum[rr] = 1.f;
+      if (i >= a.N) continue;  // wave-uniform
+      const float* rv = relv + r * nrel;
+      const float* prow = prod + (int64_t)i * a.N;
+      float mx = -INFINITY;
+      for (int j = lane; j < a.N; j += 64) {
+        float x = prow[j];
+        if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+        mx = fmaxf(mx, x);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < a.N; j += 64) {
+        float x = prow[j];
+        if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+        sum += fast_exp(x - mx);
+      }
+      rmax[rr] = mx;
+      rsum[rr] = wave_sum(sum);
+    }
+  }
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int prodsel = wave >> 1;  // 0: a~ . dv~   1: da~ . v_old
+  const int half = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const T* Vg_d = reinterpret_cast<const T*>(a.v_delta_t) + (int64_t)bh * a.dh * a.kcap;
+  const T* Vg_o = reinterpret_cast<const T*>(a.v_old_t) + (int64_t)bh * a.dh * a.kcap;
+
+  for (int k0 = 0; k0 < cnt; k0 += FKC) {
+    // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
+    int jc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kk = k0 + lane + 64 * u;
+      jc[u] = (kk < cnt) ? ix[kk] : -1;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
+      const bool live = i < a.N;
+      const float* prow = prod + (int64_t)i * a.N;
+      const float* rv = relv + r * nrel;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int jj = lane + 64 * u, j = jc[u];
+        float an = 0.f, ad = 0.f;
+        if (live && j >= 0) {
+          float e;
+          if (NREG > 0) {
+            e = et[r * EP + j];
+          } else {
+            float x = prow[j];
+            if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+            e = fast_exp(x - rmax[rr]);
+          }
+          an = Store<T>::round(e / rsum[rr]);
+          const float old = Store<T>::load(st + (int64_t)i * a.N + j);
+          ad = Store<T>::round(an - old);
+          Store<T>::store(st + (int64_t)i * a.N + j, an);
+        }
+        Store<T>::store(An + r * P + jj, an);
+        Store<T>::store(Ad + r * P + jj, ad);
+      }
+    }
+    // ---- phase 2b: stage the chunk of dv~^T and v_old^T (k contiguous), zero beyond count -------
+    constexpr int VEC = 16 / (int)sizeof(T);
+    if ((a.kcap % VEC) == 0) {
+      for (int e = tid; e < a.dh * (FKC / VEC); e += 256) {
+        const int d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
+        union { uint4 u; T t[VEC]; } xd, xo;
+        xd.u = make_uint4(0, 0, 0, 0); xo.u = xd.u;
+        if (kk < cnt) {  // kk + VEC <= kcap because kcap % VEC == 0
+          xd.u = *reinterpret_cast<const uint4*>(Vg_d + (int64_t)d * a.kcap + kk);
+          xo.u = *reinterpret_cast<const uint4*>(Vg_o + (int64_t)d * a.kcap + kk);
+          if (kk + VEC > cnt) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+              if (kk + q >= cnt) { Store<T>::store(&xd.t[q], 0.f); Store<T>::store(&xo.t[q], 0.f); }
+          }
+        }
+        *reinterpret_cast<uint4*>(Vd + d * P + jj) = xd.u;
+        *reinterpret_cast<uint4*>(Vo + d * P + jj) = xo.u;
+      }
+    } else {
+      for (int e = tid; e < a.dh * FKC; e += 256) {
+        const int d = e / FKC, jj = e - d * FKC, kk = k0 + jj;
+        float vd = 0.f, vo = 0.f;
+        if (kk < cnt) {
+          vd = Store<T>::load(Vg_d + (int64_t)d * a.kcap + kk);
+          vo = Store<T>::load(Vg_o + (int64_t)d * a.kcap + kk);
+        }
+        Store<T>::store(Vd + d * P + jj, vd);
+        Store<T>::store(Vo + d * P + jj, vo);
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: matrix cores ------------------------------------------------------------------
+    const T* At = (prodsel == 0 ? An : Ad) + lr * P;
+    const T* Vt = (prodsel == 0 ? Vd : Vo);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      acc[t] = Tile<T>::sweep(At, Vt + ((half + 2 * t) * 32 + lr) * P, lh, acc[t]);
+    __syncthreads();
+  }
+
+  // ---- phase 4: state += round(acc1); state += round(acc2); heads merged on write ---------------
+  // Both rounded products go through LDS so that the state read-modify-write and the fp32 output are
+  // whole-row 16-byte accesses by all 256 threads (8 consecutive channels per thread).
+  {
+    float* redp = (prodsel == 0) ? red1 : red2;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        redp[row * a.dh + (half + 2 * t) * 32 + lr] = Store<T>::round(acc[t][r]);
+      }
+  }
+  __syncthreads();
+  T* pv = reinterpret_cast<T*>(a.pv);
+  for (int e = tid; e < FR * (a.dh / 8); e += 256) {
+    const int row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8;
+    const int i = i0 + row;
+    if (i >= a.N) continue;
+    const int64_t o = ((int64_t)b * a.N + i) * a.D + h * a.dh + c8;
+    union { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; } st8;
+    union { float4 v[2]; float f[8]; } o8;
+#pragma unroll
+    for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) st8.u[q] = reinterpret_cast<const uint4*>(pv + o)[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[row * a.dh + c8 + q]);  // += a~ . dv~
+      v = Store<T>::round(v + red2[row * a.dh + c8 + q]);                                 // += da~ . v_old
+      Store<T>::store(&st8.t[q], v);
+      o8.f[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + o)[q] = st8.u[q];
+    reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
+    reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+  }
+}
+
+template <typename T, int TPW, int NREG>
+void launch_fused_inst(const FusedArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_av_gated_kernel<T, TPW, NREG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((softmax_av_gated_kernel<T, TPW, NREG>), grid, dim3(256), lds, s, a);
+}
+
+template <typename T>
+int launch_fused(const FusedArgs& a, void* stream) {
+  constexpr int P = Tile<T>::PITCH;
+  const int nreg = (a.N + 63) / 64;
+  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.N | 1) : 0;        // exp tile (aliases the two
+  const size_t tile_r = (size_t)2 * FR * a.dh;                          // rounded-product tiles)
+  const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) +
+                     ((tile_e > tile_r ? tile_e : tile_r) + FR * (a.gh + a.gw) + 4 * a.dh) * sizeof(float);
+  const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
+  if (grid.y == 0) return EVT_OK;
+  hipStream_t s = evt_stream(stream);
+  if (a.dh == 64) {
+    if (nreg <= 4) launch_fused_inst<T, 1, 4>(a, grid, lds, s);
+    else launch_fused_inst<T, 1, 0>(a, grid, lds, s);
+  } else {
+    if (nreg <= 4) launch_fused_inst<T, 2, 4>(a, grid, lds, s);
+    else launch_fused_inst<T, 2, 0>(a, grid, lds, s);
+  }
+  return evt_check_launch("evt_softmax_av_gated");
+}
+
+}  // namespace
+
+extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null descriptor");
+  EVT_REQUIRE(d->product && d->a_state && d->idx && d->v_delta_t && d->v_old_t && d->pv && d->out_f32,
+              EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null pointer");
+  EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->kcap >= 0 && d->D == d->H * d->dh, EVT_ERR_BAD_ARG,
+              "evt_softmax_av_gated: bad sizes");
+  EVT_REQUIRE(d->dh == 64 || d->dh == 128, EVT_ERR_BAD_SHAPE,
+              "evt_softmax_av_gated: head dim %d not supported by the fused kernel (64 or 128); use evt_softmax_gate + evt_av",
+              d->dh);
+  EVT_REQUIRE((d->rel_y == nullptr) == (d->rel_x == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_av_gated: rel_y/rel_x");
+  if (d->rel_y) {
+    EVT_REQUIRE(d->qkv != nullptr && d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N, EVT_ERR_BAD_SHAPE,
+                "evt_softmax_av_gated: rel-pos grid %dx%d does not match N=%d", d->gh, d->gw, d->N);
+  }
+  FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
+              d->pv, d->out_f32, d->B, d->H, d->N, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0};
+  EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
+  return EVT_OK;
+}

@@ -23,7 +23,7 @@ _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EV
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_mlp", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av",
+    "evt_gated_mlp", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated",
 )
 
 
@@ -79,6 +79,16 @@ class AvDesc(Structure):
     ]
 
 
+class SoftmaxAvDesc(Structure):
+    _fields_ = [
+        ("product", c_void_p), ("qkv", c_void_p), ("rel_y", c_void_p), ("rel_x", c_void_p),
+        ("gh", c_int32), ("gw", c_int32), ("a_state", c_void_p), ("idx", c_void_p), ("count", c_void_p),
+        ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
+        ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
+        ("store", c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -97,7 +107,8 @@ def _bind(lib):
         "evt_gated_mlp": [POINTER(MlpDesc), P],
         "evt_qk": [POINTER(QkDesc), P],
         "evt_softmax_gate": [POINTER(SoftmaxDesc), P],
-        "evt_v_gate": [P, P, P, I, I, I, I, P, P, P, I, I, P, I, I, P, P],
+        "evt_v_gate": [P, P, P, I, I, I, I, P, P, P, I, I, I, P, I, I, P, P],
+        "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -269,9 +280,17 @@ def softmax_gate(product, a_state, B, H, N, Nk, D, store, qkv=None, rel_y=None, 
 
 
 def v_gate(qkv, idx, count, B, N, D, kcap, v_state, v_delta, v_old, store, gated, tok_map=None, groups_per_clip=1,
-           clip_rows=0, pad_row=None):
+           clip_rows=0, pad_row=None, transposed=False):
     _check(load().evt_v_gate(_p(qkv), _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta), _p(v_old), store,
-                             int(gated), _p(tok_map), groups_per_clip, clip_rows, _p(pad_row), _stream()))
+                             int(gated), int(transposed), _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
+                             _stream()))
+
+
+def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
+                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0):
+    d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
+                      _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store)
+    _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream()))
 
 
 def av(a1, v1, lda, B, H, N, K, D, store, pv=None, out_f32=None, a2=None, v2=None, count=None, gated=False,

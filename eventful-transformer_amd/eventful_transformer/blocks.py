@@ -443,15 +443,23 @@ class EventfulBlock(EventfulMatmul1Block):
             _native.av(ag.p, vg._state, N, B, H, N, N, D, store, pv=acc._state, out_f32=attn)
             acc.matmul.count_product(B * H * N * dh, N)
             return attn
-        a_new = self._ws("a_new", (B, H, N, cap), sdt, qkv)
-        a_delta = self._ws("a_delta", (B, H, N, cap), sdt, qkv)
-        v_delta = self._ws("v_delta", (B, cap, D), sdt, qkv)
-        v_old = self._ws("v_old", (B, cap, D), sdt, qkv)
-        _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
-                             a_new=a_new, a_delta=a_delta, idx=idx, count=count, kcap=cap, gated=True)
-        _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True)
-        _native.av(a_new, v_delta, cap, B, H, N, cap, D, store, pv=acc._state, out_f32=attn, a2=a_delta, v2=v_old,
-                   count=count, gated=True)
+        if dh in (64, 128):
+            # K6a with k-contiguous outputs + fused K5/K6: a~ / da~ stay in LDS
+            v_delta = self._ws("v_delta_t", (B, D, cap), sdt, qkv)
+            v_old = self._ws("v_old_t", (B, D, cap), sdt, qkv)
+            _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
+            _native.softmax_av_gated(product, ag.p, idx, count, cap, v_delta, v_old, acc._state, attn, B, H, N, D,
+                                     store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
+        else:
+            a_new = self._ws("a_new", (B, H, N, cap), sdt, qkv)
+            a_delta = self._ws("a_delta", (B, H, N, cap), sdt, qkv)
+            v_delta = self._ws("v_delta", (B, cap, D), sdt, qkv)
+            v_old = self._ws("v_old", (B, cap, D), sdt, qkv)
+            _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
+                                 a_new=a_new, a_delta=a_delta, idx=idx, count=count, kcap=cap, gated=True)
+            _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True)
+            _native.av(a_new, v_delta, cap, B, H, N, cap, D, store, pv=acc._state, out_f32=attn, a2=a_delta, v2=v_old,
+                       count=count, gated=True)
         if self.count_mode or acc.count_mode or vg.count_mode:
             n = self._n_rows(B, cap, count)
             self._count_gate(vg, B * N * D)

@@ -214,11 +214,12 @@ EVT_API int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
  *   GATED: v_new = round(v[idx]); v_delta = round(v_new - v_state[idx]);
  *          v_old = round(v_new - v_delta)   (the `v_n_tilde - v_delta_tilde` of modules.py:294)
  *          v_state[idx] = v_new
- *   v is the third D-slice of the qkv buffer.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D), all
- *   in `store` type with heads side by side (h*dh + d).
+ *   v is the third D-slice of the qkv buffer.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D) with heads
+ *   side by side (h*dh + d), or, with `transposed`, (B,H,dh,kcap) = (B,D,kcap) with k contiguous
+ *   (the operand layout of evt_softmax_av_gated); all in `store` type.
  * ------------------------------------------------------------------------------------------ */
 EVT_API int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
-               int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated,
+               int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated, int transposed,
                const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
                void* stream);
 
@@ -246,6 +247,31 @@ typedef struct evt_av_desc {
 } evt_av_desc;
 
 EVT_API int evt_av(const evt_av_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K5+K6 fused for gated frames (EventfulBlock._forward_attention, blocks.py:558-575, t >= 1):
+ * softmax statistics of each state row (+ rel-pos), gather of the selected columns with the
+ * attention delta gate (a~, da~, reference update), and both accumulator products on the matrix
+ * cores, in one launch -- a~ / da~ never reach HBM.  Same results as evt_softmax_gate(gated) +
+ * evt_av(gated).  v_delta_t / v_old_t: (B,D,kcap) = (B,H,dh,kcap) from evt_v_gate(transposed=1).
+ * dh must be 64 or 128 (else use the two-kernel path).  bf16/fp16 store types run on
+ * v_mfma_f32_32x32x16_{bf16,f16} (operands are exactly bf16/fp16 values, fp32 accumulate);
+ * fp32 on v_mfma_f32_32x32x2_f32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_softmax_av_desc {
+  const float* product;                   /* (B,H,N,N)                                           */
+  const float* qkv;                       /* (B,N,3D); only read for rel-pos                     */
+  const float* rel_y; const float* rel_x; int32_t gh, gw;
+  void* a_state;                          /* (B,H,N,N) store type: matmul_gate.p                 */
+  const int32_t* idx; const int32_t* count; int32_t kcap;
+  const void* v_delta_t; const void* v_old_t;
+  void* pv;                               /* (B,N,D) store type: matmul_accumulator_2.product    */
+  float* out_f32;                         /* (B,N,D)                                             */
+  int32_t B, H, N, D, dh;
+  int32_t store;
+} evt_softmax_av_desc;
+
+EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

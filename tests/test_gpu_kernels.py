@@ -280,3 +280,60 @@ def test_rel_pos_softmax_matches_oracle():
     n.softmax_gate(scores.to(DEV), ap, B, H, N, N, D, 0, qkv=buf.to(DEV), rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=gh,
                    gw=gw)
     assert torch.allclose(ap.cpu(), ref, atol=2e-6, rtol=1e-4), float((ap.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("cast,N,k,rel", [(None, 70, 12, False), ("bfloat16", 70, 40, False), ("float16", 36, 20, True),
+                                          ("bfloat16", 300, 200, False), (None, 130, 130, False),
+                                          ("bfloat16", 42, 17, True)])
+def test_fused_softmax_av_gated_matches_oracle(cast, N, k, rel):
+    """K6a(transposed) + fused K5/K6 (evt_softmax_av_gated) vs the oracle's gates/accumulator, dh = 64,
+    incl. multi-chunk k > 128, partial row blocks, rel-pos terms and a device-side count < kcap."""
+    n = native()
+    B, H, dh = 2, 2, 64
+    D = H * dh
+    gh, gw = (6, N // 6) if rel else (0, 0)
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(N * 31 + k)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    ap = torch.empty(B, H, N, N, dtype=sdt, device=DEV)
+    vp = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    ry = torch.randn(gh, gh, dh, generator=g) * 0.2 if rel else None
+    rx = torch.randn(gw, gw, dh, generator=g) * 0.2 if rel else None
+    tol = 2e-5 if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+    for t in range(3):
+        scores = torch.randn(B, H, N, N, generator=g) * 2
+        buf = torch.randn(B, N, 3 * D, generator=g)
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        q, _, v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        logits = O.add_relative(scores.clone(), q, ry, rx, (gh, gw), inplace=False) if rel else scores
+        a = logits.softmax(dim=-1)
+        if cast is not None:
+            a, v = a.to(sdt), v.to(sdt)
+        else:
+            v = v.clone()
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        sd, bd, idxd = scores.to(DEV), buf.to(DEV), idx.int().to(DEV)
+        relkw = dict(qkv=bd, rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=gh, gw=gw) if rel else {}
+        if t == 0:
+            n.softmax_gate(sd, ap, B, H, N, N, D, store, **relkw)
+            n.v_gate(bd, None, None, B, N, D, 0, vp, None, None, store, False)
+            n.av(ap, vp, N, B, H, N, N, D, store, pv=pv, out_f32=out)
+        else:
+            # frame 2 exercises the device-side count: capacity k + 5, valid k
+            cap = k if t == 1 else k + 5
+            idx_cap = torch.full((B, cap), 0, dtype=torch.int32, device=DEV)
+            idx_cap[:, :k] = idxd
+            count = None if t == 1 else torch.full((B,), k, dtype=torch.int32, device=DEV)
+            v_del = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            v_old = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            n.v_gate(bd, idx_cap, count, B, N, D, cap, vp, v_del, v_old, store, True, transposed=True)
+            n.softmax_av_gated(sd, ap, idx_cap, count, cap, v_del, v_old, pv, out, B, H, N, D, store, **relkw)
+        assert torch.allclose(ap.float().cpu(), ag.t.float(), atol=tol * 0.1 + 2e-6), (cast, t)
+        err = float((out.cpu() - ref).abs().max())
+        assert err <= tol, (cast, N, k, t, err)
+        assert torch.equal(out.cpu(), pv.float().cpu())
