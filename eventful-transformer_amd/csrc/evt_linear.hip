@@ -28,7 +28,7 @@ constexpr int GEMM_THREADS = 256;
 
 struct LinArgs {
   const float* A; int64_t lda; const int32_t* a_idx; int a_rows;
-  const float* W; const float* bias;
+  const float* W; const uint16_t* Wsplit; const float* bias;
   float* out; int64_t ldo; const int32_t* o_idx; int o_rows;
   const int32_t* count; float* p_upd;
   int B, kcap, K, Nout, act;
@@ -179,11 +179,209 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-precision variant: every fp32 operand x is written x = hi + lo + O(2^-17 |x|) with hi, lo
+// bf16 (round-to-nearest-even), and a.w is accumulated in fp32 as hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate, 3 instructions per product => ~5x the
+// throughput).  The dropped lo.lo term is <= 2^-16 |a||w| per product, random in sign; measured
+// against fp64 it is ~1e-5 relative on these shapes (tests/test_gpu_kernels.py), two orders of
+// magnitude inside the 1e-3 activation tolerance.  Weights are split once (evt_split_weights);
+// activations are split while the gathered A tile is staged into LDS (v_cvt_pk_bf16_f32).
+// Same tiling as the fp32 kernel: 128x128x32, 2x2 waves of 2x2 32x32 accumulators, A rows gathered
+// through a_idx during staging, scatter epilogue, p_upd refresh by column-block 0.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int SP = BK + 8;  // bf16 LDS pitch: 80 bytes, 16 consecutive rows tile all 64 banks
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* lo) {
+  const f32x4_t x = {v.x, v.y, v.z, v.w};
+  const bf16x4_t h = __builtin_convertvector(x, bf16x4_t);
+  const f32x4_t r = x - __builtin_convertvector(h, f32x4_t);
+  *hi = h;
+  *lo = __builtin_convertvector(r, bf16x4_t);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(GEMM_THREADS) void gated_linear_split_kernel(const LinArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BM * SP];
+  __bf16* Ahi = lds;
+  __bf16* Alo = lds + BM * SP;
+  __bf16* Bhi = lds + 2 * BM * SP;
+  __bf16* Blo = lds + 3 * BM * SP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = g.B * g.kcap;
+
+  // A staging: thread -> (row r0 + 32*j, 4 floats at column c4*4), j = 0..3
+  const int r0 = tid >> 3, c4 = tid & 7;
+  const float* a_ptr[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 32 * j;
+    a_ok[j] = false;
+    a_ptr[j] = g.A;
+    if (m < M) {
+      const int b = m / g.kcap, i = m - b * g.kcap;
+      if (g.count == nullptr || i < g.count[b]) {
+        const int src = (g.a_idx != nullptr) ? g.a_idx[m] : i;
+        a_ptr[j] = g.A + ((int64_t)b * g.a_rows + src) * g.lda;
+        a_ok[j] = true;
+      }
+    }
+  }
+  // W staging: 16-byte chunks (8 bf16) of the hi and lo planes: chunk id = tid + 256*j, j = 0..1
+  const uint16_t* whi = g.Wsplit;
+  const uint16_t* wlo = g.Wsplit + (int64_t)g.Nout * g.K;
+  int w_row[2], w_c8[2];
+  bool w_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = tid + 256 * j;
+    w_row[j] = id >> 2;
+    w_c8[j] = (id & 3) * 8;
+    w_ok[j] = (n0 + w_row[j]) < g.Nout;
+  }
+
+  float4 ra[4];
+  uint4 rwh[2], rwl[2];
+  auto fetch = [&](int k0) {
+    const int kc = k0 + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kw = k0 + w_c8[j];
+      const bool ok = w_ok[j] && kw < g.K;  // K % 8 == 0 is required by the launcher
+      const int64_t o = (int64_t)(n0 + w_row[j]) * g.K + kw;
+      rwh[j] = ok ? *reinterpret_cast<const uint4*>(whi + o) : make_uint4(0, 0, 0, 0);
+      rwl[j] = ok ? *reinterpret_cast<const uint4*>(wlo + o) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4_t h, l;
+      split4(ra[j], &h, &l);
+      *reinterpret_cast<bf16x4_t*>(Ahi + (r0 + 32 * j) * SP + c4 * 4) = h;
+      *reinterpret_cast<bf16x4_t*>(Alo + (r0 + 32 * j) * SP + c4 * 4) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<uint4*>(Bhi + w_row[j] * SP + w_c8[j]) = rwh[j];
+      *reinterpret_cast<uint4*>(Blo + w_row[j] * SP + w_c8[j]) = rwl[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool do_upd = (g.p_upd != nullptr) && (blockIdx.x == 0);
+  float* u_ptr[4];
+  if (do_upd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
+  }
+  const int nk = (g.K + BK - 1) / BK;
+  const int lr = lane & 31, lh = lane >> 5;
+  fetch(0);
+  for (int t = 0; t < nk; ++t) {
+    stage();
+    if (do_upd) {
+      const int kc = t * BK + c4 * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
+    }
+    __syncthreads();
+    if (t + 1 < nk) fetch((t + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ao = (wm * 64 + i * 32 + lr) * SP + ks + 8 * lh;
+        const int bo = (wn * 64 + i * 32 + lr) * SP + ks + 8 * lh;
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
+        bh[i] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
+        bl[i] = *reinterpret_cast<const bf16x8_t*>(Blo + bo);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      const int b = m / g.kcap, ii = m - b * g.kcap;
+      if (g.count != nullptr && ii >= g.count[b]) continue;
+      const int dst = (g.o_idx != nullptr) ? g.o_idx[m] : ii;
+      float* orow = g.out + ((int64_t)b * g.o_rows + dst) * g.ldo;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + lr;
+        if (n < g.Nout) {
+          float v = acc[i][j][r] + g.bias[n];
+          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+          orow[n] = v;
+        }
+      }
+    }
+  }
+}
+
+// fp32 (rows, cols) -> bf16 hi plane followed by bf16 lo plane, hi = rne(x), lo = rne(x - hi).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                            int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  bf16x4_t h, l;
+  if (i + 4 <= n) {
+    split4(*reinterpret_cast<const float4*>(w + i), &h, &l);
+    *reinterpret_cast<bf16x4_t*>(out + i) = h;
+    *reinterpret_cast<bf16x4_t*>(out + n + i) = l;
+  } else {
+    for (int64_t q = i; q < n; ++q) {
+      const __bf16 hh = (__bf16)w[q];
+      const __bf16 ll = (__bf16)(w[q] - (float)hh);
+      reinterpret_cast<__bf16*>(out)[q] = hh;
+      reinterpret_cast<__bf16*>(out)[n + q] = ll;
+    }
+  }
+}
+
 int launch_linear(const LinArgs& a, void* stream) {
   const int M = a.B * a.kcap;
   if (M == 0) return EVT_OK;
   const dim3 grid((a.Nout + BN - 1) / BN, (M + BM - 1) / BM), block(GEMM_THREADS);
-  if (a.act == EVT_ACT_GELU_ERF)
+  if (a.Wsplit != nullptr) {
+    if (a.act == EVT_ACT_GELU_ERF)
+      hipLaunchKernelGGL(gated_linear_split_kernel<EVT_ACT_GELU_ERF>, grid, block, 0, evt_stream(stream), a);
+    else
+      hipLaunchKernelGGL(gated_linear_split_kernel<EVT_ACT_NONE>, grid, block, 0, evt_stream(stream), a);
+  } else if (a.act == EVT_ACT_GELU_ERF)
     hipLaunchKernelGGL(gated_linear_kernel<EVT_ACT_GELU_ERF>, grid, block, 0, evt_stream(stream), a);
   else
     hipLaunchKernelGGL(gated_linear_kernel<EVT_ACT_NONE>, grid, block, 0, evt_stream(stream), a);
@@ -201,7 +399,8 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
   EVT_REQUIRE(d->act == EVT_ACT_NONE || d->act == EVT_ACT_GELU_ERF, EVT_ERR_BAD_ARG, "evt_gated_linear: act=%d", d->act);
   EVT_REQUIRE(d->p_upd == nullptr || d->a_idx != nullptr, EVT_ERR_BAD_ARG, "evt_gated_linear: p_upd needs a_idx");
   EVT_REQUIRE(d->a_rows > 0 && d->o_rows > 0, EVT_ERR_BAD_ARG, "evt_gated_linear: a_rows/o_rows must be positive");
-  LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
+  EVT_REQUIRE(d->W_split == nullptr || (d->K & 7) == 0, EVT_ERR_BAD_SHAPE, "evt_gated_linear: split weights need K %% 8 == 0 (K=%d)", d->K);
+  LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act};
   return launch_linear(a, stream);
 }
@@ -212,11 +411,22 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
   EVT_REQUIRE(d->B >= 0 && d->kcap >= 0 && d->D > 0 && d->Dh > 0 && d->rows > 0, EVT_ERR_BAD_ARG, "evt_gated_mlp: bad sizes");
   EVT_REQUIRE((d->D & 3) == 0 && (d->Dh & 3) == 0 && (d->lda & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_gated_mlp: D, Dh, lda must be multiples of 4");
   EVT_REQUIRE(d->p_upd == nullptr || d->idx != nullptr, EVT_ERR_BAD_ARG, "evt_gated_mlp: p_upd needs idx");
-  LinArgs fc1{d->A, d->lda, d->idx, d->idx ? d->rows : d->kcap, d->W1, d->b1, d->hidden, (int64_t)d->Dh, nullptr,
+  EVT_REQUIRE((d->W1_split == nullptr) == (d->W2_split == nullptr), EVT_ERR_BAD_ARG, "evt_gated_mlp: W1_split/W2_split must come together");
+  EVT_REQUIRE(d->W1_split == nullptr || ((d->D & 7) == 0 && (d->Dh & 7) == 0), EVT_ERR_BAD_SHAPE, "evt_gated_mlp: split weights need D, Dh %% 8 == 0");
+  LinArgs fc1{d->A, d->lda, d->idx, d->idx ? d->rows : d->kcap, d->W1, (const uint16_t*)d->W1_split, d->b1, d->hidden, (int64_t)d->Dh, nullptr,
               d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF};
   int rc = launch_linear(fc1, stream);
   if (rc != EVT_OK) return rc;
-  LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, d->b2, d->out, d->ldo, d->idx,
+  LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, (const uint16_t*)d->W2_split, d->b2, d->out, d->ldo, d->idx,
               d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE};
   return launch_linear(fc2, stream);
+}
+
+extern "C" int evt_split_weights(const float* w, void* out, int64_t n, void* stream) {
+  EVT_REQUIRE(w != nullptr && out != nullptr && n >= 0, EVT_ERR_BAD_ARG, "evt_split_weights: bad arguments");
+  EVT_REQUIRE((n & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_split_weights: element count must be a multiple of 4");
+  if (n == 0) return EVT_OK;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, evt_stream(stream), w,
+                     (uint16_t*)out, n);
+  return evt_check_launch("evt_split_weights");
 }

@@ -23,7 +23,7 @@ _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EV
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_mlp", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated",
+    "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated",
 )
 
 
@@ -33,6 +33,7 @@ class LinearDesc(Structure):
         ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
         ("o_idx", c_void_p), ("o_rows", c_int32), ("count", c_void_p), ("p_upd", c_void_p),
         ("B", c_int32), ("kcap", c_int32), ("K", c_int32), ("Nout", c_int32), ("act", c_int32),
+        ("W_split", c_void_p),
     ]
 
 
@@ -42,6 +43,7 @@ class MlpDesc(Structure):
         ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
         ("hidden", c_void_p), ("out", c_void_p), ("ldo", c_int64), ("count", c_void_p),
         ("p_upd", c_void_p), ("B", c_int32), ("kcap", c_int32), ("D", c_int32), ("Dh", c_int32),
+        ("W1_split", c_void_p), ("W2_split", c_void_p),
     ]
 
 
@@ -105,6 +107,7 @@ def _bind(lib):
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
         "evt_gated_mlp": [POINTER(MlpDesc), P],
+        "evt_split_weights": [P, P, c_int64, P],
         "evt_qk": [POINTER(QkDesc), P],
         "evt_softmax_gate": [POINTER(SoftmaxDesc), P],
         "evt_v_gate": [P, P, P, I, I, I, I, P, P, P, I, I, I, P, I, I, P, P],
@@ -231,15 +234,35 @@ def _timed(flops, fn):
     GEMM_EVENTS.append((s, e, flops))
 
 
-def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE):
+# GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
+# (~1e-5 relative to fp32, ~5x the fp32-MFMA rate); "f32" = exact fp32-input MFMA.  EVT_GEMM overrides.
+GEMM_MODE = os.environ.get("EVT_GEMM", "split")
+
+
+def split_weight(W):
+    """Fresh bf16 hi/lo planes (2, out, in) of a weight matrix via evt_split_weights, or None when the
+    split path does not apply.  Callers cache the result (CountedLinear.split_planes)."""
+    if GEMM_MODE != "split" or (W.shape[-1] % 8) != 0:
+        return None
+    planes = torch.empty((2,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
+    _check(load().evt_split_weights(_p(W.detach()), _p(planes), W.numel(), _stream()))
+    return planes
+
+
+def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
+                 W_split=None):
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
-                   _p(p_upd), B, kcap, K, Nout, act)
+                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split))
     _timed(2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
-def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh):
+def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
+              W2_split=None):
+    s1, s2 = W1_split, W2_split
+    if s1 is None or s2 is None:
+        s1 = s2 = None
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
-                _p(p_upd), B, kcap, D, Dh)
+                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2))
     _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())))
 
 

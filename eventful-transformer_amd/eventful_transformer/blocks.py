@@ -188,7 +188,7 @@ class Block(ExtendedModule):
         D, rows = self.dim, B * N
         proj = self._ws("dense_proj", (B, N, D), torch.float32, attn)
         _native.gated_linear(attn, D, None, rows, self.projection.weight, self.projection.bias, proj, D, None, rows,
-                             None, None, 1, rows, D, D)
+                             None, None, 1, rows, D, D, W_split=self.projection.split_planes())
         self.projection.count_rows(rows)
         x2 = self._ws("x_mid", (B, N, D), torch.float32, attn)
         c = self._ws("gate_in", (B, N, D), torch.float32, attn)
@@ -199,7 +199,8 @@ class Block(ExtendedModule):
         hidden = self._ws("mlp_hidden", (rows, Dh), torch.float32, attn)
         mlp = self._ws("dense_mlp", (B, N, D), torch.float32, attn)
         _native.gated_mlp(c, D, None, rows, self.mlp_1.weight, self.mlp_1.bias, self.mlp_2.weight, self.mlp_2.bias,
-                          hidden, mlp, D, None, None, 1, rows, D, Dh)
+                          hidden, mlp, D, None, None, 1, rows, D, Dh, W1_split=self.mlp_1.split_planes(),
+                          W2_split=self.mlp_2.split_planes())
         self.mlp_1.count_rows(rows)
         self.mlp_2.count_rows(rows)
         out = torch.empty((B, N, D), dtype=torch.float32, device=attn.device)
@@ -216,7 +217,7 @@ class Block(ExtendedModule):
         _native.row_pass(x, rows, D, ln_w=w, ln_b=b, eps=LN_EPS, c_out=c)
         qkv = self._ws("dense_qkv", (B, N, 3 * D), torch.float32, x)
         _native.gated_linear(c, D, None, rows, self.qkv.weight, self.qkv.bias, qkv, 3 * D, None, rows, None, None, 1,
-                             rows, D, 3 * D)
+                             rows, D, 3 * D, W_split=self.qkv.split_planes())
         self.qkv.count_rows(rows)
         attn = self._ws("attn_out", (B, N, D), torch.float32, x)
         self._attention_dense(qkv, B, N, attn)
@@ -323,7 +324,7 @@ class EventfulTokenwiseBlock(Block):
             N = out.shape[1]
             _native.gated_linear(a, layer.in_features, idx, N if idx is not None else cap, layer.weight, layer.bias,
                                  out, layer.out_features, idx, N if idx is not None else cap, count, p_upd, B, cap,
-                                 layer.in_features, layer.out_features)
+                                 layer.in_features, layer.out_features, W_split=layer.split_planes())
             if layer.count_mode:
                 layer.count_rows(self._n_rows(B, cap, count))
         return run
@@ -333,7 +334,8 @@ class EventfulTokenwiseBlock(Block):
         D, Dh = self.dim, self.mlp_1.out_features
         hidden = self._ws("mlp_hidden", (B * cap, Dh), torch.float32, a)
         _native.gated_mlp(a, D, idx, N if idx is not None else cap, self.mlp_1.weight, self.mlp_1.bias,
-                          self.mlp_2.weight, self.mlp_2.bias, hidden, out, D, count, p_upd, B, cap, D, Dh)
+                          self.mlp_2.weight, self.mlp_2.bias, hidden, out, D, count, p_upd, B, cap, D, Dh,
+                          W1_split=self.mlp_1.split_planes(), W2_split=self.mlp_2.split_planes())
         if self.mlp_1.count_mode:
             n = self._n_rows(B, cap, count)
             self.mlp_1.count_rows(n)

@@ -93,6 +93,21 @@ class CountedLinear(ExtendedModule):
         self.out_features = out_features
         self.weight = nn.Parameter(torch.zeros((out_features, in_features), device=device, dtype=dtype))
         self.bias = nn.Parameter(torch.zeros(out_features, device=device, dtype=dtype))
+        self._split = None
+
+    def split_planes(self):
+        """bf16 hi/lo planes of `weight` for the split-precision MFMA path (None when it does not apply).
+        Cached against the weight's storage address + version and dropped on reset(), the same policy the
+        reference applies to its cached rel-pos tables / position encodings ("just in case new weights get
+        loaded", utils.py:102-105,191-195)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, _native.GEMM_MODE)
+        if self._split is None or self._split[0] != key:
+            self._split = (key, _native.split_weight(w))
+        return self._split[1]
+
+    def reset_self(self):
+        self._split = None
 
     def count_rows(self, rows):
         """Book the MACs of `rows` token rows going through this layer (used by the fused blocks)."""
@@ -126,7 +141,7 @@ class CountedLinear(ExtendedModule):
         rows = x2.shape[0]
         out = torch.empty(x.shape[:-1] + (self.out_features,), dtype=torch.float32, device=x.device)
         _native.gated_linear(x2, self.in_features, None, rows, self.weight, bias, out, self.out_features, None, rows,
-                             None, None, 1, rows, self.in_features, self.out_features)
+                             None, None, 1, rows, self.in_features, self.out_features, W_split=self.split_planes())
         return out
 
 

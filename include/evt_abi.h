@@ -129,9 +129,19 @@ typedef struct evt_linear_desc {
   float* p_upd;                            /* nullable: gate reference to refresh (ld = lda)    */
   int32_t B, kcap, K, Nout;
   int32_t act;                             /* evt_act                                           */
+  const void* W_split;                     /* nullable: evt_split_weights(W) -> split-precision  */
+                                           /* MFMA path (3 bf16 MFMAs per fp32 product)          */
 } evt_linear_desc;
 
 EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
+
+/* Split an fp32 weight matrix (n elements, n % 4 == 0) into two bf16 planes written back to back to
+ * `out` (2*n bf16): hi = rne_bf16(w), lo = rne_bf16(w - hi).  With W_split set, K3/K7 compute
+ * a.w = a_hi.w_hi + a_hi.w_lo + a_lo.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (activations are split on the fly); the dropped a_lo.w_lo term is <= 2^-16 per product, i.e. fp32
+ * activations still agree with the reference to ~1e-5 relative (tolerance 1e-3), at ~5x the
+ * fp32-input MFMA rate.  W_split == NULL keeps the exact fp32 MFMA kernel. */
+EVT_API int evt_split_weights(const float* w, void* out, int64_t n, void* stream);
 
 /* K7  Gated MLP: hidden = GELU(A[rows].W1^T + b1) -> out[rows] = hidden.W2^T + b2, as two MFMA
  * launches sharing one compact `hidden` scratch (B*kcap, Dh) provided by the caller.
@@ -145,6 +155,7 @@ typedef struct evt_mlp_desc {
   const int32_t* count;
   float* p_upd;
   int32_t B, kcap, D, Dh;
+  const void* W1_split; const void* W2_split;   /* nullable pair: split-precision MFMA path      */
 } evt_mlp_desc;
 
 EVT_API int evt_gated_mlp(const evt_mlp_desc* d, void* stream);

@@ -71,20 +71,21 @@ def main():
     n.v_gate(qkv, idx, None, B, N, D, k, vp, vd, vo, store, True)
 
     M = B * k
+    Sq, Sp, S1, S2 = (n.split_weight(t) for t in (Wqkv, Wp, W1, W2))
     cases = {
         "row_pass_ln_norm": (lambda: n.row_pass(x, B * N, D, ln_w=w, ln_b=w, c_out=c, p=p, norms=norms),
                              ("GB/s", 4 * B * N * D * 3)),
         "row_pass_norm_only": (lambda: n.row_pass(x, B * N, D, p=p, norms=norms), ("GB/s", 4 * B * N * D * 2)),
         "row_pass_add": (lambda: n.row_pass(x, B * N, D, res=p, sum_out=c), ("GB/s", 4 * B * N * D * 3)),
         "select_topk": (lambda: n.select_topk(norms, B, N, k, idx), ("GB/s", 4 * B * N)),
-        "linear_qkv": (lambda: n.gated_linear(x, D, idx, N, Wqkv, b3, qkv, 3 * D, idx, N, None, p, B, k, D, 3 * D),
+        "linear_qkv": (lambda: n.gated_linear(x, D, idx, N, Wqkv, b3, qkv, 3 * D, idx, N, None, p, B, k, D, 3 * D, W_split=Sq),
                        ("TF", 2.0 * M * D * 3 * D)),
-        "linear_proj": (lambda: n.gated_linear(x, D, idx, N, Wp, b1, buf, D, idx, N, None, p, B, k, D, D),
+        "linear_proj": (lambda: n.gated_linear(x, D, idx, N, Wp, b1, buf, D, idx, N, None, p, B, k, D, D, W_split=Sp),
                         ("TF", 2.0 * M * D * D)),
-        "mlp": (lambda: n.gated_mlp(x, D, idx, N, W1, b4, W2, b1, hidden, buf, D, None, p, B, k, D, 4 * D),
+        "mlp": (lambda: n.gated_mlp(x, D, idx, N, W1, b4, W2, b1, hidden, buf, D, None, p, B, k, D, 4 * D, W1_split=S1, W2_split=S2),
                 ("TF", 4.0 * M * D * 4 * D)),
         "linear_dense_qkv": (lambda: n.gated_linear(x, D, None, B * N, Wqkv, b3, qkv, 3 * D, None, B * N, None, None,
-                                                    1, B * N, D, 3 * D), ("TF", 2.0 * B * N * D * 3 * D)),
+                                                    1, B * N, D, 3 * D, W_split=Sq), ("TF", 2.0 * B * N * D * 3 * D)),
         "qk_delta": (lambda: n.qk_packed(qkv, B, N, D, H, 8.0, product, idx=idx, kcap=k),
                      ("TF", 2.0 * 2 * B * k * N * D)),
         "qk_full": (lambda: n.qk_packed(qkv, B, N, D, H, 8.0, product), ("TF", 2.0 * B * N * N * D)),

@@ -144,44 +144,74 @@ def test_vivit_b_full_size(golden_dir, mode, cast):
             y = bb(x)
             f = torch.nn.functional.layer_norm(y, (768,), w_d, b_d, 1e-6)[:, 0].cpu()
             worst = max(worst, float((f - feats[t]).abs().max()))
-        # gate sets of the LAST frame are still in the scratch of the last block only; re-run the
-        # last step block by block is unnecessary: compare per-block sets through forward hooks below
-    tol = 1e-3 if cast is None else 2e-2
+    # fp32: free-running features track the reference to 1e-3.  bf16 A.v cast: free-running is only a
+    # sanity bound -- gate decisions with margins down to 1e-8 flip under ANY rounding-order
+    # change and each flip moves features by O(1e-2); the reference's own fp32-vs-bf16 gap on this model is
+    # 6.6e-2.  The strict bf16 check is the teacher-forced test below.
+    tol = 1e-3 if cast is None else 1e-1
     assert worst <= tol, (mode, worst)
 
 
-def test_vivit_b_gate_sets_teacher_forced(golden_dir):
-    """Per-gate index sets on the full-size model, teacher-forced block by block: every block is fed
-    the ORACLE's input for that block, so each gate sees (up to fp32 rounding of its own block) the
-    reference's gate input.  Sets must match wherever the recorded margin is >= 1e-4."""
-    from eventful_transformer import _native, policies
+class _ForcedPolicy:
+    """Test double for teacher-forcing DECISIONS: records what the real HIP top-k policy selects on the
+    gate's delta, but hands the block the oracle's index set, so both sides refresh the same tokens."""
+
+    def __init__(self, k):
+        from eventful_transformer import policies
+        self.real = policies.TokenNormTopK(k)
+        self.force = None
+        self.mine = None
+
+    def __call__(self, e, dim=-1):
+        self.mine = self.real(e, dim=dim)
+        return self.force
+
+
+@pytest.mark.parametrize("mode,cast,out_tol,min_margin", [("fp32", None, 5e-4, 1e-4), ("bf16", "bfloat16", 1e-3, 1e-3)])
+def test_vivit_b_teacher_forced(golden_dir, mode, cast, out_tol, min_margin):
+    """Full-size ViViT-B, teacher-forced block by block AND gate by gate:
+      * every block is fed the ORACLE's input for that block;
+      * every gate is handed the oracle's index set (so near-tie decisions cannot fork the states), while
+        the set the HIP policy would have chosen is recorded;
+      * each block's fp32 output must match the oracle's (5e-4 fp32 mode, 1e-3 with the bf16 A.v cast);
+      * the recorded HIP selections must equal the reference's golden sets wherever the reference's margin
+        between the k-th and (k+1)-th norm is >= min_margin."""
     g = H.load_npz(os.path.join(golden_dir, "vivit_b.npz"))
-    seed = int(g["fp32__seed"])
-    model, sd, cls, ln_w, ln_b = H.vivit_oracle(None, seed=seed)
-    bb = H.product_vivit(sd, None)
-    H.set_policies(bb, policies.TokenNormTopK, k=128)
-    steps = 3
+    seed = int(g[f"{mode}__seed"])
+    model, sd, cls, ln_w, ln_b = H.vivit_oracle(cast, seed=seed)
+    bb = H.product_vivit(sd, cast)
+    gate_names = ("qkv_gate", "projection_gate", "mlp_gate")
+    trace_keys = ("qkv_index", "projection_index", "mlp_index")
+    for blk in bb.blocks:
+        for gn in gate_names + ("v_gate", "matmul_gate"):
+            getattr(blk, gn).policy = _ForcedPolicy(128)
+    steps = 4
     xs = O.make_token_stream(1, 196, 768, steps, 128, seed=seed + 2, small=0.01)
-    margins = g["fp32__margins"]
-    idx_gold = g["fp32__idx"]
+    margins = g[f"{mode}__margins"]
+    idx_gold = g[f"{mode}__idx"]
     checked = mismatched = 0
-    dev0 = torch.device(DEV, 0)
+    worst = 0.0
     with torch.inference_mode():
         for t in range(steps):
             x = torch.concat([cls.expand(1, 1, 768), xs[t]], dim=1) + model.backbone.encoding
             for bi, (ob, pb) in enumerate(zip(model.backbone.blocks, bb.blocks)):
-                y_dev = pb(x.to(DEV)).cpu()
                 y_ref = ob.forward(x)
-                assert float((y_dev - y_ref).abs().max()) <= 5e-4, (t, bi)
                 if t > 0:
-                    for gi, gname in enumerate(("qkv", "projection", "mlp")):
-                        got = _native.scratch(f"idx_{gname}", (1, 128), torch.int32, dev0).cpu().numpy()
-                        same = np.array_equal(got.astype(np.int64), idx_gold[t - 1, bi, gi].astype(np.int64))
-                        if margins[t - 1, bi, gi] >= 1e-4:
+                    for gn, tk in zip(gate_names, trace_keys):
+                        getattr(pb, gn).policy.force = ob.trace[tk].sort(dim=-1)[0].to(DEV)
+                y_dev = pb(x.to(DEV)).cpu()
+                err = float((y_dev - y_ref).abs().max())
+                worst = max(worst, err)
+                assert err <= out_tol, (mode, t, bi, err)
+                if t > 0:
+                    for gi, gn in enumerate(gate_names):
+                        mine = getattr(pb, gn).policy.mine.cpu().numpy()
+                        same = np.array_equal(mine, idx_gold[t - 1, bi, gi].astype(np.int64))
+                        if margins[t - 1, bi, gi] >= min_margin:
                             checked += 1
                             mismatched += (not same)
                 x = y_ref
-    assert checked >= 40 and mismatched == 0, (checked, mismatched)
+    assert checked >= 60 and mismatched == 0, (checked, mismatched)
 
 
 def _vitdet_run(golden_dir, fixture, grid, policy_cls, policy_kw, cast, stream_fn, stride, tol):

@@ -123,10 +123,61 @@ def test_select_tie_policy_and_edges():
         n.select_topk(norms, 2, 8, 9, idx)  # k > N raises like torch.topk
 
 
+@pytest.fixture(params=["split", "f32"])
+def gemm_mode(request):
+    """K3/K7 arithmetic: 'split' (bf16 hi/lo planes, 3 MFMAs per product) and 'f32' (exact fp32 MFMA)."""
+    n = native()
+    old = n.GEMM_MODE
+    n.GEMM_MODE = request.param
+    yield request.param
+    n.GEMM_MODE = old
+
+
+def test_split_weights_planes():
+    n = native()
+    g = torch.Generator().manual_seed(1)
+    W = (torch.randn(96, 64, generator=g) * torch.logspace(-6, 3, 64)).to(DEV)
+    old, n.GEMM_MODE = n.GEMM_MODE, "split"
+    try:
+        planes = n.split_weight(W)
+    finally:
+        n.GEMM_MODE = old
+    hi = W.to(torch.bfloat16)
+    lo = (W - hi.float()).to(torch.bfloat16)
+    assert torch.equal(planes[0], hi) and torch.equal(planes[1], lo)
+    rel = ((planes[0].float() + planes[1].float() - W).abs() / W.abs().clamp_min(1e-30)).max()
+    assert float(rel) < 2.0 ** -15
+
+
+def test_split_gemm_error_vs_fp64():
+    """The split-precision path is an fp32-accurate matmul: error vs fp64 ~1e-5 of the output scale, same
+    order as the fp32 MFMA kernel's own rounding noise, far inside the 1e-3 activation tolerance."""
+    n = native()
+    g = torch.Generator().manual_seed(7)
+    M, K, Nout = 512, 3072, 768
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) * 0.02
+    bias = torch.zeros(Nout)
+    ref = A.double() @ W.double().T
+    errs = {}
+    for mode in ("f32", "split"):
+        old, n.GEMM_MODE = n.GEMM_MODE, mode
+        try:
+            out = torch.empty(M, Nout, device=DEV)
+            Wd = W.to(DEV)
+            n.gated_linear(A.to(DEV), K, None, M, Wd, bias.to(DEV), out, Nout, None, M, None, None, 1, M, K, Nout,
+                           W_split=n.split_weight(Wd))
+        finally:
+            n.GEMM_MODE = old
+        errs[mode] = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert errs["f32"] < 2e-6, errs
+    assert errs["split"] < 3e-5, errs
+
+
 @pytest.mark.parametrize("B,N,K,Nout,k,act", [(2, 197, 768, 2304, 128, 0), (1, 37, 64, 192, 12, 0),
                                               (3, 50, 256, 64, 50, 1), (1, 300, 768, 3072, 131, 1),
                                               (2, 64, 3072, 768, 64, 0)])
-def test_gated_linear(B, N, K, Nout, k, act):
+def test_gated_linear(B, N, K, Nout, k, act, gemm_mode):
     n = native()
     g = torch.Generator().manual_seed(B * 1000 + N + K + Nout)
     A = torch.randn(B, N, K, generator=g)
@@ -142,7 +193,9 @@ def test_gated_linear(B, N, K, Nout, k, act):
     ref = buf0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, Nout), y.float())
     p_ref = p0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, K), rows)
     Ad, Wd, bd, idxd, buf, pd = (t.to(DEV) for t in (A, W, bias, idx, buf0, p0))
-    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf, Nout, idxd, N, None, pd, B, k, K, Nout, act)
+    Ws = n.split_weight(Wd)
+    assert (Ws is not None) == (gemm_mode == "split")
+    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf, Nout, idxd, N, None, pd, B, k, K, Nout, act, W_split=Ws)
     assert torch.allclose(buf.cpu(), ref, atol=2e-4, rtol=1e-4), float((buf.cpu() - ref).abs().max())
     mask = torch.ones(B, N, dtype=torch.bool)
     mask.scatter_(1, idx.long(), False)
@@ -151,7 +204,7 @@ def test_gated_linear(B, N, K, Nout, k, act):
     # variable count per clip (threshold policy): rows beyond count untouched
     count = torch.tensor([k // 2] + [k] * (B - 1), dtype=torch.int32)
     buf2 = buf0.to(DEV)
-    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf2, Nout, idxd, N, count.to(DEV), None, B, k, K, Nout, act)
+    n.gated_linear(Ad, K, idxd, N, Wd, bd, buf2, Nout, idxd, N, count.to(DEV), None, B, k, K, Nout, act, W_split=Ws)
     ref2 = buf0.clone()
     for b in range(B):
         sel = idx[b, : int(count[b])].long()
@@ -159,14 +212,14 @@ def test_gated_linear(B, N, K, Nout, k, act):
     assert torch.allclose(buf2.cpu(), ref2, atol=2e-4, rtol=1e-4)
     # dense mode (no index lists), as used on the first frame of a clip
     out = torch.empty(B * N, Nout, device=DEV)
-    n.gated_linear(Ad, K, None, B * N, Wd, bd, out, Nout, None, B * N, None, None, 1, B * N, K, Nout, act)
+    n.gated_linear(Ad, K, None, B * N, Wd, bd, out, Nout, None, B * N, None, None, 1, B * N, K, Nout, act, W_split=Ws)
     yd = torch.nn.functional.linear(A.double().reshape(-1, K), W.double(), bias.double())
     if act:
         yd = torch.nn.functional.gelu(yd)
     assert torch.allclose(out.cpu(), yd.float(), atol=2e-4, rtol=1e-4)
 
 
-def test_gated_mlp_matches_two_linears():
+def test_gated_mlp_matches_two_linears(gemm_mode):
     n = native()
     g = torch.Generator().manual_seed(11)
     B, N, D, Dh, k = 2, 40, 64, 256, 9
@@ -180,8 +233,9 @@ def test_gated_mlp_matches_two_linears():
     ref = buf0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, D), y)
     buf = buf0.to(DEV)
     hidden = torch.empty(B * k, Dh, device=DEV)
-    n.gated_mlp(A.to(DEV), D, idx.to(DEV), N, W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), hidden, buf, D, None,
-                None, B, k, D, Dh)
+    W1d, W2d = W1.to(DEV), W2.to(DEV)
+    n.gated_mlp(A.to(DEV), D, idx.to(DEV), N, W1d, b1.to(DEV), W2d, b2.to(DEV), hidden, buf, D, None,
+                None, B, k, D, Dh, W1_split=n.split_weight(W1d), W2_split=n.split_weight(W2d))
     assert torch.allclose(buf.cpu(), ref, atol=2e-4, rtol=1e-4)
 
 
