@@ -20,6 +20,7 @@
 // rows through o_idx (TokenBuffer update fused); column-block 0 also refreshes the gate reference
 // rows (p_upd) from the A tile it already holds.
 #include "evt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -193,7 +194,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int SP = BK + 8;  // bf16 LDS pitch: 80 bytes, 16 consecutive rows tile all 64 banks
 
 __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* lo) {
   const f32x4_t x = {v.x, v.y, v.z, v.w};
@@ -203,26 +203,53 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
   *lo = __builtin_convertvector(r, bf16x4_t);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(GEMM_THREADS) void gated_linear_split_kernel(const LinArgs g) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[4 * BM * SP];
+// Tile configuration: TBM x TBN output tile, TBK k-tile, WM x WN waves each owning a 64x64 sub-tile
+// (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
+// column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
+template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
+  static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (TBM + TBN) * TSP];
+  __shared__ int64_t orow_off[TBM];  // output row offset (elements) of each tile row, -1 = masked row
   __bf16* Ahi = lds;
-  __bf16* Alo = lds + BM * SP;
-  __bf16* Bhi = lds + 2 * BM * SP;
-  __bf16* Blo = lds + 3 * BM * SP;
+  __bf16* Alo = lds + TBM * TSP;
+  __bf16* Bhi = lds + 2 * TBM * TSP;
+  __bf16* Blo = lds + 2 * TBM * TSP + TBN * TSP;
 
+  // XCD-aware tile order (dispatch puts workgroup w on XCD w % 8): bijective for any tile count.
+  int tile;
+  {
+    const int w = blockIdx.x, q = tiles_total / 8, r = tiles_total % 8, x = w % 8, sidx = w / 8;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sidx;
+  }
+  const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = bm * TBM, n0 = bn * TBN;
   const int M = g.B * g.kcap;
 
-  // A staging: thread -> (row r0 + 32*j, 4 floats at column c4*4), j = 0..3
-  const int r0 = tid >> 3, c4 = tid & 7;
-  const float* a_ptr[4];
-  bool a_ok[4];
+  for (int r = tid; r < TBM; r += NT) {
+    const int m = m0 + r;
+    int64_t off = -1;
+    if (m < M) {
+      const int b = m / g.kcap, ii = m - b * g.kcap;
+      if (g.count == nullptr || ii < g.count[b])
+        off = ((int64_t)b * g.o_rows + ((g.o_idx != nullptr) ? g.o_idx[m] : ii)) * g.ldo;
+    }
+    orow_off[r] = off;
+  }
+  // A staging: float4 chunks, TBK/4 per row; thread -> rows ar0 + j*AROWS
+  constexpr int ACH = TBK / 4;           // float4 chunks per A row
+  constexpr int AROWS = NT / ACH;        // rows covered per pass
+  constexpr int AJ = TBM / AROWS;        // passes
+  const int ar0 = tid / ACH, ac4 = tid % ACH;
+  const float* a_ptr[AJ];
+  bool a_ok[AJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 32 * j;
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + ar0 + AROWS * j;
     a_ok[j] = false;
     a_ptr[j] = g.A;
     if (m < M) {
@@ -234,47 +261,43 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_split_kernel(const 
       }
     }
   }
-  // W staging: 16-byte chunks (8 bf16) of the hi and lo planes: chunk id = tid + 256*j, j = 0..1
+  // W staging: 16-byte chunks (8 bf16) of the hi and lo planes, TBK/8 per row
+  constexpr int WCH = TBK / 8;
+  constexpr int WROWS = NT / WCH;
+  constexpr int WJ = TBN / WROWS;
   const uint16_t* whi = g.Wsplit;
   const uint16_t* wlo = g.Wsplit + (int64_t)g.Nout * g.K;
-  int w_row[2], w_c8[2];
-  bool w_ok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int id = tid + 256 * j;
-    w_row[j] = id >> 2;
-    w_c8[j] = (id & 3) * 8;
-    w_ok[j] = (n0 + w_row[j]) < g.Nout;
-  }
+  const int wr0 = tid / WCH, wc8 = (tid % WCH) * 8;
 
-  float4 ra[4];
-  uint4 rwh[2], rwl[2];
+  float4 ra[AJ];
+  uint4 rwh[WJ], rwl[WJ];
   auto fetch = [&](int k0) {
-    const int kc = k0 + c4 * 4;
+    const int kc = k0 + ac4 * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < AJ; ++j)
       ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int kw = k0 + wc8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kw = k0 + w_c8[j];
-      const bool ok = w_ok[j] && kw < g.K;  // K % 8 == 0 is required by the launcher
-      const int64_t o = (int64_t)(n0 + w_row[j]) * g.K + kw;
+    for (int j = 0; j < WJ; ++j) {
+      const int n = n0 + wr0 + WROWS * j;
+      const bool ok = n < g.Nout && kw < g.K;  // K % 8 == 0 is required by the launcher
+      const int64_t o = (int64_t)n * g.K + kw;
       rwh[j] = ok ? *reinterpret_cast<const uint4*>(whi + o) : make_uint4(0, 0, 0, 0);
       rwl[j] = ok ? *reinterpret_cast<const uint4*>(wlo + o) : make_uint4(0, 0, 0, 0);
     }
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AJ; ++j) {
       bf16x4_t h, l;
       split4(ra[j], &h, &l);
-      *reinterpret_cast<bf16x4_t*>(Ahi + (r0 + 32 * j) * SP + c4 * 4) = h;
-      *reinterpret_cast<bf16x4_t*>(Alo + (r0 + 32 * j) * SP + c4 * 4) = l;
+      *reinterpret_cast<bf16x4_t*>(Ahi + (ar0 + AROWS * j) * TSP + ac4 * 4) = h;
+      *reinterpret_cast<bf16x4_t*>(Alo + (ar0 + AROWS * j) * TSP + ac4 * 4) = l;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      *reinterpret_cast<uint4*>(Bhi + w_row[j] * SP + w_c8[j]) = rwh[j];
-      *reinterpret_cast<uint4*>(Blo + w_row[j] * SP + w_c8[j]) = rwl[j];
+    for (int j = 0; j < WJ; ++j) {
+      *reinterpret_cast<uint4*>(Bhi + (wr0 + WROWS * j) * TSP + wc8) = rwh[j];
+      *reinterpret_cast<uint4*>(Blo + (wr0 + WROWS * j) * TSP + wc8) = rwl[j];
     }
   };
 
@@ -286,32 +309,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_split_kernel(const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_upd = (g.p_upd != nullptr) && (blockIdx.x == 0);
-  float* u_ptr[4];
+  const bool do_upd = (g.p_upd != nullptr) && (bn == 0);
+  float* u_ptr[AJ];
   if (do_upd) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
+    for (int j = 0; j < AJ; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
   }
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk = (g.K + TBK - 1) / TBK;
   const int lr = lane & 31, lh = lane >> 5;
   fetch(0);
   for (int t = 0; t < nk; ++t) {
     stage();
     if (do_upd) {
-      const int kc = t * BK + c4 * 4;
+      const int kc = t * TBK + ac4 * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < AJ; ++j)
         if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
     }
     __syncthreads();
-    if (t + 1 < nk) fetch((t + 1) * BK);
+    if (t + 1 < nk) fetch((t + 1) * TBK);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 16) {
+    for (int ks = 0; ks < TBK; ks += 16) {
       bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ao = (wm * 64 + i * 32 + lr) * SP + ks + 8 * lh;
-        const int bo = (wn * 64 + i * 32 + lr) * SP + ks + 8 * lh;
+        const int ao = (wm * 64 + i * 32 + lr) * TSP + ks + 8 * lh;
+        const int bo = (wn * 64 + i * 32 + lr) * TSP + ks + 8 * lh;
         ah[i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
         al[i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
         bh[i] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
@@ -326,29 +350,58 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_split_kernel(const 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
+  float bv[2];
+  int ncol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ncol[j] = n0 + wn * 64 + j * 32 + lr;
+    bv[j] = ncol[j] < g.Nout ? g.bias[ncol[j]] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-      const int b = m / g.kcap, ii = m - b * g.kcap;
-      if (g.count != nullptr && ii >= g.count[b]) continue;
-      const int dst = (g.o_idx != nullptr) ? g.o_idx[m] : ii;
-      float* orow = g.out + ((int64_t)b * g.o_rows + dst) * g.ldo;
+      const int64_t off = orow_off[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      if (off < 0) continue;
+      float* orow = g.out + off;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + lr;
-        if (n < g.Nout) {
-          float v = acc[i][j][r] + g.bias[n];
+        if (ncol[j] < g.Nout) {
+          float v = acc[i][j][r] + bv[j];
           if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-          orow[n] = v;
+          orow[ncol[j]] = v;
         }
       }
     }
+  }
+}
+
+template <int TBM, int TBN, int TBK, int WM, int WN>
+void launch_split_cfg(const LinArgs& a, hipStream_t s) {
+  const int M = a.B * a.kcap;
+  const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
+  const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  if (a.act == EVT_ACT_GELU_ERF)
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
+                       tiles_n, tiles_m * tiles_n);
+  else
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
+                       tiles_n, tiles_m * tiles_n);
+}
+
+void launch_split(const LinArgs& a, hipStream_t s) {
+  static const int variant = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : 0;
+  switch (variant) {
+    case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
+    case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
+    case 3: launch_split_cfg<256, 128, 64, 4, 2>(a, s); break;
+    case 4: launch_split_cfg<128, 256, 32, 2, 4>(a, s); break;
+    case 5: launch_split_cfg<256, 256, 32, 4, 4>(a, s); break;
+    default: launch_split_cfg<128, 128, 32, 2, 2>(a, s); break;
   }
 }
 
@@ -377,10 +430,7 @@ int launch_linear(const LinArgs& a, void* stream) {
   if (M == 0) return EVT_OK;
   const dim3 grid((a.Nout + BN - 1) / BN, (M + BM - 1) / BM), block(GEMM_THREADS);
   if (a.Wsplit != nullptr) {
-    if (a.act == EVT_ACT_GELU_ERF)
-      hipLaunchKernelGGL(gated_linear_split_kernel<EVT_ACT_GELU_ERF>, grid, block, 0, evt_stream(stream), a);
-    else
-      hipLaunchKernelGGL(gated_linear_split_kernel<EVT_ACT_NONE>, grid, block, 0, evt_stream(stream), a);
+    launch_split(a, evt_stream(stream));
   } else if (a.act == EVT_ACT_GELU_ERF)
     hipLaunchKernelGGL(gated_linear_kernel<EVT_ACT_GELU_ERF>, grid, block, 0, evt_stream(stream), a);
   else
