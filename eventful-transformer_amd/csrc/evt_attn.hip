@@ -14,7 +14,8 @@ namespace {
 //   part 0 (FULL)      : rm, cn identity                         (modules.py:224-230)
 //   part 1 (DELTA rows): rm = idx_q, cn identity                  (modules.py:236-241)
 //   part 2 (DELTA cols): rm identity, cn = idx_k                  (modules.py:242-247)
-// 64x64 output tile per workgroup, one 32x32 MFMA accumulator per wave, K = dh in one LDS pass.
+// 128x128 output tile per workgroup (2x2 waves of 2x2 32x32 MFMA accumulators); the head dim is staged
+// through LDS in chunks of 32 with register prefetch of the next chunk under the MFMAs.
 // q / k are addressed as base + clip*bs + token*rs + head*hs so both the packed (B,N,3D) token
 // buffer of the blocks and free-standing (B,H,N,dh) tensors fit.
 // =============================================================================================
@@ -38,13 +39,15 @@ __device__ __forceinline__ const float* qk_row(const float* base, int64_t bs, in
   return base + (int64_t)(g / gpc) * bs + (int64_t)r * rs;
 }
 
+constexpr int QT = 128;   // output tile edge
+constexpr int QKC = 32;   // head-dim chunk staged per pass (LDS 2 x 128 x 36 floats = 36 KB -> 4 workgroups / CU)
+constexpr int QLD = QKC + 4;
+
 __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ldt = a.dh + 4;
-  float* As = smem;
-  float* Bs = smem + 64 * ldt;
-  int* rmap = reinterpret_cast<int*>(Bs + 64 * ldt);  // 64 output rows
-  int* cmap = rmap + 64;                              // 64 output cols
+  __shared__ __attribute__((aligned(16))) float As[QT * QLD];
+  __shared__ __attribute__((aligned(16))) float Bs[QT * QLD];
+  __shared__ int rmap[QT];
+  __shared__ int cmap[QT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int z = blockIdx.z;
@@ -54,80 +57,123 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
   const int b = a.tok_map ? g / a.groups_per_clip : g;
   int m_lim, n_lim, m0, n0;
   if (part == 2) {
-    m0 = blockIdx.x * 64; n0 = blockIdx.y * 64;
+    m0 = blockIdx.x * QT; n0 = blockIdx.y * QT;
     m_lim = a.Nq; n_lim = a.count_k ? a.count_k[b] : a.kcap_k;
   } else {
-    m0 = blockIdx.y * 64; n0 = blockIdx.x * 64;
+    m0 = blockIdx.y * QT; n0 = blockIdx.x * QT;
     m_lim = (part == 1) ? (a.count_q ? a.count_q[b] : a.kcap_q) : a.Nq; n_lim = a.Nk;
   }
   if (m0 >= m_lim || n0 >= n_lim) return;
 
-  if (tid < 64) {
-    const int m = m0 + tid;
-    rmap[tid] = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m] : m) : -1;
-  } else if (tid < 128) {
-    const int n = n0 + tid - 64;
-    cmap[tid - 64] = (n < n_lim) ? ((part == 2) ? a.idx_k[(int64_t)b * a.kcap_k + n] : n) : -1;
-  }
-  __syncthreads();
-
-  const int v4 = a.dh >> 2;
-  for (int e = tid; e < 64 * v4; e += 256) {
-    const int r = e / v4, c4 = e - r * v4;
-    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), kb = qa;
-    const int tm = rmap[r], tn = cmap[r];
-    if (tm >= 0) {
-      const float* row = qk_row(a.q, a.q_bs, a.q_rs, a.tok_map, a.groups_per_clip, a.pad_q, g, tm, a.Nq);
-      qa = *reinterpret_cast<const float4*>(row + h * a.q_hs + c4 * 4);
-      qa.x /= a.scale; qa.y /= a.scale; qa.z /= a.scale; qa.w /= a.scale;  // q / self.scale, blocks.py:514
-    }
-    if (tn >= 0) {
-      const float* row = qk_row(a.k, a.k_bs, a.k_rs, a.tok_map, a.groups_per_clip, a.pad_k, g, tn, a.Nk);
-      kb = *reinterpret_cast<const float4*>(row + h * a.k_hs + c4 * 4);
-    }
-    *reinterpret_cast<float4*>(As + r * ldt + c4 * 4) = qa;
-    *reinterpret_cast<float4*>(Bs + r * ldt + c4 * 4) = kb;
-  }
-  __syncthreads();
-
-  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-  f32x16 acc;
+  // staging assignment: thread -> rows r0 + 32 j (j = 0..3), one float4 at column c4 * 4 of the chunk
+  const int r0 = tid >> 3, c4 = tid & 7;
+  const float* qp[4];
+  const float* kp[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int half = a.dh >> 1;  // k-range per lane half (multiple of 4)
-  const float* pa = As + (wm * 32 + lr) * ldt + lh * half;
-  const float* pb = Bs + (wn * 32 + lr) * ldt + lh * half;
-  for (int q = 0; q < half; q += 4) {
-    const float4 fa = *reinterpret_cast<const float4*>(pa + q);
-    const float4 fb = *reinterpret_cast<const float4*>(pb + q);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + 32 * j;
+    const int m = m0 + r, n = n0 + r;
+    const int tm = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m] : m) : -1;
+    const int tn = (n < n_lim) ? ((part == 2) ? a.idx_k[(int64_t)b * a.kcap_k + n] : n) : -1;
+    if (c4 == 0) { rmap[r] = tm; cmap[r] = tn; }
+    qp[j] = (tm >= 0) ? qk_row(a.q, a.q_bs, a.q_rs, a.tok_map, a.groups_per_clip, a.pad_q, g, tm, a.Nq) + h * a.q_hs : nullptr;
+    kp[j] = (tn >= 0) ? qk_row(a.k, a.k_bs, a.k_rs, a.tok_map, a.groups_per_clip, a.pad_k, g, tn, a.Nk) + h * a.k_hs : nullptr;
+  }
+  // q / self.scale (blocks.py:514): a power-of-two scale (dh = 16, 64, 256) makes x * (1/scale) exact
+  const float inv = 1.0f / a.scale;
+  const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+
+  float4 rq[4], rk[4];
+  auto fetch = [&](int d0) {
+    const int d = d0 + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rq[j] = (qp[j] != nullptr && d < a.dh) ? *reinterpret_cast<const float4*>(qp[j] + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rk[j] = (kp[j] != nullptr && d < a.dh) ? *reinterpret_cast<const float4*>(kp[j] + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  // 2 x 2 waves, each a 64 x 64 region = 2 x 2 accumulators of 32 x 32; sub-tiles wholly outside the
+  // valid range are skipped (N = 197 -> 7 of 8 32-wide column groups are live).
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  bool live_m[2], live_n[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    live_m[i] = (m0 + wm * 64 + i * 32) < m_lim;
+    live_n[i] = (n0 + wn * 64 + i * 32) < n_lim;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  for (int d0 = 0; d0 < a.dh; d0 += QKC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 qa = rq[j];
+      if (pow2) { qa.x *= inv; qa.y *= inv; qa.z *= inv; qa.w *= inv; }
+      else { qa.x /= a.scale; qa.y /= a.scale; qa.z /= a.scale; qa.w /= a.scale; }
+      *reinterpret_cast<float4*>(As + (r0 + 32 * j) * QLD + c4 * 4) = qa;
+      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * QLD + c4 * 4) = rk[j];
+    }
+    __syncthreads();
+    if (d0 + QKC < a.dh) fetch(d0 + QKC);
+    // lane half lh covers k in [16 lh, 16 lh + 16) of the chunk (k order is free inside a sum)
+#pragma unroll
+    for (int q = 0; q < QKC / 2; q += 4) {
+      float4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const float4*>(As + (wm * 64 + i * 32 + lr) * QLD + lh * (QKC / 2) + q);
+        fb[i] = *reinterpret_cast<const float4*>(Bs + (wn * 64 + i * 32 + lr) * QLD + lh * (QKC / 2) + q);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (!(live_m[i] && live_n[j])) continue;  // wave-uniform
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
   }
   float* out = a.product + ((int64_t)g * a.H + h) * a.Nq * a.Nk;
-  const int cn = cmap[wn * 32 + lr];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rm = rmap[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-    if (rm >= 0 && cn >= 0) out[(int64_t)rm * a.Nk + cn] = acc[r];
+  for (int j = 0; j < 2; ++j) {
+    if (!live_n[j]) continue;
+    const int cn = cmap[wn * 64 + j * 32 + lr];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!live_m[i]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rm = rmap[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        if (rm >= 0 && cn >= 0) out[(int64_t)rm * a.Nk + cn] = acc[i][j][r];
+      }
+    }
   }
 }
 
 int launch_qk(const QkArgs& a, void* stream) {
-  const size_t lds = (size_t)(2 * 64 * (a.dh + 4)) * sizeof(float) + 128 * sizeof(int);
-  const int ntq = (a.Nq + 63) / 64, ntk = (a.Nk + 63) / 64;
+  const int ntq = (a.Nq + QT - 1) / QT, ntk = (a.Nk + QT - 1) / QT;
   dim3 grid;
   if (a.delta) {
     // part 1: x -> Nk tiles, y -> kcap_q tiles; part 2: x -> Nq tiles, y -> kcap_k tiles
     const int gx = ntq > ntk ? ntq : ntk;
-    const int ky = ((a.kcap_q > a.kcap_k ? a.kcap_q : a.kcap_k) + 63) / 64;
+    const int ky = ((a.kcap_q > a.kcap_k ? a.kcap_q : a.kcap_k) + QT - 1) / QT;
     grid = dim3(gx, ky, a.G * a.H * 2);
   } else {
     grid = dim3(ntk, ntq, a.G * a.H);
   }
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return EVT_OK;
-  hipLaunchKernelGGL(qk_kernel, grid, dim3(256), lds, evt_stream(stream), a);
+  hipLaunchKernelGGL(qk_kernel, grid, dim3(256), 0, evt_stream(stream), a);
   return evt_check_launch("evt_qk");
 }
 
