@@ -238,6 +238,16 @@ def main():
     frames_total = world * args.clips * args.frames * args.steps
     value = frames_total / elapsed
 
+    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+    # read in-process); profiles/*/pmc_traffic_*.json holds the per-launch figure for the workload it names.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_B64.json")))
+        wl = pmc["workload"]
+        if (wl["clips"], wl["frames"], wl["k"], wl["cast"], wl["gemm"]) == (args.clips, args.frames, args.k, cast, _native.GEMM_MODE):
+            traffic = pmc["gated_linear_hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = None
     if events:
         ms = sum(s.elapsed_time(e) for s, e, _ in events)
@@ -252,7 +262,8 @@ def main():
                     "kernel": ("gated_linear_split_kernel" if split else "gated_linear_kernel") +
                               " (evt_gated_linear / evt_gated_mlp)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01/pmc_traffic_B64.json",
                     "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
                     "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
                     "launches": len(events), "avg_launch_us": round(ms * 1e3 / len(events), 2),
