@@ -250,8 +250,9 @@ def main():
         traffic = None
     roofline = None
     if events:
-        ms = sum(s.elapsed_time(e) for s, e, _ in events)
-        flops = sum(f for _, _, f in events)
+        ms = sum(ev[0].elapsed_time(ev[1]) for ev in events)
+        flops = sum(ev[2] for ev in events)
+        launches = sum(ev[3] for ev in events)
         achieved = flops / (ms * 1e-3) / 1e12
         split = _native.GEMM_MODE == "split"
         # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
@@ -266,7 +267,7 @@ def main():
                     "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01/pmc_traffic_B64.json",
                     "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
                     "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
-                    "launches": len(events), "avg_launch_us": round(ms * 1e3 / len(events), 2),
+                    "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
 
     if rank == 0:

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void softmax_gate_kernel(const SmArgs a) {
   float* rx = ry + a.gh;
 
   const bool rel = a.rel_y != nullptr;
+  const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
   if (rel) {
     const float* qrow = evt_token_row(a.qkv, 3 * (int64_t)a.D, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row,
                                       g, i, a.N) + h * a.dh;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void softmax_gate_kernel(const SmArgs a) {
   for (int j = lane; j < a.Nk; j += 64) {
     float x = prow[j];
     if (rel) {
-      const int ky = j / a.gw;
+      const int ky = fast_div(j, inv_gw);
       // (x + ty) + tx: the reference adds the y term first (utils.py:159-168)
       x = (x + ry[ky]) + rx[j - ky * a.gw];
     }

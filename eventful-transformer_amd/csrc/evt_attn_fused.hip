@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   const int cnt = a.count ? a.count[b] : a.kcap;
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;
+  const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
   const float* prod = a.product + (int64_t)bh * a.N * a.N;
   T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.N;
   const int32_t* ix = a.idx + (int64_t)b * a.kcap;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
         float x = -INFINITY;
         if (j < a.N) {
           x = prow[j];
-          if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+          if (rel) { const int ky = fast_div(j, inv_gw); x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
         }
         xv[rr][u] = x;
       }
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();  // each wave only ever reads back its own 8 rows
   } else {
+    // any N: ONE pass over the row with an online (running max / rescaled sum) softmax, 8 independent
+    // 256-byte wave loads in flight per step so the cold HBM stream is not latency-serialised.
 #pragma unroll 1
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
@@ -184,20 +187,35 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       if (i >= a.N) continue;  // wave-uniform
       const float* rv = relv + r * nrel;
       const float* prow = prod + (int64_t)i * a.N;
-      float mx = -INFINITY;
-      for (int j = lane; j < a.N; j += 64) {
-        float x = prow[j];
-        if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
-        mx = fmaxf(mx, x);
+      float mx = -INFINITY, sum = 0.f;
+      for (int j0 = 0; j0 < a.N; j0 += 512) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + lane + 64 * u;
+          x[u] = (j < a.N) ? prow[j] : -INFINITY;
+        }
+        if (rel) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + lane + 64 * u;
+            if (j < a.N) { const int ky = fast_div(j, inv_gw); x[u] = (x[u] + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+          }
+        }
+        float cm = x[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) cm = fmaxf(cm, x[u]);
+        const float nm = fmaxf(mx, cm);
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part += fast_exp(x[u] - nm);   // exp(-inf) == 0 for masked / empty
+        sum = (nm == -INFINITY) ? 0.f : sum * fast_exp(mx - nm) + part;
+        mx = nm;
       }
-      mx = wave_max(mx);
-      float sum = 0.f;
-      for (int j = lane; j < a.N; j += 64) {
-        float x = prow[j];
-        if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
-        sum += fast_exp(x - mx);
-      }
-      rmax[rr] = mx;
+      // combine the 64 per-lane (max, sum) pairs
+      const float wmx = wave_max(mx);
+      sum = (mx == -INFINITY) ? 0.f : sum * fast_exp(mx - wmx);
+      rmax[rr] = wmx;
       rsum[rr] = wave_sum(sum);
     }
   }
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
             e = et[r * EP + j];
           } else {
             float x = prow[j];
-            if (rel) { const int ky = j / a.gw; x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+            if (rel) { const int ky = fast_div(j, inv_gw); x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
             e = fast_exp(x - rmax[rr]);
           }
           an = Store<T>::round(e / rsum[rr]);

@@ -40,6 +40,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// j -> (j / gw, j % gw) without an integer division: (j + 0.5) / gw is at least 0.5/gw away from every
+// integer, far more than fp32 rounding for j < 2^20, gw <= 4096, so truncation is exact.
+__device__ __forceinline__ int fast_div(int j, float inv_gw) { return (int)(((float)j + 0.5f) * inv_gw); }
+
 // Storage types for tensors the reference keeps in the `matmul_2_cast` dtype (blocks.py:183-189).
 // Round-to-nearest-even on store, exact widening on load.
 struct bf16_t { uint16_t u; };

@@ -224,14 +224,14 @@ def scatter_rows(x, buf, idx, count, B, N, F, kcap):
 GEMM_EVENTS = None
 
 
-def _timed(flops, fn):
+def _timed(flops, fn, launches=1):
     if GEMM_EVENTS is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
-    GEMM_EVENTS.append((s, e, flops))
+    GEMM_EVENTS.append((s, e, flops, launches))
 
 
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
@@ -263,7 +263,7 @@ def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd,
         s1 = s2 = None
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
                 _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2))
-    _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())))
+    _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
 
 
 def _ptr_off(t, elems):
