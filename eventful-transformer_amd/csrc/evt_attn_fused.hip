@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   T* Ad = An + FR * P;                                 // [FR][P]
   T* Vd = Ad + FR * P;                                 // [dh][P]
   T* Vo = Vd + a.dh * P;                               // [dh][P]
+  const bool rel_lds = a.rel_y != nullptr;
   float* relv = reinterpret_cast<float*>(Vo + a.dh * P);  // [FR][gh+gw] rel-pos terms per row
-  float* qs = relv + FR * (a.gh + a.gw);               // [4][dh]     per-wave q row
-  float* et = qs + 4 * a.dh;                           // [FR][EP] exp(x - max) (NREG > 0), later the
+  float* qs = relv + FR * (a.gh + a.gw);               // [FR][dh]    q rows (rel-pos only)
+  float* et = qs + (rel_lds ? FR : 0) * a.dh;                           // [FR][EP] exp(x - max) (NREG > 0), later the
   float* red1 = et;                                    // [FR][dh] round(a~ . dv~)   (aliases et)
   float* red2 = et + FR * a.dh;                        // [FR][dh] round(da~ . v_old)
   const int EP = a.N | 1;                              // odd pitch: row-strided LDS access conflict-free
@@ -114,30 +115,39 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   // ---- phase 1: per-row softmax statistics; wave w owns rows w*8 .. w*8+7 -----------------------
   float rmax[8], rsum[8];
   if (rel) {
-#pragma unroll 1
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr, i = i0 + r;
-      if (i >= a.N) break;  // wave-uniform
-      float* rv = relv + r * nrel;
-      const float* qrow = a.qkv + ((int64_t)b * a.N + i) * 3 * a.D + h * a.dh;
-      for (int d = lane; d < a.dh; d += 64) qs[wave * a.dh + d] = qrow[d];
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      const int yi = i / a.gw, xi = i - yi * a.gw;
-      for (int e = lane; e < nrel; e += 64) {
-        const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * a.dh
-                                      : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * a.dh;
-        float s = 0.f;
-        for (int d = 0; d < a.dh; d += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(tab + d);
-          const float* q = qs + wave * a.dh + d;
-          s += q[0] * t.x + q[1] * t.y + q[2] * t.z + q[3] * t.w;
-        }
-        rv[e] = s;
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
+    // rel-pos terms of the workgroup's 32 rows (utils.py:159-168): q rows staged once in LDS, then the
+    // 32 x (gh + gw) dot products are spread over all 256 threads (8 threads per row), head dim unrolled
+    // so the 16-byte table loads of one dot are all in flight together.
+    constexpr int DH = 64 * TPW;
+    for (int e = tid; e < FR * (DH / 4); e += 256) {
+      const int r = e / (DH / 4), c4 = e - r * (DH / 4), i = i0 + r;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < a.N) q = *reinterpret_cast<const float4*>(a.qkv + ((int64_t)b * a.N + i) * 3 * a.D + h * DH + c4 * 4);
+      *reinterpret_cast<float4*>(qs + r * DH + c4 * 4) = q;
     }
+    __syncthreads();
+    {
+      const int r = tid >> 3, sub = tid & 7, i = i0 + r;
+      if (i < a.N) {
+        const int yi = fast_div(i, inv_gw), xi = i - yi * a.gw;
+        const float* q = qs + r * DH;
+        for (int e = sub; e < nrel; e += 8) {
+          const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * DH
+                                        : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * DH;
+          float4 t[DH / 4];
+#pragma unroll
+          for (int d = 0; d < DH / 4; ++d) t[d] = *reinterpret_cast<const float4*>(tab + d * 4);
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int d = 0; d < DH / 4; d += 2) {
+            s0 += q[4 * d] * t[d].x + q[4 * d + 1] * t[d].y + q[4 * d + 2] * t[d].z + q[4 * d + 3] * t[d].w;
+            s1 += q[4 * d + 4] * t[d + 1].x + q[4 * d + 5] * t[d + 1].y + q[4 * d + 6] * t[d + 1].z + q[4 * d + 7] * t[d + 1].w;
+          }
+          relv[r * nrel + e] = s0 + s1;
+        }
+      }
+    }
+    __syncthreads();
   }
   if (NREG > 0) {
     float xv[8][NREG > 0 ? NREG : 1];
@@ -361,7 +371,7 @@ int launch_fused(const FusedArgs& a, void* stream) {
   const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.N | 1) : 0;        // exp tile (aliases the two
   const size_t tile_r = (size_t)2 * FR * a.dh;                          // rounded-product tiles)
   const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) +
-                     ((tile_e > tile_r ? tile_e : tile_r) + FR * (a.gh + a.gw) + 4 * a.dh) * sizeof(float);
+                     ((tile_e > tile_r ? tile_e : tile_r) + FR * (a.gh + a.gw) + (a.rel_y ? FR * a.dh : 0)) * sizeof(float);
   const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
   if (grid.y == 0) return EVT_OK;
   hipStream_t s = evt_stream(stream);

@@ -394,13 +394,15 @@ void launch_split_cfg(const LinArgs& a, hipStream_t s) {
 }
 
 void launch_split(const LinArgs& a, hipStream_t s) {
-  static const int variant = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : 0;
+  static const int forced = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : -1;
+  const int variant = forced < 0 ? 0 : forced;
   switch (variant) {
     case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
     case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
     case 3: launch_split_cfg<256, 128, 64, 4, 2>(a, s); break;
     case 4: launch_split_cfg<128, 256, 32, 2, 4>(a, s); break;
     case 5: launch_split_cfg<256, 256, 32, 4, 4>(a, s); break;
+    case 6: launch_split_cfg<64, 64, 32, 1, 1>(a, s); break;
     default: launch_split_cfg<128, 128, 32, 2, 2>(a, s); break;
   }
 }
