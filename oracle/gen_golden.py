@@ -371,13 +371,39 @@ def gen_vitdet1024():
     np.savez_compressed(os.path.join(OUT, "vitdet_1024.npz"), **pack)
 
 
+
+
+def gen_counts():
+    """Reference MAC counters (I5) for a small 3-block backbone (windowed EventfulTokenwiseBlock with
+    rel-pos + two EventfulBlocks, one with rel-pos), 2 clips, 3 frames, top-k."""
+    from eventful_transformer.base import Counts  # noqa: F401
+    dim, heads, grid, k = 64, 4, (6, 6), 12
+    cfg = dict(dim=dim, heads=heads, mlp_ratio=4, relative_embedding_size=(8, 8), window_size=(3, 3))
+    ref = RefBackbone(block_config=cfg, depth=3, position_encoding_size=(3, 3), input_size=grid,
+                      block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock", window_indices=(0,)).eval()
+    ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k))
+    xs = O.make_token_stream(2, 36, dim, 3, k, seed=11, small=0.02)
+    ref.counting()
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    with torch.inference_mode():
+        for t in range(3):
+            ref.clear_counts()
+            ref(xs[t].clone())
+            c = ref.total_counts()
+            for key, val in c.items():
+                pack[f"t{t}__{key}"] = np.int64(val)
+            print("counts", t, dict(c))
+    np.savez_compressed(os.path.join(OUT, "counts.npz"), **pack)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vitdet672": gen_vitdet672,
-            "vitdet1024": gen_vitdet1024}
+            "vitdet1024": gen_vitdet1024, "counts": gen_counts}
     for name, fn in todo.items():
         if args.only in (None, name):
             fn()
+

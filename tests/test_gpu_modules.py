@@ -1,0 +1,172 @@
+"""GPU: the reference's stand-alone module / policy API on HIP tensors
+against the oracle, plus reference-pinned MAC counters (I5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import eventful_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _asc(index):
+    return index.sort(dim=-1)[0]
+
+
+def test_policies_standalone():
+    from eventful_transformer import policies
+    c, p = O.make_gate_case(3, 2, 197, 768)
+    e = c - p
+    top = policies.TokenNormTopK(k=64, save_status=True)
+    got = top(e.to(DEV))
+    assert got.dtype == torch.int64 and got.shape == (2, 64) and got.device.type == "cuda"
+    assert torch.equal(got.cpu(), _asc(O.TopK(64)(e)))
+    assert torch.equal(top.last_output, got) and torch.equal(top.last_input.cpu(), e)
+    frac = policies.TokenNormTopFraction(0.25)
+    assert torch.equal(frac(e.to(DEV)).cpu(), _asc(O.TopFraction(0.25)(e)))
+    # norm over dim=-2 (column structure): tokens along the last dim
+    assert torch.equal(top(e.transpose(1, 2).contiguous().to(DEV), dim=-2).cpu(), _asc(O.TopK(64)(e)))
+    c1, p1, thr = O.make_threshold_case(5, 300, 128, 41)
+    thr_pol = policies.TokenNormThreshold(threshold=thr)
+    got = thr_pol((c1 - p1).to(DEV))
+    assert got.shape == (1, 41) and torch.equal(got.cpu(), O.Threshold(thr)(c1 - p1))
+    with pytest.raises(AssertionError):
+        thr_pol(e.to(DEV))  # batch > 1, policies.py:25
+
+
+@pytest.mark.parametrize("delta", [False, True])
+def test_token_gates_standalone(delta):
+    """TokenGate / TokenDeltaGate .forward(c[, forced_index]) with the reference's returns and state."""
+    from eventful_transformer import modules, policies
+    cls = modules.TokenDeltaGate if delta else modules.TokenGate
+    ogate = O.token_delta_gate if delta else O.token_gate
+    gate, slot = cls(), O.Slot()
+    gate.policy = policies.TokenNormTopK(k=9)
+    xs = O.make_token_stream(2, 40, 64, 4, 9, seed=1, small=0.05)
+    for t in range(3):
+        out = gate(xs[t].clone().to(DEV))
+        ref = ogate(slot, xs[t].clone(), O.TopK(9))
+        if t == 0:
+            assert out[-1] is None and torch.equal(out[0].cpu(), ref[0])
+            continue
+        assert torch.equal(out[-1].cpu(), _asc(ref[-1]))
+        order = ref[-1].sort(dim=-1)[1]
+        for got, want in zip(out[:-1], ref[:-1]):
+            want = want.gather(1, order.unsqueeze(-1).expand(-1, -1, 64))
+            assert torch.equal(got.cpu(), want)
+        assert torch.equal(gate.p.cpu(), slot.t)  # I3
+    # forced index on a head-split tensor (B, H, N, dh): the (B, k) index broadcasts over heads
+    g2, s2 = cls(), O.Slot()
+    v0, v1 = torch.randn(2, 3, 20, 16), torch.randn(2, 3, 20, 16)
+    forced = torch.stack([torch.randperm(20)[:5].sort()[0] for _ in range(2)])
+    g2(v0.clone().to(DEV)); ogate(s2, v0.clone(), None)
+    out = g2(v1.clone().to(DEV), forced_index=forced.to(DEV))
+    ref = ogate(s2, v1.clone(), None, forced=forced)
+    for got, want in zip(out[:-1], ref[:-1]):
+        assert torch.equal(got.cpu(), want)
+    assert torch.equal(g2.p.cpu(), s2.t)
+    gate.reset()
+    assert gate.first and gate.p is None
+
+
+def test_col_gate_and_buffers_standalone():
+    from eventful_transformer import modules
+    a0, a1 = torch.rand(2, 3, 10, 10), torch.rand(2, 3, 10, 10)
+    forced = torch.stack([torch.randperm(10)[:4].sort()[0] for _ in range(2)])
+    g, s = modules.TokenDeltaGate(structure="col"), O.Slot()
+    g(a0.clone().to(DEV)); O.token_delta_gate(s, a0.clone(), None, structure="col")
+    out = g(a1.clone().to(DEV), forced_index=forced.to(DEV))
+    ref = O.token_delta_gate(s, a1.clone(), None, forced=forced, structure="col")
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1]) and torch.equal(g.p.cpu(), s.t)
+    # TokenBuffer rows / cols
+    for structure, shape_x in (("row", (2, 4, 32)), ("col", (2, 3, 10, 4))):
+        buf, sb = modules.TokenBuffer(structure=structure), O.Slot()
+        first = torch.randn(2, 10, 32) if structure == "row" else torch.randn(2, 3, 10, 10)
+        x = torch.randn(*shape_x)
+        b0 = buf(first.clone().to(DEV), None)
+        O.token_buffer(sb, first.clone(), None, structure=structure)
+        assert b0 is buf.b
+        out = buf(x.to(DEV), forced.to(DEV))
+        ref = O.token_buffer(sb, x, forced, structure=structure)
+        assert out is buf.b and torch.equal(out.cpu(), ref)
+    # SimpleSTGTGate: reference replaced wholesale each frame
+    from eventful_transformer import policies
+    st, ss = modules.SimpleSTGTGate(), O.Slot()
+    st.policy = policies.TokenNormTopK(k=3)
+    xs = O.make_token_stream(1, 12, 32, 3, 3, seed=2, small=0.05)
+    for t in range(3):
+        out = st(xs[t].clone().to(DEV))
+        ref = O.stgt_gate(ss, xs[t].clone(), O.TopK(3))
+        if t:
+            assert torch.equal(out[1].cpu(), _asc(ref[1]))
+            assert torch.equal(st.p.cpu(), xs[t])
+
+
+def test_matmul_buffer_and_accumulator_standalone():
+    from eventful_transformer import modules
+    B, Hh, N, dh, k = 2, 3, 21, 16, 6
+    mb, sm = modules.MatmulBuffer(), O.Slot()
+    acc, sa = modules.MatmulDeltaAccumulator(), O.Slot()
+    g = torch.Generator().manual_seed(0)
+    for t in range(3):
+        q, kT = torch.randn(B, Hh, N, dh, generator=g), torch.randn(B, Hh, dh, N, generator=g)
+        iq = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        ik = torch.stack([torch.randperm(N, generator=g)[:k + 1].sort()[0] for _ in range(B)])
+        out = mb(q.to(DEV), kT.to(DEV), iq.to(DEV) if t else None, ik.to(DEV) if t else None)
+        ref = O.qk_buffer(sm, q, kT, iq, ik)
+        assert out is mb.product and torch.allclose(out.cpu(), ref, atol=1e-5)
+        a_n, a_d = torch.rand(B, Hh, N, k if t else N, generator=g), torch.randn(B, Hh, N, k if t else N, generator=g) * 0.1
+        v_n, v_d = torch.randn(B, Hh, k if t else N, dh, generator=g), torch.randn(B, Hh, k if t else N, dh, generator=g) * 0.1
+        out = acc(a_n.to(DEV), v_n.to(DEV), a_d.to(DEV) if t else None, v_d.to(DEV) if t else None)
+        ref = O.av_accumulator(sa, a_n, v_n, a_d, v_d)
+        assert out.shape == ref.shape and torch.allclose(out.cpu(), ref, atol=2e-5)
+    mb.reset(); acc.reset()
+    assert mb.first and mb.product is None and acc.product is None
+
+
+def test_counted_linear_and_position_encoding():
+    from eventful_transformer.counting import CountedLinear
+    from eventful_transformer.utils import PositionEncoding
+    lin = CountedLinear(64, 96)
+    w, b = torch.randn(96, 64) * 0.1, torch.randn(96)
+    lin.load_state_dict({"weight": w, "bias": b})
+    lin = lin.to(DEV)
+    x = torch.randn(3, 5, 64)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double()).float()
+    assert torch.allclose(lin(x.to(DEV)).cpu(), ref, atol=1e-4)
+    assert torch.allclose(lin.forward_linear(x.to(DEV)).cpu(), ref - b, atol=1e-4)
+    assert torch.equal(lin.forward_bias(x.new_zeros(1, 96).to(DEV)).cpu(), b.unsqueeze(0))
+    pe = PositionEncoding(64, (3, 3), (6, 6), True).eval()
+    enc = torch.randn(1, 10, 64) * 0.1
+    pe.load_state_dict({"encoding": enc})
+    pe = pe.to(DEV)
+    xx = torch.randn(2, 37, 64)
+    want = xx + O.sized_position_encoding(enc, (3, 3), (6, 6), True)
+    assert torch.allclose(pe(xx.to(DEV)).cpu(), want, atol=2e-6)
+
+
+def test_mac_counters_match_reference(golden_dir):
+    """I5: MAC counters of the fused HIP path == the REFERENCE's counters (golden) on a 3-block backbone
+    with a windowed rel-pos block and two global EventfulBlocks, first frame and two gated frames."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+    g = H.load_npz(os.path.join(golden_dir, "counts.npz"))
+    cfg = dict(dim=64, heads=4, mlp_ratio=4, relative_embedding_size=(8, 8), window_size=(3, 3))
+    bb = ViTBackbone(block_config=cfg, depth=3, position_encoding_size=(3, 3), input_size=(6, 6),
+                     block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock", window_indices=(0,)).eval().to(DEV)
+    H.set_policies(bb, policies.TokenNormTopK, k=12)
+    xs = O.make_token_stream(2, 36, 64, 3, 12, seed=11, small=0.02)
+    bb.counting()
+    keys = ("add_flops", "bias_flops", "linear_flops", "einsum_flops", "matmul_flops", "gate_flops", "accumulator_flops")
+    with torch.inference_mode():
+        for t in range(3):
+            bb.clear_counts()
+            bb(xs[t].to(DEV))
+            c = bb.total_counts()
+            for key in keys:
+                want = int(g[f"t{t}__{key}"]) if f"t{t}__{key}" in g.files else 0
+                assert int(c[key]) == want, (t, key, int(c[key]), want)
