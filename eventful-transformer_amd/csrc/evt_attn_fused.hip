@@ -28,7 +28,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int FR = 32;    // rows per workgroup
-constexpr int FKC = 128;  // selected columns per chunk
+constexpr int FKC = 64;   // selected columns per chunk
 
 template <typename T> struct Tile;  // LDS row pitch (elements) and the MFMA sweep over one chunk
 template <> struct Tile<bf16_t> {
@@ -243,9 +243,10 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
 
   for (int k0 = 0; k0 < cnt; k0 += FKC) {
     // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
-    int jc[2];
+    constexpr int NU = FKC / 64;
+    int jc[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int kk = k0 + lane + 64 * u;
       jc[u] = (kk < cnt) ? ix[kk] : -1;
     }
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       const float* prow = prod + (int64_t)i * a.N;
       const float* rv = relv + r * nrel;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int jj = lane + 64 * u, j = jc[u];
         float an = 0.f, ad = 0.f;
         if (live && j >= 0) {
