@@ -97,11 +97,17 @@ __global__ __launch_bounds__(256) void k(const float* A, const uint16_t* W, floa
       }
 #endif
 #if !(ABL & 8)
+#ifdef REORDER
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#else
       for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
+#endif
 #else
       for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)ah[i][0] + (float)bl[j][1] + (float)al[i][2] + (float)bh[j][3];
 #endif
