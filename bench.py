@@ -242,7 +242,7 @@ def main():
     # read in-process); profiles/*/pmc_traffic_*.json holds the per-launch figure for the workload it names.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_B64.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_B{args.clips}.json")))
         wl = pmc["workload"]
         if (wl["clips"], wl["frames"], wl["k"], wl["cast"], wl["gemm"]) == (args.clips, args.frames, args.k, cast, _native.GEMM_MODE):
             traffic = pmc["gated_linear_hbm_bytes_per_launch"]
@@ -264,7 +264,7 @@ def main():
                               " (evt_gated_linear / evt_gated_mlp)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01/pmc_traffic_B64.json",
+                    "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01/pmc_traffic_B<clips>.json",
                     "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
                     "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
                     "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
