@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=64, help="clips resident per GPU (B)")
+    ap.add_argument("--clips", type=int, default=256, help="clips resident per GPU (B); 256 clips = ~32 GB of per-clip state")
     ap.add_argument("--frames", type=int, default=16, help="backbone frames per clip (T)")
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--cast", default="bfloat16")
