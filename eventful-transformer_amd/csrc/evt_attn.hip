@@ -185,7 +185,7 @@ struct SmArgs {
   const int32_t* tok_map; const float* pad_row; int groups_per_clip, clip_rows;
   void* a_state; void* a_new; void* a_delta;
   const int32_t* idx; const int32_t* count;
-  int G, H, N, Nk, D, dh, kcap, gh, gw, gated;
+  int G, H, N, Nk, D, dh, kcap, gh, gw, qw, gated;   // gh x gw: KEY grid; qw: query grid width
 };
 
 template <typename T>
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void softmax_gate_kernel(const SmArgs a) {
     // same-wave LDS visibility: wave-synchronous, but make the compiler keep the order
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-    const int yi = i / a.gw, xi = i - yi * a.gw;
+    const int yi = i / a.qw, xi = i - yi * a.qw;
     for (int e = lane; e < a.gh + a.gw; e += 64) {
       const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * a.dh
                                     : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * a.dh;
@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void softmax_gate_kernel(const SmArgs a) {
 // K6a: value delta gate, one thread per 4 channels of one (clip, token).
 // =============================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ vsrc, int64_t v_rs,
+                                                     const int32_t* __restrict__ idx,
                                                      const int32_t* __restrict__ count, int G, int N, int D, int kcap,
                                                      T* __restrict__ v_state, T* __restrict__ v_delta,
                                                      T* __restrict__ v_old, int gated, int transposed, int H,
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ q
     if (count != nullptr && ii >= count[g]) return;
     tok = idx[(int64_t)g * kcap + ii];
   }
-  const float* row = evt_token_row(qkv, 3 * (int64_t)D, tok_map, groups_per_clip, clip_rows, pad_row, g, tok, N);
-  const float4 v = *reinterpret_cast<const float4*>(row + 2 * D + c4 * 4);
+  const float* row = evt_token_row(vsrc, v_rs, tok_map, groups_per_clip, clip_rows, pad_row, g, tok, N);
+  const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
   const float vv[4] = {v.x, v.y, v.z, v.w};
   T* st = v_state + ((int64_t)g * N + tok) * D + c4 * 4;
 #pragma unroll
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ q
 // v / v_state with whole-row-segment accesses, and writes v_delta^T / v_old^T (B, D, kcap) as 128-byte
 // k-contiguous segments (the operand layout of evt_softmax_av_gated).
 template <typename T>
-__global__ __launch_bounds__(256) void v_gate_t_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void v_gate_t_kernel(const float* __restrict__ vsrc, int64_t v_rs,
+                                                       const int32_t* __restrict__ idx,
                                                        const int32_t* __restrict__ count, int N, int D, int kcap,
                                                        T* __restrict__ v_state, T* __restrict__ v_delta_t,
                                                        T* __restrict__ v_old_t) {
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void v_gate_t_kernel(const float* __restrict__
     float dl[4] = {0.f, 0.f, 0.f, 0.f}, vo[4] = {0.f, 0.f, 0.f, 0.f};
     if (ii < cnt) {
       const int tok = idx[(int64_t)b * kcap + ii];
-      const float4 v = *reinterpret_cast<const float4*>(qkv + ((int64_t)b * N + tok) * 3 * D + 2 * D + c0 + c4);
+      const float4 v = *reinterpret_cast<const float4*>(vsrc + ((int64_t)b * N + tok) * v_rs + c0 + c4);
       const float vv[4] = {v.x, v.y, v.z, v.w};
       T* st = v_state + ((int64_t)b * N + tok) * D + c0 + c4;
 #pragma unroll
@@ -487,6 +489,65 @@ int launch_av(const AvArgs& a, void* stream) {
   return evt_check_launch("evt_av");
 }
 
+
+// =============================================================================================
+// K/V token pooling (Block._pool_tokens, blocks.py:303-326): average the k and v slices of the packed
+// (B, qh*qw, 3D) token buffer over p0 x p1 cells of the token grid -> (B, kh*kw, 2D) = [k | v].
+// One thread per 4 channels of one pooled token; window order (dy, dx) as ATen's avg_pool2d, then / area.
+// =============================================================================================
+__global__ __launch_bounds__(256) void pool_kv_kernel(const float* __restrict__ qkv, int B, int qw, int kh, int kw, int D,
+                                                      int p0, int p1, float* __restrict__ kv) {
+  const int v4 = (2 * D) >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * kh * kw * v4) return;
+  const int c4 = (int)(e % v4);
+  const int64_t cell = e / v4;
+  const int kx = (int)(cell % kw), ky = (int)((cell / kw) % kh), b = (int)(cell / ((int64_t)kw * kh));
+  const int N = kh * p0 * qw;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dy = 0; dy < p0; ++dy)
+    for (int dx = 0; dx < p1; ++dx) {
+      const int tok = (ky * p0 + dy) * qw + kx * p1 + dx;
+      const float4 t = *reinterpret_cast<const float4*>(qkv + ((int64_t)b * N + tok) * 3 * D + D + c4 * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+  const float area = (float)(p0 * p1);
+  *reinterpret_cast<float4*>(kv + cell * 2 * D + c4 * 4) = make_float4(s.x / area, s.y / area, s.z / area, s.w / area);
+}
+
+// Block._pool_index (blocks.py:525-540): map selected tokens to pooled cells, de-duplicate, ascending.
+// One workgroup per clip: flags in LDS, then the same wavefront-ballot compaction as K1.
+__global__ __launch_bounds__(256) void pool_index_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                                                         int kcap, int qw, int p0, int p1, int kw, int Nk, int kcap_k,
+                                                         int32_t* __restrict__ idx_k, int32_t* __restrict__ count_k) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t pflag[];  // Nk flags + 4 wave sums
+  uint32_t* wsum = pflag + Nk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int cnt = count ? count[b] : kcap;
+  for (int j = tid; j < Nk; j += 256) pflag[j] = 0;
+  __syncthreads();
+  for (int i = tid; i < cnt; i += 256) {
+    const int t = idx[(int64_t)b * kcap + i];
+    const int y = t / qw, x = t - y * qw;
+    pflag[(y / p0) * kw + x / p1] = 1;
+  }
+  __syncthreads();
+  uint32_t run = 0;
+  for (int base = 0; base < Nk; base += 256) {
+    const int j = base + tid;
+    const bool sel = j < Nk && pflag[j] != 0;
+    const unsigned long long bal = __ballot(sel);
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t pos = run + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += wsum[w];
+    if (sel && pos < (uint32_t)kcap_k) idx_k[(int64_t)b * kcap_k + pos] = j;
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) count_k[b] = (int32_t)run;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -528,8 +589,8 @@ extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
   int dh = 0;
   if (d->rel_y) {
     EVT_REQUIRE(d->qkv != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_gate: rel-pos needs qkv");
-    EVT_REQUIRE(d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N && d->Nk == d->N, EVT_ERR_BAD_SHAPE,
-                "evt_softmax_gate: rel-pos grid %dx%d does not match N=%d/Nk=%d", d->gh, d->gw, d->N, d->Nk);
+    EVT_REQUIRE(d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->Nk && d->qw > 0 && d->N % d->qw == 0, EVT_ERR_BAD_SHAPE,
+                "evt_softmax_gate: rel-pos key grid %dx%d / query width %d do not match N=%d/Nk=%d", d->gh, d->gw, d->qw, d->N, d->Nk);
     int rc = check_heads("evt_softmax_gate", d->D, d->H, &dh);
     if (rc) return rc;
   }
@@ -541,7 +602,7 @@ extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
   SmArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row,
            d->tok_map ? d->groups_per_clip : 1, d->clip_rows,
            d->a_state, d->a_new, d->a_delta, d->idx, d->count,
-           d->B, d->H, d->N, d->Nk, d->D, dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->gated};
+           d->B, d->H, d->N, d->Nk, d->D, dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->gated};
   const int64_t rows = (int64_t)d->B * d->H * d->N;
   if (rows == 0) return EVT_OK;
   const size_t lds = (size_t)4 * (a.Nk + a.dh + a.gh + a.gw) * sizeof(float);
@@ -556,12 +617,13 @@ extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
   return evt_check_launch("evt_softmax_gate");
 }
 
-extern "C" int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D, int kcap,
+extern "C" int evt_v_gate(const float* v, int64_t v_rs, const int32_t* idx, const int32_t* count, int B, int N, int D, int kcap,
                           void* v_state, void* v_delta, void* v_old, int store, int gated, int transposed,
                           const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
                           void* stream) {
-  EVT_REQUIRE(qkv && v_state, EVT_ERR_BAD_ARG, "evt_v_gate: null pointer");
-  EVT_REQUIRE(B >= 0 && N > 0 && D > 0 && (D & 3) == 0, EVT_ERR_BAD_ARG, "evt_v_gate: bad sizes");
+  EVT_REQUIRE(v && v_state, EVT_ERR_BAD_ARG, "evt_v_gate: null pointer");
+  EVT_REQUIRE(B >= 0 && N > 0 && D > 0 && (D & 3) == 0 && v_rs >= D && (v_rs & 3) == 0, EVT_ERR_BAD_ARG, "evt_v_gate: bad sizes");
+  const float* qkv = v;
   if (gated) EVT_REQUIRE(idx && v_delta && v_old && kcap >= 0 && tok_map == nullptr, EVT_ERR_BAD_ARG, "evt_v_gate: gated mode needs idx/v_delta/v_old and no tok_map");
   EVT_REQUIRE(tok_map == nullptr || (groups_per_clip > 0 && clip_rows > 0 && pad_row), EVT_ERR_BAD_ARG,
               "evt_v_gate: tok_map needs groups_per_clip, clip_rows and pad_row");
@@ -572,13 +634,13 @@ extern "C" int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* c
   if (gated && transposed && (D % 64) == 0 && (kcap % 8) == 0 && kcap > 0) {
     const dim3 tgrid((kcap + 63) / 64, D / 64, B);
     EVT_DISPATCH_STORE(store, T, {
-      hipLaunchKernelGGL(v_gate_t_kernel<T>, tgrid, block, 0, s, qkv, idx, count, N, D, kcap, (T*)v_state,
+      hipLaunchKernelGGL(v_gate_t_kernel<T>, tgrid, block, 0, s, qkv, v_rs, idx, count, N, D, kcap, (T*)v_state,
                          (T*)v_delta, (T*)v_old);
     });
     return evt_check_launch("evt_v_gate");
   }
   EVT_DISPATCH_STORE(store, T, {
-    hipLaunchKernelGGL(v_gate_kernel<T>, grid, block, 0, s, qkv, idx, count, B, N, D, kcap, (T*)v_state, (T*)v_delta,
+    hipLaunchKernelGGL(v_gate_kernel<T>, grid, block, 0, s, qkv, v_rs, idx, count, B, N, D, kcap, (T*)v_state, (T*)v_delta,
                        (T*)v_old, gated, transposed, 0, tok_map, tok_map ? groups_per_clip : 1, clip_rows, pad_row);
   });
   return evt_check_launch("evt_v_gate");
@@ -600,4 +662,29 @@ extern "C" int evt_av(const evt_av_desc* d, void* stream) {
            d->out_map ? d->groups_per_clip : 1, d->clip_rows, d->B, d->H, d->N, d->K, d->D, dh, d->gated};
   EVT_DISPATCH_STORE(d->store, T, { return launch_av<T>(a, stream); });
   return EVT_OK;
+}
+
+extern "C" int evt_pool_kv(const float* qkv, int B, int qh, int qw, int D, int p0, int p1, float* kv, void* stream) {
+  EVT_REQUIRE(qkv && kv, EVT_ERR_BAD_ARG, "evt_pool_kv: null pointer");
+  EVT_REQUIRE(B >= 0 && qh > 0 && qw > 0 && D > 0 && p0 > 0 && p1 > 0, EVT_ERR_BAD_ARG, "evt_pool_kv: bad sizes");
+  EVT_REQUIRE(qh % p0 == 0 && qw % p1 == 0 && (D & 3) == 0, EVT_ERR_BAD_SHAPE,
+              "evt_pool_kv: grid %dx%d must be divisible by the pool %dx%d (blocks.py:480-482) and D %% 4 == 0", qh, qw, p0, p1);
+  const int kh = qh / p0, kw = qw / p1;
+  const int64_t n = (int64_t)B * kh * kw * (2 * D / 4);
+  if (n == 0) return EVT_OK;
+  hipLaunchKernelGGL(pool_kv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, evt_stream(stream), qkv, B, qw, kh, kw,
+                     D, p0, p1, kv);
+  return evt_check_launch("evt_pool_kv");
+}
+
+extern "C" int evt_pool_index(const int32_t* idx, const int32_t* count, int B, int kcap, int qw, int p0, int p1, int kw,
+                              int Nk, int kcap_k, int32_t* idx_k, int32_t* count_k, void* stream) {
+  EVT_REQUIRE(idx && idx_k && count_k, EVT_ERR_BAD_ARG, "evt_pool_index: null pointer");
+  EVT_REQUIRE(B >= 0 && kcap >= 0 && qw > 0 && p0 > 0 && p1 > 0 && kw > 0 && Nk > 0 && kcap_k > 0, EVT_ERR_BAD_ARG,
+              "evt_pool_index: bad sizes");
+  EVT_REQUIRE(Nk <= 32768, EVT_ERR_BAD_SHAPE, "evt_pool_index: Nk=%d exceeds 32768", Nk);
+  if (B == 0) return EVT_OK;
+  hipLaunchKernelGGL(pool_index_kernel, dim3(B), dim3(256), (size_t)(Nk + 4) * sizeof(uint32_t), evt_stream(stream), idx,
+                     count, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k);
+  return evt_check_launch("evt_pool_index");
 }

@@ -80,7 +80,7 @@ struct FusedArgs {
   const float* product; const float* qkv; const float* rel_y; const float* rel_x;
   void* a_state; const int32_t* idx; const int32_t* count;
   const void* v_delta_t; const void* v_old_t; void* pv; float* out_f32;
-  int B, H, N, D, dh, kcap, gh, gw;
+  int B, H, N, Nk, D, dh, kcap, gh, gw, qw;   // N rows x Nk columns; gh x gw: KEY grid; qw: query grid width
 };
 
 // TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   float* et = qs + (rel_lds ? FR : 0) * a.dh;                           // [FR][EP] exp(x - max) (NREG > 0), later the
   float* red1 = et;                                    // [FR][dh] round(a~ . dv~)   (aliases et)
   float* red2 = et + FR * a.dh;                        // [FR][dh] round(da~ . v_old)
-  const int EP = a.N | 1;                              // odd pitch: row-strided LDS access conflict-free
+  const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;
   const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
-  const float* prod = a.product + (int64_t)bh * a.N * a.N;
-  T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.N;
+  const float* prod = a.product + (int64_t)bh * a.N * a.Nk;
+  T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.Nk;
   const int32_t* ix = a.idx + (int64_t)b * a.kcap;
 
   // ---- phase 1: per-row softmax statistics; wave w owns rows w*8 .. w*8+7 -----------------------
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     {
       const int r = tid >> 3, sub = tid & 7, i = i0 + r;
       if (i < a.N) {
-        const int yi = fast_div(i, inv_gw), xi = i - yi * a.gw;
+        const int yi = i / a.qw, xi = i - yi * a.qw;
         const float* q = qs + r * DH;
         for (int e = sub; e < nrel; e += 8) {
           const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * DH
@@ -154,13 +154,13 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
-      const float* prow = prod + (int64_t)(i < a.N ? i : 0) * a.N;
+      const float* prow = prod + (int64_t)(i < a.N ? i : 0) * a.Nk;
       const float* rv = relv + r * nrel;
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
         const int j = lane + 64 * u;
         float x = -INFINITY;
-        if (j < a.N) {
+        if (j < a.Nk) {
           x = prow[j];
           if (rel) { const int ky = fast_div(j, inv_gw); x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
         }
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
         const float e = fast_exp(xv[rr][u] - rmax[rr]);  // exp(-inf) == 0 past N
-        if (lane + 64 * u < a.N) et[(wave * 8 + rr) * EP + lane + 64 * u] = e;
+        if (lane + 64 * u < a.Nk) et[(wave * 8 + rr) * EP + lane + 64 * u] = e;
         sum += e;
       }
       rsum[rr] = wave_sum(sum);
@@ -196,20 +196,20 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       rmax[rr] = 0.f; rsum[rr] = 1.f;
       if (i >= a.N) continue;  // wave-uniform
       const float* rv = relv + r * nrel;
-      const float* prow = prod + (int64_t)i * a.N;
+      const float* prow = prod + (int64_t)i * a.Nk;
       float mx = -INFINITY, sum = 0.f;
-      for (int j0 = 0; j0 < a.N; j0 += 512) {
+      for (int j0 = 0; j0 < a.Nk; j0 += 512) {
         float x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = j0 + lane + 64 * u;
-          x[u] = (j < a.N) ? prow[j] : -INFINITY;
+          x[u] = (j < a.Nk) ? prow[j] : -INFINITY;
         }
         if (rel) {
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const int j = j0 + lane + 64 * u;
-            if (j < a.N) { const int ky = fast_div(j, inv_gw); x[u] = (x[u] + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+            if (j < a.Nk) { const int ky = fast_div(j, inv_gw); x[u] = (x[u] + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
           }
         }
         float cm = x[0];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
       const bool live = i < a.N;
-      const float* prow = prod + (int64_t)i * a.N;
+      const float* prow = prod + (int64_t)i * a.Nk;
       const float* rv = relv + r * nrel;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
             e = fast_exp(x - rmax[rr]);
           }
           an = Store<T>::round(e / rsum[rr]);
-          const float old = Store<T>::load(st + (int64_t)i * a.N + j);
+          const float old = Store<T>::load(st + (int64_t)i * a.Nk + j);
           ad = Store<T>::round(an - old);
-          Store<T>::store(st + (int64_t)i * a.N + j, an);
+          Store<T>::store(st + (int64_t)i * a.Nk + j, an);
         }
         Store<T>::store(An + r * P + jj, an);
         Store<T>::store(Ad + r * P + jj, ad);
@@ -368,8 +368,8 @@ void launch_fused_inst(const FusedArgs& a, dim3 grid, size_t lds, hipStream_t s)
 template <typename T>
 int launch_fused(const FusedArgs& a, void* stream) {
   constexpr int P = Tile<T>::PITCH;
-  const int nreg = (a.N + 63) / 64;
-  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.N | 1) : 0;        // exp tile (aliases the two
+  const int nreg = (a.Nk + 63) / 64;
+  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.Nk | 1) : 0;        // exp tile (aliases the two
   const size_t tile_r = (size_t)2 * FR * a.dh;                          // rounded-product tiles)
   const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) +
                      ((tile_e > tile_r ? tile_e : tile_r) + FR * (a.gh + a.gw) + (a.rel_y ? FR * a.dh : 0)) * sizeof(float);
@@ -398,12 +398,15 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
               "evt_softmax_av_gated: head dim %d not supported by the fused kernel (64 or 128); use evt_softmax_gate + evt_av",
               d->dh);
   EVT_REQUIRE((d->rel_y == nullptr) == (d->rel_x == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_av_gated: rel_y/rel_x");
+  EVT_REQUIRE(d->Nk > 0, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: Nk=%d", d->Nk);
   if (d->rel_y) {
-    EVT_REQUIRE(d->qkv != nullptr && d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N, EVT_ERR_BAD_SHAPE,
-                "evt_softmax_av_gated: rel-pos grid %dx%d does not match N=%d", d->gh, d->gw, d->N);
+    EVT_REQUIRE(d->qkv != nullptr && d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->Nk && d->qw > 0 && d->N % d->qw == 0,
+                EVT_ERR_BAD_SHAPE, "evt_softmax_av_gated: rel-pos key grid %dx%d / query width %d do not match N=%d Nk=%d",
+                d->gh, d->gw, d->qw, d->N, d->Nk);
   }
   FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
-              d->pv, d->out_f32, d->B, d->H, d->N, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0};
+              d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
+              d->rel_y ? d->qw : 1};
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }

@@ -23,7 +23,7 @@ _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EV
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated",
+    "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
 )
 
 
@@ -67,7 +67,7 @@ class SoftmaxDesc(Structure):
         ("clip_rows", c_int32), ("pad_row", c_void_p), ("a_state", c_void_p), ("a_new", c_void_p),
         ("a_delta", c_void_p), ("idx", c_void_p), ("count", c_void_p),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("Nk", c_int32), ("D", c_int32),
-        ("kcap", c_int32), ("store", c_int32), ("gated", c_int32),
+        ("kcap", c_int32), ("store", c_int32), ("gated", c_int32), ("qw", c_int32),
     ]
 
 
@@ -87,7 +87,7 @@ class SoftmaxAvDesc(Structure):
         ("gh", c_int32), ("gw", c_int32), ("a_state", c_void_p), ("idx", c_void_p), ("count", c_void_p),
         ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
         ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
-        ("store", c_int32),
+        ("store", c_int32), ("Nk", c_int32), ("qw", c_int32),
     ]
 
 
@@ -110,7 +110,9 @@ def _bind(lib):
         "evt_split_weights": [P, P, c_int64, P],
         "evt_qk": [POINTER(QkDesc), P],
         "evt_softmax_gate": [POINTER(SoftmaxDesc), P],
-        "evt_v_gate": [P, P, P, I, I, I, I, P, P, P, I, I, I, P, I, I, P, P],
+        "evt_v_gate": [P, c_int64, P, P, I, I, I, I, P, P, P, I, I, I, P, I, I, P, P],
+        "evt_pool_kv": [P, I, I, I, I, I, I, P, P],
+        "evt_pool_index": [P, P, I, I, I, I, I, I, I, I, P, P, P],
         "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
@@ -271,14 +273,19 @@ def _ptr_off(t, elems):
 
 
 def qk_packed(qkv, B, N, D, H, scale, product, idx=None, count=None, kcap=0, tok_map=None, groups_per_clip=1,
-              clip_rows=0, pad_row=None):
-    """K4 on the packed (B, rows, 3D) token buffer; idx given -> delta update of rows+columns idx."""
+              clip_rows=0, pad_row=None, kv=None, Nk=None, idx_k=None, count_k=None, kcap_k=0):
+    """K4 on the packed (B, rows, 3D) token buffer; idx given -> delta update of rows idx / columns idx_k.
+    kv: pooled (B, Nk, 2D) key/value buffer (evt_pool_kv) -- keys then come from it, with their own index list."""
     dh = D // H
     rows = clip_rows if tok_map is not None else N
-    G = B
-    d = QkDesc(_p(qkv), rows * 3 * D, dh, 3 * D, _ptr_off(qkv, D), rows * 3 * D, dh, 3 * D, _p(product),
-               _p(idx), _p(count), kcap, _p(idx), _p(count), kcap, _p(tok_map), groups_per_clip,
-               _p(pad_row), None if pad_row is None else _ptr_off(pad_row, D), G, H, N, N, dh, float(scale),
+    if kv is None:
+        kptr, k_bs, k_rs, Nk_ = _ptr_off(qkv, D), rows * 3 * D, 3 * D, N
+        idx_k, count_k, kcap_k = idx, count, kcap
+    else:
+        kptr, k_bs, k_rs, Nk_ = _p(kv), Nk * 2 * D, 2 * D, Nk
+    d = QkDesc(_p(qkv), rows * 3 * D, dh, 3 * D, kptr, k_bs, dh, k_rs, _p(product),
+               _p(idx), _p(count), kcap, _p(idx_k), _p(count_k), kcap_k, _p(tok_map), groups_per_clip,
+               _p(pad_row), None if pad_row is None else _ptr_off(pad_row, D), B, H, N, Nk_, dh, float(scale),
                int(idx is not None))
     _check(load().evt_qk(ctypes.byref(d), _stream()))
 
@@ -295,24 +302,39 @@ def qk_strided(q, k, product, scale, idx_q=None, count_q=None, kcap_q=0, idx_k=N
 
 def softmax_gate(product, a_state, B, H, N, Nk, D, store, qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, tok_map=None,
                  groups_per_clip=1, clip_rows=0, pad_row=None, a_new=None, a_delta=None, idx=None, count=None, kcap=0,
-                 gated=False):
+                 gated=False, qw=None):
     d = SoftmaxDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(tok_map), groups_per_clip, clip_rows,
                     _p(pad_row), _p(a_state), _p(a_new), _p(a_delta), _p(idx), _p(count), B, H, N, Nk, D, kcap, store,
-                    int(gated))
+                    int(gated), gw if qw is None else qw)
     _check(load().evt_softmax_gate(ctypes.byref(d), _stream()))
 
 
 def v_gate(qkv, idx, count, B, N, D, kcap, v_state, v_delta, v_old, store, gated, tok_map=None, groups_per_clip=1,
-           clip_rows=0, pad_row=None, transposed=False):
-    _check(load().evt_v_gate(_p(qkv), _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta), _p(v_old), store,
-                             int(gated), int(transposed), _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
-                             _stream()))
+           clip_rows=0, pad_row=None, transposed=False, v_offset=None, v_rs=None):
+    """K6a.  Default source: the value slice of the packed (B,N,3D) buffer `qkv`; with v_offset / v_rs the value
+    slice of any row-major buffer (e.g. the pooled (B,Nk,2D) buffer: v_offset=D, v_rs=2D)."""
+    off = 2 * D if v_offset is None else v_offset
+    rs = 3 * D if v_rs is None else v_rs
+    pad = None if pad_row is None else _ptr_off(pad_row, off)
+    _check(load().evt_v_gate(_ptr_off(qkv, off), rs, _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta),
+                             _p(v_old), store, int(gated), int(transposed), _p(tok_map), groups_per_clip, clip_rows,
+                             pad, _stream()))
+
+
+def pool_kv(qkv, B, qh, qw, D, p0, p1, kv):
+    _check(load().evt_pool_kv(_p(qkv), B, qh, qw, D, p0, p1, _p(kv), _stream()))
+
+
+def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
+    _check(load().evt_pool_index(_p(idx), _p(count), B, kcap, qw, p0, p1, kw, Nk, kcap_k, _p(idx_k), _p(count_k),
+                                 _stream()))
 
 
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
-                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0):
+                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None):
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
-                      _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store)
+                      _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
+                      N if Nk is None else Nk, gw if qw is None else qw)
     _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream()))
 
 

@@ -23,8 +23,10 @@ shape-dependent allocation after the first frame of a clip except the returned t
 
 Per-clip state lives on the gate / buffer sub-modules under the reference's attribute names
 (`qkv_gate.p`, `qkv_accumulator.b`, `matmul_accumulator_1.product`, ...), so `reset()` and state
-inspection work as in the reference.  Not implemented yet (SURVEY.md §8f "next"): `ats_fraction`
-(adaptive token sampling) and `pool_size` (K/V pooling); both raise at construction.
+inspection work as in the reference.  `pool_size` (K/V token pooling, blocks.py:303-326,525-540) is
+supported on global blocks: keys/values are pooled by `evt_pool_kv`, the gate's index list is mapped to
+pooled cells by `evt_pool_index`, and K4/K5/K6 run with Nq != Nk.  Not implemented:
+`ats_fraction` (adaptive token sampling) and pooling inside windowed blocks; both raise at construction.
 """
 from math import prod, sqrt
 
@@ -71,8 +73,9 @@ class Block(ExtendedModule):
         super().__init__()
         if ats_fraction is not None:
             raise NotImplementedError("ats_fraction (adaptive token sampling) is not built yet in the MI355X path")
-        if pool_size is not None:
-            raise NotImplementedError("pool_size (K/V token pooling) is not built yet in the MI355X path")
+        if pool_size is not None and window_size is not None:
+            raise NotImplementedError("pool_size together with window_size is not built in the MI355X path "
+                                      "(the reference's configs pool only the global blocks)")
         assert not (drop_path_rate < 0.0 or drop_path_rate > 1.0)
         assert matmul_2_cast in [None, "float16", "bfloat16"]
         self.dim = dim
@@ -81,7 +84,7 @@ class Block(ExtendedModule):
         self.ats_fraction = None
         self.last_ats_indices = None
         self.matmul_2_cast = matmul_2_cast
-        self.pool_size = None
+        self.pool_size = None if pool_size is None else numeric_tuple(pool_size, length=2)
         if window_size is None:
             self.window_size = None
             attention_size = self.input_size
@@ -97,7 +100,7 @@ class Block(ExtendedModule):
         self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
         if relative_embedding_size is not None:
             self.relative_position = RelativePositionEmbedding(attention_size, relative_embedding_size, dim // heads,
-                                                               pool_size=None)
+                                                               pool_size=self.pool_size)
         else:
             self.relative_position = None
         self.matmul = CountedMatmul()
@@ -137,10 +140,31 @@ class Block(ExtendedModule):
         return self._wmap
 
     def _rel_tables(self):
+        """(rel_y, rel_x, key-grid height, key-grid width, query-grid width) for K5; tables are (q, k, dh)."""
         if self.relative_position is None:
-            return None, None, 0, 0
+            return None, None, 0, 0, 0
         ry, rx = self.relative_position.tables()
-        return ry, rx, ry.shape[0], rx.shape[0]
+        return ry, rx, ry.shape[1], rx.shape[1], rx.shape[0]
+
+    def _pool_kv(self, qkv, B, N):
+        """K/V token pooling (blocks.py:303-326).  Returns (kv (B,Nk,2D) or None, Nk)."""
+        if self.pool_size is None:
+            return None, N
+        qh, qw = self.input_size
+        p0, p1 = self.pool_size
+        assert qh * qw == N, "token pooling needs tokens == prod(input_size) (no class token), as in the reference"
+        Nk = (qh // p0) * (qw // p1)
+        kv = self._ws("pooled_kv", (B, Nk, 2 * self.dim), torch.float32, qkv)
+        _native.pool_kv(qkv, B, qh, qw, self.dim, p0, p1, kv)
+        return kv, Nk
+
+    def _v_full(self, qkv, kv, G, n, Nk, v_s, store, **win):
+        """K6a FULL: value state from the packed buffer, or from the pooled buffer's value half."""
+        D = self.dim
+        if kv is None:
+            _native.v_gate(qkv, None, None, G, n, D, 0, v_s, None, None, store, False, **win)
+        else:
+            _native.v_gate(kv, None, None, G, Nk, D, 0, v_s, None, None, store, False, v_offset=D, v_rs=2 * D)
 
     def _ws(self, name, shape, dtype, x):
         return _native.scratch(name, shape, dtype, x.device)
@@ -160,7 +184,7 @@ class Block(ExtendedModule):
         dh = D // H
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
-        ry, rx, gh, gw = self._rel_tables()
+        ry, rx, gh, gw, qw = self._rel_tables()
         if self.window_size is None:
             G, n, tok_map, gpc, pad = B, N, None, 1, None
         else:
@@ -168,20 +192,19 @@ class Block(ExtendedModule):
             gpc, n = tok_map.shape
             G, pad = B * gpc, self.qkv.bias
             assert prod(self.input_size) == N, "windowed attention needs tokens == prod(input_size)"
-        prod_s = self._ws("attn_scores", (G, H, n, n), torch.float32, qkv)
-        a_s = self._ws("attn_probs", (G, H, n, n), sdt, qkv)
-        v_s = self._ws("attn_values", (G, n, D), sdt, qkv)
-        _native.qk_packed(qkv, G, n, D, H, self.scale, prod_s, tok_map=tok_map, groups_per_clip=gpc, clip_rows=N,
-                          pad_row=pad)
-        self.matmul.count_product(G * H * n * n, dh)
+        kv, nk = self._pool_kv(qkv, B, N) if self.window_size is None else (None, n)
+        win = dict(tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
+        prod_s = self._ws("attn_scores", (G, H, n, nk), torch.float32, qkv)
+        a_s = self._ws("attn_probs", (G, H, n, nk), sdt, qkv)
+        v_s = self._ws("attn_values", (G, nk, D), sdt, qkv)
+        _native.qk_packed(qkv, G, n, D, H, self.scale, prod_s, kv=kv, Nk=nk, **win)
+        self.matmul.count_product(G * H * n * nk, dh)
         if self.relative_position is not None:
             self.relative_position.count_fused(G, H)
-        _native.softmax_gate(prod_s, a_s, G, H, n, n, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
-                             tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
-        _native.v_gate(qkv, None, None, G, n, D, 0, v_s, None, None, store, False, tok_map=tok_map,
-                       groups_per_clip=gpc, clip_rows=N, pad_row=pad)
-        _native.av(a_s, v_s, n, G, H, n, n, D, store, out_f32=out, out_map=tok_map, groups_per_clip=gpc, clip_rows=N)
-        self.matmul.count_product(G * H * n * dh, n)
+        _native.softmax_gate(prod_s, a_s, G, H, n, nk, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw, **win)
+        self._v_full(qkv, kv, G, n, nk, v_s, store, **win)
+        _native.av(a_s, v_s, nk, G, H, n, nk, D, store, out_f32=out, out_map=tok_map, groups_per_clip=gpc, clip_rows=N)
+        self.matmul.count_product(G * H * n * dh, nk)
 
     def _dense_tail(self, attn, skip, B, N):
         """projection + skip + LN2 + MLP + skip over all tokens (Block.forward, blocks.py:127-137)."""
@@ -382,35 +405,49 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         self.matmul_accumulator_1 = MatmulBuffer()
 
     def _scores(self, qkv, idx, count, cap, B, N):
-        """q.k^T state update (K4).  Returns the (B,H,N,N) fp32 product state."""
+        """q.k^T state update (K4), with pooled keys when `pool_size` is set.
+
+        Returns (product (B,H,N,Nk) fp32 state, kv or None, Nk, idx_k, count_k, cap_k): the key-side index list
+        is the gate's own list, or its pooled / de-duplicated image (`_pool_index`, blocks.py:525-540)."""
         D, H = self.dim, self.heads
         acc = self.matmul_accumulator_1
+        kv, Nk = self._pool_kv(qkv, B, N)
+        idx_k, count_k, cap_k = idx, count, cap
+        if kv is not None and idx is not None:
+            cap_k = min(cap, Nk)
+            idx_k = self._ws("idx_k", (B, cap_k), torch.int32, qkv)
+            count_k = self._ws("cnt_k", (B,), torch.int32, qkv)
+            p0, p1 = self.pool_size
+            _native.pool_index(idx, count, B, cap, self.input_size[1], p0, p1, self.input_size[1] // p1, Nk, cap_k,
+                               idx_k, count_k)
         if acc.first:
             acc.first = False
-            acc.product = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
-            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product)
-            acc.matmul.count_product(B * H * N * N, D // H)
+            acc.product = torch.empty((B, H, N, Nk), dtype=torch.float32, device=qkv.device)
+            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, kv=kv, Nk=Nk)
+            acc.matmul.count_product(B * H * N * Nk, D // H)
         else:
-            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, idx=idx, count=count, kcap=cap)
+            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, idx=idx, count=count, kcap=cap, kv=kv, Nk=Nk,
+                              idx_k=idx_k, count_k=count_k, kcap_k=cap_k)
             if acc.matmul.count_mode:
-                acc.matmul.count_product(2 * H * N * self._n_rows(B, cap, count), D // H)
+                acc.matmul.count_product(H * Nk * self._n_rows(B, cap, count), D // H)
+                acc.matmul.count_product(H * N * self._n_rows(B, cap_k, count_k), D // H)
         if self.relative_position is not None:
             self.relative_position.count_fused(B, H)
-        return acc.product
+        return acc.product, kv, Nk, idx_k, count_k, cap_k
 
     def _forward_attention(self, qkv, idx, count, cap, B, N):
         D, H = self.dim, self.heads
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
-        product = self._scores(qkv, idx, count, cap, B, N)
-        ry, rx, gh, gw = self._rel_tables()
-        a_s = self._ws("attn_probs", (B, H, N, N), sdt, qkv)
-        v_s = self._ws("attn_values", (B, N, D), sdt, qkv)
-        _native.softmax_gate(product, a_s, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
-        _native.v_gate(qkv, None, None, B, N, D, 0, v_s, None, None, store, False)
+        product, kv, Nk, _, _, _ = self._scores(qkv, idx, count, cap, B, N)
+        ry, rx, gh, gw, qw = self._rel_tables()
+        a_s = self._ws("attn_probs", (B, H, N, Nk), sdt, qkv)
+        v_s = self._ws("attn_values", (B, Nk, D), sdt, qkv)
+        _native.softmax_gate(product, a_s, B, H, N, Nk, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
+        self._v_full(qkv, kv, B, N, Nk, v_s, store)
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
-        _native.av(a_s, v_s, N, B, H, N, N, D, store, out_f32=attn)
-        self.matmul.count_product(B * H * N * (D // H), N)
+        _native.av(a_s, v_s, Nk, B, H, N, Nk, D, store, out_f32=attn)
+        self.matmul.count_product(B * H * N * (D // H), Nk)
         return attn
 
 
@@ -428,44 +465,48 @@ class EventfulBlock(EventfulMatmul1Block):
         dh = D // H
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
-        product = self._scores(qkv, idx, count, cap, B, N)
-        ry, rx, gh, gw = self._rel_tables()
+        product, kv, Nk, idx_k, count_k, cap_k = self._scores(qkv, idx, count, cap, B, N)
+        ry, rx, gh, gw, qw = self._rel_tables()
+        rel = dict(qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
         vg, ag, acc = self.v_gate, self.matmul_gate, self.matmul_accumulator_2
+        # value source for K6a: packed buffer, or the value half of the pooled buffer
+        vsrc, vkw = (qkv, {}) if kv is None else (kv, dict(v_offset=D, v_rs=2 * D))
         if acc.first:
             vg.first = ag.first = acc.first = False
-            ag.p = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
-            vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            ag.p = torch.empty((B, H, N, Nk), dtype=sdt, device=qkv.device)
+            vg._state = torch.empty((B, Nk, D), dtype=sdt, device=qkv.device)
             acc._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
-            # head-split views with the reference's logical shapes (B,H,N,dh)
-            vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            # head-split views with the reference's logical shapes (B,H,tokens,dh)
+            vg.p = vg._state.view(B, Nk, H, dh).permute(0, 2, 1, 3)
             acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
-            _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
-            _native.v_gate(qkv, None, None, B, N, D, 0, vg._state, None, None, store, False)
-            _native.av(ag.p, vg._state, N, B, H, N, N, D, store, pv=acc._state, out_f32=attn)
-            acc.matmul.count_product(B * H * N * dh, N)
+            _native.softmax_gate(product, ag.p, B, H, N, Nk, D, store, **rel)
+            self._v_full(qkv, kv, B, N, Nk, vg._state, store)
+            _native.av(ag.p, vg._state, Nk, B, H, N, Nk, D, store, pv=acc._state, out_f32=attn)
+            acc.matmul.count_product(B * H * N * dh, Nk)
             return attn
         if dh in (64, 128):
             # K6a with k-contiguous outputs + fused K5/K6: a~ / da~ stay in LDS
-            v_delta = self._ws("v_delta_t", (B, D, cap), sdt, qkv)
-            v_old = self._ws("v_old_t", (B, D, cap), sdt, qkv)
-            _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
-            _native.softmax_av_gated(product, ag.p, idx, count, cap, v_delta, v_old, acc._state, attn, B, H, N, D,
-                                     store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw)
+            v_delta = self._ws("v_delta_t", (B, D, cap_k), sdt, qkv)
+            v_old = self._ws("v_old_t", (B, D, cap_k), sdt, qkv)
+            _native.v_gate(vsrc, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True,
+                           transposed=True, **vkw)
+            _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state, attn, B, H, N, D,
+                                     store, Nk=Nk, **rel)
         else:
-            a_new = self._ws("a_new", (B, H, N, cap), sdt, qkv)
-            a_delta = self._ws("a_delta", (B, H, N, cap), sdt, qkv)
-            v_delta = self._ws("v_delta", (B, cap, D), sdt, qkv)
-            v_old = self._ws("v_old", (B, cap, D), sdt, qkv)
-            _native.softmax_gate(product, ag.p, B, H, N, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
-                                 a_new=a_new, a_delta=a_delta, idx=idx, count=count, kcap=cap, gated=True)
-            _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True)
-            _native.av(a_new, v_delta, cap, B, H, N, cap, D, store, pv=acc._state, out_f32=attn, a2=a_delta, v2=v_old,
-                       count=count, gated=True)
+            a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)
+            a_delta = self._ws("a_delta", (B, H, N, cap_k), sdt, qkv)
+            v_delta = self._ws("v_delta", (B, cap_k, D), sdt, qkv)
+            v_old = self._ws("v_old", (B, cap_k, D), sdt, qkv)
+            _native.softmax_gate(product, ag.p, B, H, N, Nk, D, store, a_new=a_new, a_delta=a_delta, idx=idx_k,
+                                 count=count_k, kcap=cap_k, gated=True, **rel)
+            _native.v_gate(vsrc, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True, **vkw)
+            _native.av(a_new, v_delta, cap_k, B, H, N, cap_k, D, store, pv=acc._state, out_f32=attn, a2=a_delta,
+                       v2=v_old, count=count_k, gated=True)
         if self.count_mode or acc.count_mode or vg.count_mode:
-            n = self._n_rows(B, cap, count)
-            self._count_gate(vg, B * N * D)
-            self._count_gate(ag, B * H * N * N)
+            n = self._n_rows(B, cap_k, count_k)
+            self._count_gate(vg, B * Nk * D)
+            self._count_gate(ag, B * H * N * Nk)
             if acc.count_mode:
                 acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
             acc.matmul.count_product(2 * B * N * D, n // B if B else 0)

@@ -202,12 +202,13 @@ EVT_API int evt_qk(const evt_qk_desc* d, void* stream);
  *                 a_new[b,h,i,jj]   = a[j]
  *                 a_delta[b,h,i,jj] = round(a[j] - a_state[b,h,i,j])
  *                 a_state[b,h,i,j]  = a[j]                  (modules.py:187-201, structure="col")
- *   rel_y/rel_x: (gh, gh, dh) / (gw, gw, dh) tables (utils.py:151-156) or NULL; gh*gw == N.
+ *   rel_y/rel_x: (qh, gh, dh) / (qw, gw, dh) tables (utils.py:151-156) or NULL.  gh x gw is the KEY grid
+ *   (gh*gw == Nk), qw the query grid width; they differ only with K/V pooling (utils.py:143-146,185-188).
  * ------------------------------------------------------------------------------------------ */
 typedef struct evt_softmax_desc {
   const float* product;                   /* (B,H,N,Nk)                                          */
   const float* qkv;                       /* (B,N,3D) for the rel-pos terms; nullable if no rel  */
-  const float* rel_y; const float* rel_x; int32_t gh, gw;
+  const float* rel_y; const float* rel_x; int32_t gh, gw;   /* KEY grid (gh*gw == Nk)                */
   const int32_t* tok_map; int32_t groups_per_clip, clip_rows; const float* pad_row;
   void* a_state;                          /* (B,H,N,Nk) in `store` type                          */
   void* a_new; void* a_delta;             /* (B,H,N,kcap) in `store` type (GATED only)           */
@@ -215,6 +216,7 @@ typedef struct evt_softmax_desc {
   int32_t B, H, N, Nk, D, kcap;
   int32_t store;                          /* evt_dtype                                           */
   int32_t gated;                          /* 0 = FULL, 1 = GATED                                 */
+  int32_t qw;                             /* query grid width (== gw unless K/V are pooled)      */
 } evt_softmax_desc;
 
 EVT_API int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
@@ -225,14 +227,15 @@ EVT_API int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
  *   GATED: v_new = round(v[idx]); v_delta = round(v_new - v_state[idx]);
  *          v_old = round(v_new - v_delta)   (the `v_n_tilde - v_delta_tilde` of modules.py:294)
  *          v_state[idx] = v_new
- *   v is the third D-slice of the qkv buffer.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D) with heads
+ *   v points at the value slice of token 0 (qkv + 2D of the packed buffer, or kv + D of the pooled
+ *   buffer of evt_pool_kv), rows v_rs elements apart; pad_row likewise points at its value slice.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D) with heads
  *   side by side (h*dh + d), or, with `transposed`, (B,H,dh,kcap) = (B,D,kcap) with k contiguous
  *   (the operand layout of evt_softmax_av_gated); all in `store` type.
  * ------------------------------------------------------------------------------------------ */
-EVT_API int evt_v_gate(const float* qkv, const int32_t* idx, const int32_t* count, int B, int N, int D,
-               int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated, int transposed,
-               const int32_t* tok_map, int groups_per_clip, int clip_rows, const float* pad_row,
-               void* stream);
+EVT_API int evt_v_gate(const float* v, int64_t v_rs, const int32_t* idx, const int32_t* count, int B, int N,
+               int D, int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated,
+               int transposed, const int32_t* tok_map, int groups_per_clip, int clip_rows,
+               const float* pad_row, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K6  Attention-value product state, heads merged on write (blocks.py:328-344 fused):
@@ -270,19 +273,32 @@ EVT_API int evt_av(const evt_av_desc* d, void* stream);
  * fp32 on v_mfma_f32_32x32x2_f32.
  * ------------------------------------------------------------------------------------------ */
 typedef struct evt_softmax_av_desc {
-  const float* product;                   /* (B,H,N,N)                                           */
+  const float* product;                   /* (B,H,N,Nk)                                          */
   const float* qkv;                       /* (B,N,3D); only read for rel-pos                     */
   const float* rel_y; const float* rel_x; int32_t gh, gw;
-  void* a_state;                          /* (B,H,N,N) store type: matmul_gate.p                 */
+  void* a_state;                          /* (B,H,N,Nk) store type: matmul_gate.p                */
   const int32_t* idx; const int32_t* count; int32_t kcap;
   const void* v_delta_t; const void* v_old_t;
   void* pv;                               /* (B,N,D) store type: matmul_accumulator_2.product    */
   float* out_f32;                         /* (B,N,D)                                             */
   int32_t B, H, N, D, dh;
   int32_t store;
+  int32_t Nk, qw;                         /* key count (== N unless pooled), query grid width    */
 } evt_softmax_av_desc;
 
 EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K/V token pooling (`pool_size`, blocks.py:303-326, 525-540).
+ * evt_pool_kv   : kv[b, (ky,kx), :] = mean over the p0 x p1 cell of [k | v] of the packed (B, qh*qw, 3D)
+ *                 token buffer -> (B, (qh/p0)*(qw/p1), 2D).  Replaces the avg_pool2d of `_pool_tokens`.
+ * evt_pool_index: selected tokens -> pooled cells, de-duplicated, ascending, per clip, with the count on
+ *                 the device (`_pool_index`; the reference's `.unique(dim=-1)` equals this for batch 1,
+ *                 the only batch size its pooled configs use).  idx_k: (B, kcap_k), count_k: (B,).
+ * ------------------------------------------------------------------------------------------ */
+EVT_API int evt_pool_kv(const float* qkv, int B, int qh, int qw, int D, int p0, int p1, float* kv, void* stream);
+EVT_API int evt_pool_index(const int32_t* idx, const int32_t* count, int B, int kcap, int qw, int p0, int p1,
+                           int kw, int Nk, int kcap_k, int32_t* idx_k, int32_t* count_k, void* stream);
 
 #ifdef __cplusplus
 }

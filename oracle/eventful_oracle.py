@@ -181,8 +181,8 @@ def av_accumulator(slot, a_new, v_new, a_delta, v_delta):
 # --------------------------------------------------------------------------------------------
 # relative position embedding (utils.py:108-195)
 # --------------------------------------------------------------------------------------------
-def relative_table(embedding, emb_size, attn_size, axis):
-    """RelativePositionEmbedding._get_relative (utils.py:175-189), no pooling."""
+def relative_table(embedding, emb_size, attn_size, axis, pool=None):
+    """RelativePositionEmbedding._get_relative (utils.py:175-189); `pool` = pool_size or None."""
     n = emb_size[axis]
     offs = torch.arange(n).unsqueeze(1) - torch.arange(n).unsqueeze(0) + n - 1
     rel = embedding[offs]
@@ -190,13 +190,16 @@ def relative_table(embedding, emb_size, attn_size, axis):
         rel = rel.transpose(0, 2).unsqueeze(0)
         rel = F.interpolate(rel, tuple(attn_size), mode="bicubic", align_corners=False)
         rel = rel.squeeze(0).transpose(0, 2)
+    if pool is not None:  # utils.py:185-188: average the KEY axis
+        rel = F.avg_pool1d(rel.transpose(1, 2), pool[axis]).transpose(1, 2)
     return rel
 
 
-def add_relative(x, q, rel_y, rel_x, attn_size, inplace):
-    """RelativePositionEmbedding.forward (utils.py:139-173), no pooling.  q is UNSCALED."""
+def add_relative(x, q, rel_y, rel_x, attn_size, inplace, pool=None):
+    """RelativePositionEmbedding.forward (utils.py:139-173).  q is UNSCALED; keys live on the pooled grid."""
     a = tuple(attn_size)
-    x = x.view(x.shape[:2] + a + a)
+    kgrid = a if pool is None else (a[0] // pool[0], a[1] // pool[1])
+    x = x.view(x.shape[:2] + a + kgrid)
     q = q.view(q.shape[:2] + a + q.shape[-1:])
     ty = torch.einsum("abhwc,hkc->abhwk", q, rel_y).unsqueeze(-1)
     tx = torch.einsum("abhwc,wkc->abhwk", q, rel_x).unsqueeze(-2)
@@ -205,7 +208,7 @@ def add_relative(x, q, rel_y, rel_x, attn_size, inplace):
     else:
         x = x + ty
     x += tx
-    return x.view(x.shape[:2] + (prod(a), prod(a)))
+    return x.view(x.shape[:2] + (prod(a), prod(kgrid)))
 
 
 # --------------------------------------------------------------------------------------------
@@ -227,7 +230,7 @@ class BlockOracle:
     """
 
     def __init__(self, kind, params, dim, heads, input_size, window_size=None,
-                 relative_embedding_size=None, matmul_2_cast=None, gate_before_ln=False, stgt=False):
+                 relative_embedding_size=None, matmul_2_cast=None, gate_before_ln=False, stgt=False, pool_size=None):
         self.kind = kind
         self.p = params
         self.dim, self.heads = dim, heads
@@ -236,6 +239,7 @@ class BlockOracle:
         self.cast = None if matmul_2_cast is None else getattr(torch, matmul_2_cast)
         self.gate_before_ln = gate_before_ln
         self.stgt = stgt
+        self.pool = None if pool_size is None else ((pool_size,) * 2 if isinstance(pool_size, int) else tuple(pool_size))
         self.scale = sqrt(dim // heads)  # blocks.py:92
         if self.window_size is not None:
             attn = self.window_size
@@ -333,9 +337,28 @@ class BlockOracle:
         if self.rel_size is None:
             return x
         if self.rel_y is None:
-            self.rel_y = relative_table(self.p["relative_position.y_embedding"], self.rel_size, self.attn_size, 0)
-            self.rel_x = relative_table(self.p["relative_position.x_embedding"], self.rel_size, self.attn_size, 1)
-        return add_relative(x, q, self.rel_y, self.rel_x, self.attn_size, inplace)
+            self.rel_y = relative_table(self.p["relative_position.y_embedding"], self.rel_size, self.attn_size, 0, self.pool)
+            self.rel_x = relative_table(self.p["relative_position.x_embedding"], self.rel_size, self.attn_size, 1, self.pool)
+        return add_relative(x, q, self.rel_y, self.rel_x, self.attn_size, inplace, self.pool)
+
+    def _pool_tokens(self, x):
+        # blocks.py:303-326: average pooling of keys / values over the token grid
+        if self.pool is None:
+            return x
+        w = self.input_size if self.window_size is None else self.window_size
+        s = x.shape
+        x = x.reshape((-1,) + w + x.shape[-1:]).permute(0, 3, 1, 2)
+        x = F.avg_pool2d(x, self.pool).permute(0, 2, 3, 1)
+        return x.view(s[:-2] + (-1,) + s[-1:])
+
+    def _pool_index(self, index):
+        # blocks.py:525-540
+        if self.pool is None or index is None:
+            return index
+        width = self.input_size[1]
+        iy = index.div(width, rounding_mode="floor").div(self.pool[0], rounding_mode="floor")
+        ix = index.remainder(width).div(self.pool[1], rounding_mode="floor")
+        return (iy * (width // self.pool[1]) + ix).unique(dim=-1)
 
     def _cast2(self, a, v):
         # blocks.py:183-189
@@ -347,6 +370,7 @@ class BlockOracle:
     def _attention_dense(self, qkv):
         # Block._forward_attention (blocks.py:205-240)
         q, k, v = self._heads(self._to_windows(qkv))
+        k, v = self._pool_tokens(k), self._pool_tokens(v)
         x = (q / self.scale) @ k.transpose(-2, -1)
         x = self._rel(x, q, inplace=True)
         x = x.softmax(dim=-1)
@@ -357,24 +381,27 @@ class BlockOracle:
     def _scores_gated(self, qkv, index):
         # EventfulMatmul1Block._forward_matmul_1 (blocks.py:506-523)
         q, k, v = self._heads(qkv)
-        x = qk_buffer(self.s["matmul_accumulator_1"], q / self.scale, k.transpose(-2, -1), index, index)
+        k, v = self._pool_tokens(k), self._pool_tokens(v)
+        index_k = self._pool_index(index)
+        self.trace["index_k"] = index_k
+        x = qk_buffer(self.s["matmul_accumulator_1"], q / self.scale, k.transpose(-2, -1), index, index_k)
         x = self._rel(x, q, inplace=False)
-        return x.softmax(dim=-1), v
+        return x.softmax(dim=-1), v, index_k
 
     def _attention_matmul1(self, qkv, index):
         # EventfulMatmul1Block._forward_attention (blocks.py:497-504)
-        a, v = self._scores_gated(qkv, index)
+        a, v, _ = self._scores_gated(qkv, index)
         a, v, old = self._cast2(a, v)
         x = self._merge(a @ v)
         return x.to(old) if self.cast is not None else x
 
     def _attention_eventful(self, qkv, index):
         # EventfulBlock._forward_attention (blocks.py:558-575)
-        a, v = self._scores_gated(qkv, index)
+        a, v, index_k = self._scores_gated(qkv, index)
         a, v, old = self._cast2(a, v)
         if self.cast is None:
             v = v.clone()
-        v_new, v_delta, index_v = token_delta_gate(self.s["v_gate"], v, None, forced=index)
+        v_new, v_delta, index_v = token_delta_gate(self.s["v_gate"], v, None, forced=index_k)
         a_new, a_delta, _ = token_delta_gate(self.s["matmul_gate"], a, None, forced=index_v, structure="col")
         x = av_accumulator(self.s["matmul_accumulator_2"], a_new, v_new, a_delta, v_delta)
         self.trace["attn_state"] = x

@@ -144,6 +144,12 @@ def small_cases():
                                            dict(window_size=(3, 3), relative_embedding_size=(8, 8)), ("topk", 12))
     cs["EventfulTokenwiseBlock_stgt"] = ("EventfulTokenwiseBlock", (6, 6), True, dict(stgt=True), ("topk", 12))
     cs["EventfulBlock_gate_before_ln"] = ("EventfulBlock", (6, 6), True, dict(gate_before_ln=True), ("topk", 12))
+    cs["EventfulBlock_pool"] = ("EventfulBlock", (6, 6), False, dict(pool_size=2), ("topk", 12))
+    cs["EventfulBlock_pool_rel_bf16"] = ("EventfulBlock", (6, 6), False,
+                                         dict(pool_size=2, relative_embedding_size=(8, 8), matmul_2_cast="bfloat16"), ("topk", 12))
+    cs["EventfulMatmul1Block_pool"] = ("EventfulMatmul1Block", (6, 6), False, dict(pool_size=(2, 3)), ("topk", 12))
+    cs["EventfulBlock_pool_thr"] = ("EventfulBlock", (6, 6), False, dict(pool_size=2), ("thr", 0.6))
+    cs["Block_pool_rel"] = ("Block", (6, 6), False, dict(pool_size=2, relative_embedding_size=(6, 6)), None)
     cs["Block_dense"] = ("Block", (6, 6), True, {}, None)
     cs["Block_win_rel"] = ("Block", (7, 5), False, dict(window_size=(3, 3), relative_embedding_size=(8, 8)), None)
     return cs
@@ -163,7 +169,10 @@ def gen_blocks():
     steps, batch = 4, 2
     for ci, (name, (kind, isz, has_cls, kw, pol)) in enumerate(small_cases().items()):
         tokens = isz[0] * isz[1] + int(has_cls)
-        b = 1 if (pol is not None and pol[0] == "thr") else batch
+        # batch 1 for the threshold policy (policies.py:25) and for pooled blocks: `_pool_index` de-duplicates with
+        # `.unique(dim=-1)` (blocks.py:539), which for batch > 1 compares whole COLUMNS across clips and leaves
+        # per-clip duplicates that double-count A.v delta terms; every pooled config of the reference is batch 1.
+        b = 1 if ((pol is not None and pol[0] == "thr") or kw.get("pool_size")) else batch
         rel = kw.get("relative_embedding_size")
         if rel is not None and kw.get("window_size"):
             rel = kw["window_size"]  # blocks.py:90-91: windowed blocks size the table by the window

@@ -72,6 +72,12 @@ def small_cases():
                                            dict(window_size=(3, 3), relative_embedding_size=(8, 8)), ("topk", 12))
     cs["EventfulTokenwiseBlock_stgt"] = ("EventfulTokenwiseBlock", (6, 6), True, dict(stgt=True), ("topk", 12))
     cs["EventfulBlock_gate_before_ln"] = ("EventfulBlock", (6, 6), True, dict(gate_before_ln=True), ("topk", 12))
+    cs["EventfulBlock_pool"] = ("EventfulBlock", (6, 6), False, dict(pool_size=2), ("topk", 12))
+    cs["EventfulBlock_pool_rel_bf16"] = ("EventfulBlock", (6, 6), False,
+                                         dict(pool_size=2, relative_embedding_size=(8, 8), matmul_2_cast="bfloat16"), ("topk", 12))
+    cs["EventfulMatmul1Block_pool"] = ("EventfulMatmul1Block", (6, 6), False, dict(pool_size=(2, 3)), ("topk", 12))
+    cs["EventfulBlock_pool_thr"] = ("EventfulBlock", (6, 6), False, dict(pool_size=2), ("thr", 0.6))
+    cs["Block_pool_rel"] = ("Block", (6, 6), False, dict(pool_size=2, relative_embedding_size=(6, 6)), None)
     cs["Block_dense"] = ("Block", (6, 6), True, {}, None)
     cs["Block_win_rel"] = ("Block", (7, 5), False, dict(window_size=(3, 3), relative_embedding_size=(8, 8)), None)
     return cs

@@ -258,3 +258,50 @@ def test_vitdet_1024_threshold(golden_dir):
     assert got == want.tolist(), (got, want)
     idx = _native.scratch("idx_mlp", (1, 4096), torch.int32, dev0).cpu()[0, : got[2]].numpy()
     assert np.array_equal(idx.astype(np.int64), g[f"idx_1_11_mlp_index"].reshape(-1).astype(np.int64))
+
+
+def test_pooled_block_batch_is_per_clip():
+    """K/V pooling with batch > 1: the HIP path de-duplicates pooled indices PER CLIP, so a batch equals the
+    clips run one by one (the reference's `.unique(dim=-1)` couples clips for batch > 1 -- blocks.py:535-539 --
+    and is only exact at batch 1, the regime its pooled configs use).  Checked against batch-1 oracle runs."""
+    from eventful_transformer import policies
+    params = O.make_block_params(64, 4, seed=21, std=0.08, rel_sizes=(6, 6), head_dim=16)
+    kw = dict(pool_size=2, relative_embedding_size=(6, 6))
+    blk = H.product_block("EventfulBlock", params, 64, 4, (6, 6), **kw)
+    H.set_policies(blk, policies.TokenNormTopK, k=10)
+    xs = O.make_token_stream(3, 36, 64, 4, 10, seed=22, small=0.02)
+    oracles = []
+    for b in range(3):
+        o = O.BlockOracle("EventfulBlock", params, 64, 4, (6, 6), **kw)
+        o.set_policy(lambda: O.TopK(10))
+        oracles.append(o)
+    with torch.inference_mode():
+        for t in range(4):
+            y = blk(xs[t].to(DEV)).cpu()
+            ref = torch.cat([oracles[b].forward(xs[t, b:b + 1].clone()) for b in range(3)])
+            assert float((y - ref).abs().max()) <= 2e-4, t
+
+
+@pytest.mark.parametrize("cast,policy", [(None, ("topk", 20)), ("bfloat16", ("topk", 20)), (None, ("thr", 0.8))])
+def test_pooled_eventful_block_head_dim_64(cast, policy):
+    """Pooled K/V through the FUSED K5+K6 kernel (head dim 64, N = 64 queries x Nk = 16 pooled keys, rel-pos
+    tables pooled along the key axis), batch 1, 4 frames, against the oracle."""
+    from eventful_transformer import policies
+    dim, heads, grid = 256, 4, (8, 8)
+    kw = dict(pool_size=2, relative_embedding_size=(8, 8))
+    if cast:
+        kw["matmul_2_cast"] = cast
+    params = O.make_block_params(dim, 4, seed=31, std=0.05, rel_sizes=(8, 8), head_dim=64)
+    blk = H.product_block("EventfulBlock", params, dim, heads, grid, **kw)
+    ora = O.BlockOracle("EventfulBlock", params, dim, heads, grid, **kw)
+    H.product_policy(blk, policy)
+    ora.set_policy(H.oracle_policy(policy))
+    xs = O.make_token_stream(1, 64, dim, 4, 20, seed=32, small=0.02)
+    tol = 3e-4 if cast is None else 1e-3
+    with torch.inference_mode():
+        for t in range(4):
+            y = blk(xs[t].to(DEV)).cpu()
+            ref = ora.forward(xs[t].clone())
+            assert float((y - ref).abs().max()) <= tol, (cast, policy, t, float((y - ref).abs().max()))
+            if t:
+                assert blk.matmul_gate.p.shape == (1, 4, 64, 16) and blk.v_gate.p.shape == (1, 4, 16, 64)

@@ -78,7 +78,11 @@ def test_state_dict_keys_and_constructor_contract():
     with pytest.raises(AssertionError):
         blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, window_size=(3, 3))  # blocks.py:485
     with pytest.raises(NotImplementedError):
-        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2)
+        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, window_size=(3, 3))
+    with pytest.raises(NotImplementedError):
+        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5)
+    pooled = blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, relative_embedding_size=(6, 6))
+    assert pooled.pool_size == (2, 2) and pooled.relative_position.pool_size == (2, 2)
     bb = ViTBackbone(block_config=dict(dim=64, heads=4, mlp_ratio=4, relative_embedding_size=(8, 8), window_size=(3, 3)),
                      depth=3, position_encoding_size=(3, 3), input_size=(6, 6), block_class="EventfulBlock",
                      windowed_class="EventfulTokenwiseBlock", window_indices=(0, 2),
