@@ -23,7 +23,7 @@ struct QkArgs {
   const float* q; int64_t q_bs, q_hs, q_rs;
   const float* k; int64_t k_bs, k_hs, k_rs;
   float* product;
-  const int32_t* idx_q; const int32_t* count_q; int kcap_q;
+  const int32_t* idx_q; const int32_t* count_q; int kcap_q; const int32_t* idx_q_rest;
   const int32_t* idx_k; const int32_t* count_k; int kcap_k;
   const int32_t* tok_map; int groups_per_clip; const float* pad_q; const float* pad_k;
   int G, H, Nq, Nk, dh;
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
   int m_lim, n_lim, m0, n0;
   if (part == 2) {
     m0 = blockIdx.x * QT; n0 = blockIdx.y * QT;
-    m_lim = a.Nq; n_lim = a.count_k ? a.count_k[b] : a.kcap_k;
+    // rows already rewritten whole by part 1 are skipped when the complement list is available
+    m_lim = a.idx_q_rest ? a.Nq - (a.count_q ? a.count_q[b] : a.kcap_q) : a.Nq;
+    n_lim = a.count_k ? a.count_k[b] : a.kcap_k;
   } else {
     m0 = blockIdx.y * QT; n0 = blockIdx.x * QT;
     m_lim = (part == 1) ? (a.count_q ? a.count_q[b] : a.kcap_q) : a.Nq; n_lim = a.Nk;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
   for (int j = 0; j < 4; ++j) {
     const int r = r0 + 32 * j;
     const int m = m0 + r, n = n0 + r;
-    const int tm = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m] : m) : -1;
+    const int tm = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m]
+                                              : (part == 2 && a.idx_q_rest) ? a.idx_q_rest[(int64_t)b * a.Nq + m] : m) : -1;
     const int tn = (n < n_lim) ? ((part == 2) ? a.idx_k[(int64_t)b * a.kcap_k + n] : n) : -1;
     if (c4 == 0) { rmap[r] = tm; cmap[r] = tn; }
     qp[j] = (tm >= 0) ? qk_row(a.q, a.q_bs, a.q_rs, a.tok_map, a.groups_per_clip, a.pad_q, g, tm, a.Nq) + h * a.q_hs : nullptr;
@@ -575,7 +578,7 @@ extern "C" int evt_qk(const evt_qk_desc* d, void* stream) {
     if (d->kcap_q == 0 && d->kcap_k == 0) return EVT_OK;
   }
   QkArgs a{d->q, d->q_bs, d->q_hs, d->q_rs, d->k, d->k_bs, d->k_hs, d->k_rs, d->product,
-           d->idx_q, d->count_q, d->kcap_q, d->idx_k, d->count_k, d->kcap_k,
+           d->idx_q, d->count_q, d->kcap_q, d->delta ? d->idx_q_rest : nullptr, d->idx_k, d->count_k, d->kcap_k,
            d->tok_map, d->tok_map ? d->groups_per_clip : 1, d->pad_q, d->pad_k,
            d->G, d->H, d->Nq, d->Nk, d->dh, d->scale, d->delta};
   return launch_qk(a, stream);

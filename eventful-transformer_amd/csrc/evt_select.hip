@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t norm_key(float v) { return __float_as_uint(v
 // mode 0: top-k (k given); mode 1: threshold (norm > thr).
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ norms, int N, int k, float thr,
                                                              int mode, int kcap, int32_t* __restrict__ idx,
-                                                             int32_t* __restrict__ count) {
+                                                             int32_t* __restrict__ count, int32_t* __restrict__ rest) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* keys = smem;               // N
   uint32_t* hist = smem + N;           // 256
@@ -111,6 +111,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
     uint32_t pos = out_run + (uint32_t)__popcll(bsel & lower);
     for (int w = 0; w < wave; ++w) pos += wsum[4 + w];
     if (is_sel && pos < (uint32_t)kcap) out[pos] = i;
+    // complement list, ascending too: #unselected before token i = i - #selected before i
+    if (rest != nullptr && i < N && !is_sel) rest[(int64_t)b * N + (i - (int)pos)] = i;
     out_run += wsum[4] + wsum[5] + wsum[6] + wsum[7];
     __syncthreads();
   }
@@ -118,31 +120,33 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 }
 
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
-                  void* stream) {
+                  int32_t* rest, void* stream) {
   const size_t lds = (size_t)(N + 256 + 8 + 4) * sizeof(uint32_t);
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), lds, evt_stream(stream), norms, N, k, thr, mode, kcap,
-                     idx, count);
+                     idx, count, rest);
   return evt_check_launch("evt_select");
 }
 
 }  // namespace
 
-extern "C" int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, void* stream) {
+extern "C" int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream) {
   EVT_REQUIRE(norms != nullptr && idx != nullptr, EVT_ERR_BAD_ARG, "evt_select_topk: null pointer");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk: B=%d N=%d", B, N);
   EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk: k=%d out of range for N=%d (topk would raise)", k, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk: N=%d exceeds %d", N, SEL_MAX_N);
-  if (B == 0 || k == 0) return EVT_OK;
-  return launch_select(norms, B, N, k, 0.f, 0, k, idx, nullptr, stream);
+  if (B == 0) return EVT_OK;
+  EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk: k == 0 with a complement list");
+  if (k == 0) return EVT_OK;
+  return launch_select(norms, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream);
 }
 
 extern "C" int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap, int32_t* idx,
-                                    int32_t* count, void* stream) {
+                                    int32_t* count, int32_t* rest, void* stream) {
   EVT_REQUIRE(norms != nullptr && idx != nullptr && count != nullptr, EVT_ERR_BAD_ARG, "evt_select_threshold: null pointer");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_threshold: B=%d N=%d", B, N);
   EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold: kcap=%d must be >= N=%d", kcap, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold: N=%d exceeds %d", N, SEL_MAX_N);
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold: NaN threshold");
   if (B == 0) return EVT_OK;
-  return launch_select(norms, B, N, 0, threshold, 1, kcap, idx, count, stream);
+  return launch_select(norms, B, N, 0, threshold, 1, kcap, idx, count, rest, stream);
 }

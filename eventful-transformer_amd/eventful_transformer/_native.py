@@ -52,7 +52,7 @@ class QkDesc(Structure):
         ("q", c_void_p), ("q_bs", c_int64), ("q_hs", c_int64), ("q_rs", c_int64),
         ("k", c_void_p), ("k_bs", c_int64), ("k_hs", c_int64), ("k_rs", c_int64),
         ("product", c_void_p),
-        ("idx_q", c_void_p), ("count_q", c_void_p), ("kcap_q", c_int32),
+        ("idx_q", c_void_p), ("count_q", c_void_p), ("kcap_q", c_int32), ("idx_q_rest", c_void_p),
         ("idx_k", c_void_p), ("count_k", c_void_p), ("kcap_k", c_int32),
         ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("pad_q", c_void_p), ("pad_k", c_void_p),
         ("G", c_int32), ("H", c_int32), ("Nq", c_int32), ("Nk", c_int32), ("dh", c_int32),
@@ -101,8 +101,8 @@ def _bind(lib):
     lib.evt_target_arch.restype = c_char_p
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
-        "evt_select_topk": [P, I, I, I, P, P],
-        "evt_select_threshold": [P, I, I, F, I, P, P, P],
+        "evt_select_topk": [P, I, I, I, P, P, P],
+        "evt_select_threshold": [P, I, I, F, I, P, P, P, P],
         "evt_gate_gather_update": [P, P, P, P, I, I, I, I, P, P, I, P],
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
@@ -204,12 +204,12 @@ def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=Non
                                _p(norms), rows, D, _stream()))
 
 
-def select_topk(norms, B, N, k, idx):
-    _check(load().evt_select_topk(_p(norms), B, N, k, _p(idx), _stream()))
+def select_topk(norms, B, N, k, idx, rest=None):
+    _check(load().evt_select_topk(_p(norms), B, N, k, _p(idx), _p(rest), _stream()))
 
 
-def select_threshold(norms, B, N, threshold, kcap, idx, count):
-    _check(load().evt_select_threshold(_p(norms), B, N, float(threshold), kcap, _p(idx), _p(count), _stream()))
+def select_threshold(norms, B, N, threshold, kcap, idx, count, rest=None):
+    _check(load().evt_select_threshold(_p(norms), B, N, float(threshold), kcap, _p(idx), _p(count), _p(rest), _stream()))
 
 
 def gate_gather_update(c, p, idx, count, B, N, D, kcap, c_tilde=None, e_tilde=None, update_p=True):
@@ -273,7 +273,7 @@ def _ptr_off(t, elems):
 
 
 def qk_packed(qkv, B, N, D, H, scale, product, idx=None, count=None, kcap=0, tok_map=None, groups_per_clip=1,
-              clip_rows=0, pad_row=None, kv=None, Nk=None, idx_k=None, count_k=None, kcap_k=0):
+              clip_rows=0, pad_row=None, kv=None, Nk=None, idx_k=None, count_k=None, kcap_k=0, idx_rest=None):
     """K4 on the packed (B, rows, 3D) token buffer; idx given -> delta update of rows idx / columns idx_k.
     kv: pooled (B, Nk, 2D) key/value buffer (evt_pool_kv) -- keys then come from it, with their own index list."""
     dh = D // H
@@ -284,7 +284,7 @@ def qk_packed(qkv, B, N, D, H, scale, product, idx=None, count=None, kcap=0, tok
     else:
         kptr, k_bs, k_rs, Nk_ = _p(kv), Nk * 2 * D, 2 * D, Nk
     d = QkDesc(_p(qkv), rows * 3 * D, dh, 3 * D, kptr, k_bs, dh, k_rs, _p(product),
-               _p(idx), _p(count), kcap, _p(idx_k), _p(count_k), kcap_k, _p(tok_map), groups_per_clip,
+               _p(idx), _p(count), kcap, _p(idx_rest), _p(idx_k), _p(count_k), kcap_k, _p(tok_map), groups_per_clip,
                _p(pad_row), None if pad_row is None else _ptr_off(pad_row, D), B, H, N, Nk_, dh, float(scale),
                int(idx is not None))
     _check(load().evt_qk(ctypes.byref(d), _stream()))
@@ -295,7 +295,7 @@ def qk_strided(q, k, product, scale, idx_q=None, count_q=None, kcap_q=0, idx_k=N
     B, H, Nq, dh = q.shape
     Nk = k.shape[2]
     d = QkDesc(_p(q), H * Nq * dh, Nq * dh, dh, _p(k), H * Nk * dh, Nk * dh, dh, _p(product),
-               _p(idx_q), _p(count_q), kcap_q, _p(idx_k), _p(count_k), kcap_k, None, 1, None, None,
+               _p(idx_q), _p(count_q), kcap_q, None, _p(idx_k), _p(count_k), kcap_k, None, 1, None, None,
                B, H, Nq, Nk, dh, float(scale), int(idx_q is not None))
     _check(load().evt_qk(ctypes.byref(d), _stream()))
 

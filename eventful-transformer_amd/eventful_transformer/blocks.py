@@ -261,6 +261,8 @@ class EventfulTokenwiseBlock(Block):
         self.projection_accumulator = TokenBuffer()
         self.mlp_gate = token_gate_class()
         self.mlp_accumulator = TokenBuffer()
+        self._wants_rest = False   # set by subclasses that keep a q.k^T product state
+        self._rest = None
 
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
@@ -272,11 +274,16 @@ class EventfulTokenwiseBlock(Block):
             cap = policy.capacity(N)
             idx = self._ws("idx_" + tag, (B, cap), torch.int32, c)
             count = None if policy.fixed_count(N) is not None else self._ws("cnt_" + tag, (B,), torch.int32, c)
-            policy.select_into(norms, B, N, idx, count)
+            # the qkv gate of blocks with a q.k^T state also wants the complement list (K4 skips re-written rows)
+            rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
+            self._rest = rest if tag == "qkv" else self._rest
+            policy.select_into(norms, B, N, idx, count, rest)
             return idx, count, cap
         # Any other callable gets the delta tensor like in the reference (modules.py:149).
         index = policy(c - gate.p, dim=-1)
         idx = index.reshape(B, -1).to(torch.int32).contiguous()
+        if tag == "qkv":
+            self._rest = None
         return idx, None, idx.shape[1]
 
     def _count_gate(self, gate, n):
@@ -403,6 +410,7 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         super().__init__(**super_kwargs)
         assert self.window_size is None  # blocks.py:485
         self.matmul_accumulator_1 = MatmulBuffer()
+        self._wants_rest = True
 
     def _scores(self, qkv, idx, count, cap, B, N):
         """q.k^T state update (K4), with pooled keys when `pool_size` is set.
@@ -427,7 +435,7 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
             acc.matmul.count_product(B * H * N * Nk, D // H)
         else:
             _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, idx=idx, count=count, kcap=cap, kv=kv, Nk=Nk,
-                              idx_k=idx_k, count_k=count_k, kcap_k=cap_k)
+                              idx_k=idx_k, count_k=count_k, kcap_k=cap_k, idx_rest=self._rest)
             if acc.matmul.count_mode:
                 acc.matmul.count_product(H * Nk * self._n_rows(B, cap, count), D // H)
                 acc.matmul.count_product(H * N * self._n_rows(B, cap_k, count_k), D // H)

@@ -83,11 +83,13 @@ EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* 
  * evt_select_threshold: idx[b, 0..count[b]) = tokens with norm > threshold, ascending;
  *   count[b] written on the device (no host sync).  Replaces `.gt(thr).nonzero()`
  *   (policies.py:28-32, a host sync in the reference).  kcap (row stride of idx) must be >= N.
+ *   rest (nullable, (B, N)): the COMPLEMENT list (unselected tokens, ascending, N - count entries per clip),
+ *   a by-product of the same compaction; evt_qk uses it to skip rows it has already rewritten.
  * N <= 16384.
  * ------------------------------------------------------------------------------------------ */
-EVT_API int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, void* stream);
+EVT_API int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream);
 EVT_API int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap,
-                         int32_t* idx, int32_t* count, void* stream);
+                         int32_t* idx, int32_t* count, int32_t* rest, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K2  Gate gather + reference update for the selected tokens (rows):
@@ -182,6 +184,8 @@ typedef struct evt_qk_desc {
   const float* k; int64_t k_bs, k_hs, k_rs;
   float* product;
   const int32_t* idx_q; const int32_t* count_q; int32_t kcap_q;   /* delta only                  */
+  const int32_t* idx_q_rest;  /* nullable (G, Nq): complement of idx_q; the column panel then covers only these rows
+                                 (the rows in idx_q are rewritten whole by the row panel) */
   const int32_t* idx_k; const int32_t* count_k; int32_t kcap_k;
   const int32_t* tok_map; int32_t groups_per_clip; const float* pad_q; const float* pad_k;
   int32_t G, H, Nq, Nk, dh;

@@ -108,10 +108,13 @@ def test_select_tie_policy_and_edges():
     big[:, 100:200] = big[:, 300:400]  # force exact duplicates
     for k in (1, 63, 64, 65, 2500, 4999, 5000):
         idx = torch.empty((3, k), dtype=torch.int32, device=DEV)
-        n.select_topk(big.to(DEV), 3, 5000, k, idx)
+        rest = torch.full((3, 5000), -1, dtype=torch.int32, device=DEV)
+        n.select_topk(big.to(DEV), 3, 5000, k, idx, rest)
         order = np.lexsort((np.arange(5000)[None].repeat(3, 0), -big.numpy()), axis=-1)
         want = np.sort(order[:, :k], axis=-1)
         assert np.array_equal(idx.cpu().numpy(), want), k
+        want_rest = np.sort(order[:, k:], axis=-1)   # complement list: unselected tokens, ascending
+        assert np.array_equal(rest.cpu().numpy()[:, : 5000 - k], want_rest), k
     cnt = torch.empty(3, dtype=torch.int32, device=DEV)
     idx = torch.empty((3, 5000), dtype=torch.int32, device=DEV)
     n.select_threshold(big.to(DEV), 3, 5000, 0.5, 5000, idx, cnt)
