@@ -207,7 +207,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
 template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total) {
+__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map) {
   constexpr int NT = WM * WN * 64;
   constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
   static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
@@ -218,11 +218,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   __bf16* Bhi = lds + 2 * TBM * TSP;
   __bf16* Blo = lds + 2 * TBM * TSP + TBN * TSP;
 
-  // XCD-aware tile order (dispatch puts workgroup w on XCD w % 8): bijective for any tile count.
+  // XCD-aware tile order (dispatch puts workgroup w on XCD w % 8).  map 0: each XCD owns a contiguous run of
+  // row-major tiles (bijective for any tile count).  map 1 (tiles_n even, tiles_m % 4 == 0): each XCD owns a
+  // (tiles_m/4) x (tiles_n/2) rectangle, so its half of W stays resident in its 4 MB L2 and every A panel is
+  // fetched by 2 XCDs instead of being streamed past all of W.
   int tile;
   {
-    const int w = blockIdx.x, q = tiles_total / 8, r = tiles_total % 8, x = w % 8, sidx = w / 8;
-    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sidx;
+    const int w = blockIdx.x, x = w % 8, sidx = w / 8;
+    if (tile_map == 1) {
+      const int mg = tiles_total / tiles_n / 4, ngw = tiles_n / 2;
+      const int m = (x >> 1) * mg + sidx / ngw, n = (x & 1) * ngw + sidx % ngw;
+      tile = m * tiles_n + n;
+    } else {
+      const int q = tiles_total / 8, r = tiles_total % 8;
+      tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sidx;
+    }
   }
   const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,12 +395,14 @@ void launch_split_cfg(const LinArgs& a, hipStream_t s) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
   const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  static const int want_map = getenv("EVT_GEMM_MAP") ? atoi(getenv("EVT_GEMM_MAP")) : 0;
+  const int tile_map = (want_map == 1 && (tiles_n % 2) == 0 && (tiles_m % 4) == 0) ? 1 : 0;
   if (a.act == EVT_ACT_GELU_ERF)
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n);
+                       tiles_n, tiles_m * tiles_n, tile_map);
   else
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n);
+                       tiles_n, tiles_m * tiles_n, tile_map);
 }
 
 void launch_split(const LinArgs& a, hipStream_t s) {
