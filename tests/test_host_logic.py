@@ -31,7 +31,7 @@ def test_abi_argument_errors_without_gpu():
     """Argument validation runs before any HIP call, so it is checkable on a GPU-less box."""
     from eventful_transformer import _native
     lib = _native.load()
-    rc = lib.evt_select_topk(None, 1, 8, 2, None, None)
+    rc = lib.evt_select_topk(None, 1, 8, 2, None, None, None)
     assert rc == -1 and b"null pointer" in lib.evt_last_error_string()
     rc = lib.evt_row_pass(ctypes.c_void_p(16), None, 0, None, None, None, 1e-6, None, None, None, 4, 6, None)
     assert rc == -2 and b"multiple of 4" in lib.evt_last_error_string()
