@@ -21,6 +21,7 @@
 // rows (p_upd) from the A tile it already holds.
 #include "evt_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct LinArgs {
   float* out; int64_t ldo; const int32_t* o_idx; int o_rows;
   const int32_t* count; float* p_upd;
   int B, kcap, K, Nout, act;
+  float* ws; int64_t ws_bytes;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -207,7 +209,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
 template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map) {
+__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit) {
   constexpr int NT = WM * WN * 64;
   constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
   static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   // fetched by 2 XCDs instead of being streamed past all of W.
   int tile;
   {
-    const int w = blockIdx.x, x = w % 8, sidx = w / 8;
+    const int w = blockIdx.x % tiles_total, x = w % 8, sidx = w / 8;
     if (tile_map == 1) {
       const int mg = tiles_total / tiles_n / 4, ngw = tiles_n / 2;
       const int m = (x >> 1) * mg + sidx / ngw, n = (x & 1) * ngw + sidx % ngw;
@@ -325,10 +327,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
 #pragma unroll
     for (int j = 0; j < AJ; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
   }
-  const int nk = (g.K + TBK - 1) / TBK;
+  // split-K: this workgroup contracts k-tiles [t0, nk) of the tile; ksplit == 1 is the whole K.
+  const int split = blockIdx.x / tiles_total;
+  const int nk_all = (g.K + TBK - 1) / TBK, kps = (nk_all + ksplit - 1) / ksplit;
+  const int t0 = split * kps, nk = min(nk_all, t0 + kps);
   const int lr = lane & 31, lh = lane >> 5;
-  fetch(0);
-  for (int t = 0; t < nk; ++t) {
+  fetch(t0 * TBK);
+  for (int t = t0; t < nk; ++t) {
     stage();
     if (do_upd) {
       const int kc = t * TBK + ac4 * 4;
@@ -371,6 +376,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
     ncol[j] = n0 + wn * 64 + j * 32 + lr;
     bv[j] = ncol[j] < g.Nout ? g.bias[ncol[j]] : 0.f;
   }
+  if (ksplit > 1) {
+    // raw partial tile -> workspace plane `split`, compact row m; bias / act / scatter in splitk_finish_kernel
+    float* wsp = g.ws + (int64_t)split * M * g.Nout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (ncol[j] < g.Nout) wsp[(int64_t)m * g.Nout + ncol[j]] = acc[i][j][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -390,24 +410,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   }
 }
 
+// Split-K factor for the default 128x128x32 tiling: only when the tile count leaves most of the 256 CUs idle;
+// every split keeps >= 4 k-tiles.  Depends on the shape alone so that reruns are bit-identical.
+int splitk_factor(int M, int K, int Nout) {
+  const int tiles = ((M + 127) / 128) * ((Nout + 127) / 128), nk = (K + 31) / 32;
+  if (tiles == 0 || tiles >= 128) return 1;
+  int s = std::min(std::min((256 + tiles - 1) / tiles, nk / 4), 16);
+  if (s < 2) return 1;
+  const int kps = (nk + s - 1) / s;
+  return (nk + kps - 1) / kps;  // drop empty trailing splits
+}
+
+// out[orow(m), n] = act(bias[n] + sum_s ws[s][m][n]), s ascending; one thread per 4 columns.
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int ksplit) {
+  const int n4 = g.Nout >> 2;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = g.B * g.kcap;
+  if (t >= (int64_t)M * n4) return;
+  const int m = (int)(t / n4), c = (int)(t - (int64_t)m * n4) * 4;
+  const int b = m / g.kcap, i = m - b * g.kcap;
+  if (g.count != nullptr && i >= g.count[b]) return;
+  const int64_t plane = (int64_t)M * g.Nout;
+  const float* p = g.ws + (int64_t)m * g.Nout + c;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int s = 1; s < ksplit; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(p + s * plane);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  const float4 bv = *reinterpret_cast<const float4*>(g.bias + c);
+  v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+  if (ACT == EVT_ACT_GELU_ERF) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+  const int64_t orow = (int64_t)b * g.o_rows + ((g.o_idx != nullptr) ? g.o_idx[m] : i);
+  *reinterpret_cast<float4*>(g.out + orow * g.ldo + c) = v;
+}
+
 template <int TBM, int TBN, int TBK, int WM, int WN>
-void launch_split_cfg(const LinArgs& a, hipStream_t s) {
+void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
-  const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  const dim3 grid(tiles_m * tiles_n * ksplit), block(WM * WN * 64);
   static const int want_map = getenv("EVT_GEMM_MAP") ? atoi(getenv("EVT_GEMM_MAP")) : 0;
   const int tile_map = (want_map == 1 && (tiles_n % 2) == 0 && (tiles_m % 4) == 0) ? 1 : 0;
   if (a.act == EVT_ACT_GELU_ERF)
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n, tile_map);
+                       tiles_n, tiles_m * tiles_n, tile_map, ksplit);
   else
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n, tile_map);
+                       tiles_n, tiles_m * tiles_n, tile_map, ksplit);
+  if (ksplit > 1) {
+    const int64_t work = (int64_t)M * (a.Nout / 4);
+    const dim3 fg((unsigned)((work + 255) / 256));
+    if (a.act == EVT_ACT_GELU_ERF) hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_GELU_ERF>, fg, dim3(256), 0, s, a, ksplit);
+    else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit);
+  }
 }
 
 void launch_split(const LinArgs& a, hipStream_t s) {
   static const int forced = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : -1;
   const int variant = forced < 0 ? 0 : forced;
+  static const int splitk_on = getenv("EVT_GEMM_SPLITK") ? atoi(getenv("EVT_GEMM_SPLITK")) : 1;
+  if (variant == 0 && splitk_on && a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {
+    const int M = a.B * a.kcap, ks = splitk_factor(M, a.K, a.Nout);
+    if (ks > 1 && (int64_t)ks * M * a.Nout * 4 <= a.ws_bytes) {
+      launch_split_cfg<128, 128, 32, 2, 2>(a, s, ks);
+      return;
+    }
+  }
   switch (variant) {
     case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
     case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
@@ -464,9 +533,18 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
   EVT_REQUIRE(d->p_upd == nullptr || d->a_idx != nullptr, EVT_ERR_BAD_ARG, "evt_gated_linear: p_upd needs a_idx");
   EVT_REQUIRE(d->a_rows > 0 && d->o_rows > 0, EVT_ERR_BAD_ARG, "evt_gated_linear: a_rows/o_rows must be positive");
   EVT_REQUIRE(d->W_split == nullptr || (d->K & 7) == 0, EVT_ERR_BAD_SHAPE, "evt_gated_linear: split weights need K %% 8 == 0 (K=%d)", d->K);
+  EVT_REQUIRE(d->workspace_bytes >= 0, EVT_ERR_BAD_ARG, "evt_gated_linear: negative workspace_bytes");
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
-            d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act};
+            d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
   return launch_linear(a, stream);
+}
+
+extern "C" int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout) {
+  if (B <= 0 || kcap <= 0 || K <= 0 || Nout <= 0) return 0;
+  const int64_t M = (int64_t)B * kcap;
+  if (M > (1 << 20)) return 0;
+  const int ks = splitk_factor((int)M, K, Nout);
+  return ks > 1 ? (int64_t)ks * M * Nout * 4 : 0;
 }
 
 extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
@@ -478,11 +556,11 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
   EVT_REQUIRE((d->W1_split == nullptr) == (d->W2_split == nullptr), EVT_ERR_BAD_ARG, "evt_gated_mlp: W1_split/W2_split must come together");
   EVT_REQUIRE(d->W1_split == nullptr || ((d->D & 7) == 0 && (d->Dh & 7) == 0), EVT_ERR_BAD_SHAPE, "evt_gated_mlp: split weights need D, Dh %% 8 == 0");
   LinArgs fc1{d->A, d->lda, d->idx, d->idx ? d->rows : d->kcap, d->W1, (const uint16_t*)d->W1_split, d->b1, d->hidden, (int64_t)d->Dh, nullptr,
-              d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF};
+              d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF, (float*)d->workspace, d->workspace_bytes};
   int rc = launch_linear(fc1, stream);
   if (rc != EVT_OK) return rc;
   LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, (const uint16_t*)d->W2_split, d->b2, d->out, d->ldo, d->idx,
-              d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE};
+              d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE, (float*)d->workspace, d->workspace_bytes};
   return launch_linear(fc2, stream);
 }
 

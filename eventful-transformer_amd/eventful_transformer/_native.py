@@ -23,7 +23,7 @@ _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EV
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
+    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
 )
 
 
@@ -33,7 +33,7 @@ class LinearDesc(Structure):
         ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
         ("o_idx", c_void_p), ("o_rows", c_int32), ("count", c_void_p), ("p_upd", c_void_p),
         ("B", c_int32), ("kcap", c_int32), ("K", c_int32), ("Nout", c_int32), ("act", c_int32),
-        ("W_split", c_void_p),
+        ("W_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -43,7 +43,7 @@ class MlpDesc(Structure):
         ("W1", c_void_p), ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p),
         ("hidden", c_void_p), ("out", c_void_p), ("ldo", c_int64), ("count", c_void_p),
         ("p_upd", c_void_p), ("B", c_int32), ("kcap", c_int32), ("D", c_int32), ("Dh", c_int32),
-        ("W1_split", c_void_p), ("W2_split", c_void_p),
+        ("W1_split", c_void_p), ("W2_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -99,6 +99,8 @@ def _bind(lib):
     lib.evt_version.restype = c_int
     lib.evt_last_error_string.restype = c_char_p
     lib.evt_target_arch.restype = c_char_p
+    lib.evt_gated_linear_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
+    lib.evt_gated_linear_workspace_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
@@ -251,10 +253,19 @@ def split_weight(W):
     return planes
 
 
+def _splitk_workspace(device, *shapes):
+    """Split-K partial-sum workspace for small launches (evt_gated_linear_workspace_bytes); (None, 0) if unused."""
+    need = max(load().evt_gated_linear_workspace_bytes(*s) for s in shapes)
+    if need == 0:
+        return None, 0
+    return scratch("splitk_ws", (need // 4,), torch.float32, device), need
+
+
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
                  W_split=None):
+    ws, ws_bytes = _splitk_workspace(out.device, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
-                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split))
+                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes)
     _timed(2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
@@ -263,8 +274,9 @@ def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd,
     s1, s2 = W1_split, W2_split
     if s1 is None or s2 is None:
         s1 = s2 = None
+    ws, ws_bytes = _splitk_workspace(out.device, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
-                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2))
+                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes)
     _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
 
 

@@ -133,9 +133,18 @@ typedef struct evt_linear_desc {
   int32_t act;                             /* evt_act                                           */
   const void* W_split;                     /* nullable: evt_split_weights(W) -> split-precision  */
                                            /* MFMA path (3 bf16 MFMAs per fp32 product)          */
+  void* workspace;       int64_t workspace_bytes;  /* nullable: split-K partial sums (see below) */
 } evt_linear_desc;
 
 EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
+
+/* Split-K for launches with few output tiles (one stream, small r: ViTDet, batch 1).  When the
+ * 128x128 tiling yields fewer workgroups than the chip has CUs, the split-precision kernel divides K
+ * among S workgroups per tile; each writes its fp32 partial tile to `workspace` and a second kernel
+ * sums the S partials IN FIXED ORDER (bit-reproducible), adds bias, applies act and scatters through
+ * o_idx.  S depends only on (B*kcap, K, Nout).  This returns the bytes K3 wants for a given shape
+ * (0 = split-K not used); a smaller or null workspace silently selects the single-pass kernel. */
+EVT_API int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout);
 
 /* Split an fp32 weight matrix (n elements, n % 4 == 0) into two bf16 planes written back to back to
  * `out` (2*n bf16): hi = rne_bf16(w), lo = rne_bf16(w - hi).  With W_split set, K3/K7 compute
@@ -158,6 +167,8 @@ typedef struct evt_mlp_desc {
   float* p_upd;
   int32_t B, kcap, D, Dh;
   const void* W1_split; const void* W2_split;   /* nullable pair: split-precision MFMA path      */
+  void* workspace;       int64_t workspace_bytes; /* nullable: split-K partials, max over both   */
+                                                  /* linears of evt_gated_linear_workspace_bytes  */
 } evt_mlp_desc;
 
 EVT_API int evt_gated_mlp(const evt_mlp_desc* d, void* stream);

@@ -222,6 +222,45 @@ def test_gated_linear(B, N, K, Nout, k, act, gemm_mode):
     assert torch.allclose(out.cpu(), yd.float(), atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,K,Nout,act", [(256, 3072, 768, 0), (256, 768, 3072, 1), (196, 768, 2304, 0), (50, 1024, 1024, 0)])
+def test_splitk_small_launch(M, K, Nout, act):
+    """Few-tile launches take the split-K path (fixed-order partial sums): same accuracy, bit-reproducible,
+    scatter / count / fused p refresh unchanged."""
+    n = native()
+    if n.GEMM_MODE != "split":
+        pytest.skip("split-K belongs to the split-precision kernel")
+    assert n.load().evt_gated_linear_workspace_bytes(1, M, K, Nout) > 0
+    g = torch.Generator().manual_seed(M + K + Nout)
+    N = M + 60
+    A = torch.randn(1, N, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) * 0.03
+    bias = torch.randn(Nout, generator=g)
+    idx = torch.randperm(N, generator=g)[:M].sort()[0].int().unsqueeze(0)
+    count = torch.tensor([M - 7], dtype=torch.int32)
+    buf0 = torch.randn(1, N, Nout, generator=g)
+    p0 = torch.randn(1, N, K, generator=g)
+    sel = idx[0, : M - 7].long()
+    y = torch.nn.functional.linear(A[0, sel].double(), W.double(), bias.double())
+    if act:
+        y = torch.nn.functional.gelu(y)
+    ref = buf0.clone()
+    ref[0, sel] = y.float()
+    p_ref = p0.clone()
+    p_ref[0, sel] = A[0, sel]
+    Ad, Wd, bd, idxd, cd = (t.to(DEV) for t in (A, W, bias, idx, count))
+    Ws = n.split_weight(Wd)
+    outs = []
+    for _ in range(2):
+        buf, pd = buf0.to(DEV), p0.to(DEV)
+        n.gated_linear(Ad, K, idxd, N, Wd, bd, buf, Nout, idxd, N, cd, pd, 1, M, K, Nout, act, W_split=Ws)
+        outs.append(buf.cpu())
+        assert torch.equal(pd.cpu(), p_ref)
+    assert torch.equal(outs[0], outs[1])  # I7: reruns bit-identical
+    assert torch.allclose(outs[0], ref, atol=2e-4, rtol=1e-4), float((outs[0] - ref).abs().max())
+    err = (outs[0][0, sel].double() - y).abs().max() / y.abs().max()
+    assert err < 2e-5, float(err)
+
+
 def test_gated_mlp_matches_two_linears(gemm_mode):
     n = native()
     g = torch.Generator().manual_seed(11)
