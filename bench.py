@@ -95,6 +95,7 @@ class SpatialModel:
                 gate.policy = policies.TokenNormTopK(k=k)
         self.class_token = extra["class_token"].to(device)
         self.ln_w, self.ln_b = extra["ln.weight"].to(device), extra["ln.bias"].to(device)
+        self.graphs = None
 
     def reset(self):
         self.backbone.reset()
@@ -113,8 +114,16 @@ class SpatialModel:
 
     def clip(self, clips):
         """vivit.py:146-147: reset, then one backbone call per time step."""
+        if self.graphs is not None:  # HIP-graph replay of the same launches (eventful_transformer/graphs.py)
+            self.graphs.reset()
+            return torch.stack([self.graphs(clips[t]).clone() for t in range(clips.shape[0])], dim=1)
         self.reset()
         return torch.stack([self.frame(clips[t]) for t in range(clips.shape[0])], dim=1)
+
+    def use_graphs(self):
+        from eventful_transformer.graphs import FrameGraphs
+
+        self.graphs = FrameGraphs(self.backbone, forward=self.frame)
 
 
 def cpu_baseline(sd, extra, cast, k, frames, budget_s=20.0):
@@ -190,6 +199,8 @@ def main():
     ap.add_argument("--cast", default="bfloat16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the per-frame launches (small --clips: "
+                    "host-bound otherwise); implies --no-kernel-events")
     args = ap.parse_args()
     cast = None if args.cast in ("none", "fp32", "None") else args.cast
 
@@ -212,6 +223,9 @@ def main():
     if world > 1:
         broadcast_weights(sd, extra, device, rank)
     model = SpatialModel(sd, extra, cast, args.k, device)
+    if args.graphs:
+        model.use_graphs()
+        args.no_kernel_events = True
     clips = synthetic_clips(args.clips, args.frames, args.k, 1000 + rank, device)
 
     def sync_all():
@@ -280,7 +294,7 @@ def main():
             "config": {"workload": f"ViViT-B spatial 16x224^2 (N=197, D=768, 12 EventfulBlocks) top-k r={args.k}, "
                                    f"T={args.frames} frames/clip incl. dense first frame, matmul_2_cast={cast}",
                        "clips_per_gpu": args.clips, "frames_per_step": args.clips * args.frames,
-                       "parallelism": f"clip-sharded x{world}"},
+                       "parallelism": f"clip-sharded x{world}", "launch": "hip-graph replay" if args.graphs else "eager"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

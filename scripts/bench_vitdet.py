@@ -20,6 +20,7 @@ ap.add_argument("--thr", type=float, default=1.0)
 ap.add_argument("--cast", default="none")
 ap.add_argument("--frames", type=int, default=12)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the first / incremental frame (graphs.py)")
 a = ap.parse_args()
 cast = None if a.cast == "none" else a.cast
 from eventful_transformer import policies
@@ -34,16 +35,20 @@ else:
     xs = O.make_threshold_stream(a.grid ** 2, 768, a.frames, 7)
 xs = xs.cuda()
 times = []
+run = bb
+if a.graphs:
+    from eventful_transformer.graphs import FrameGraphs
+    run = FrameGraphs(bb)
 with torch.inference_mode():
-    for rep in range(2):
-        bb.reset()
+    for rep in range(3 if a.graphs else 2):
+        run.reset()
         times = []
         for t in range(a.frames):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            bb(xs[t])
+            run(xs[t])
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
 nf = times[1:]
-print(json.dumps({"config": f"ViTDet-B backbone {a.grid*16}^2 N={a.grid**2} policy={a.policy} k={a.k} thr={a.thr} cast={cast} B={a.batch}",
+print(json.dumps({"config": f"ViTDet-B backbone {a.grid*16}^2 N={a.grid**2} policy={a.policy} k={a.k} thr={a.thr} cast={cast} B={a.batch} graphs={a.graphs}",
                   "first_frame_ms": round(times[0] * 1e3, 2), "non_first_ms": round(sum(nf) / len(nf) * 1e3, 2),
                   "frames_per_s_non_first": round(a.batch * len(nf) / sum(nf), 1),
                   "frames_per_s_all": round(a.batch * len(times) / sum(times), 1)}))

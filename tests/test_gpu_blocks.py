@@ -305,3 +305,43 @@ def test_pooled_eventful_block_head_dim_64(cast, policy):
             assert float((y - ref).abs().max()) <= tol, (cast, policy, t, float((y - ref).abs().max()))
             if t:
                 assert blk.matmul_gate.p.shape == (1, 4, 64, 16) and blk.v_gate.p.shape == (1, 4, 16, 64)
+
+
+@pytest.mark.parametrize("policy,kw,windowed", [("TokenNormTopK", dict(k=20), False), ("TokenNormThreshold", dict(threshold=0.8), False),
+                                                ("TokenNormTopK", dict(k=30), True)])
+def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed):
+    """HIP-graph replay of the first / incremental frame (graphs.py) against the eager path: same kernels on the
+    same buffers, so outputs must be bit-identical over several clips, including the clip boundary handled by
+    replaying the first-frame graph instead of reset()."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+    from eventful_transformer.graphs import FrameGraphs
+
+    def make():
+        torch.manual_seed(3)
+        cfg = dict(dim=128, heads=2, mlp_ratio=2, matmul_2_cast="bfloat16")
+        extra = {}
+        if windowed:
+            cfg.update(window_size=(4, 4), relative_embedding_size=(8, 8))
+            extra = dict(window_indices=(0, 2), windowed_class="EventfulTokenwiseBlock", windowed_overrides=dict(matmul_2_cast=None))
+        bb = ViTBackbone(block_config=cfg, depth=3, position_encoding_size=(8, 8), input_size=(8, 8),
+                         block_class="EventfulBlock", **extra)
+        for p_ in bb.parameters():
+            torch.nn.init.normal_(p_, std=0.05)
+        bb = bb.eval().to(DEV)
+        H.set_policies(bb, getattr(policies, policy), **kw)
+        return bb
+
+    clips = [O.make_token_stream(2, 64, 128, 6, 20, seed=40 + c, small=0.01).to(DEV) for c in range(3)]
+    eager, graphed = make(), FrameGraphs(make())
+    with torch.inference_mode():
+        for clip in clips:
+            eager.reset()
+            graphed.reset()
+            for t in range(clip.shape[0]):
+                want = eager(clip[t])
+                got = graphed(clip[t])
+                assert torch.equal(got, want), (t, float((got - want).abs().max()))
+    assert graphed._first is not None and graphed._inc is not None
+    with pytest.raises(RuntimeError, match="differs from the captured"):
+        graphed(clips[0][0][:1])
