@@ -1,0 +1,324 @@
+// evt_attn_dense.hip -- K8: whole (window or clip) attention in one launch for groups of <= 256 keys, head dim 64:
+//
+//   S = (q / scale) k^T                     Block._forward_attention, blocks.py:205-240 (windowed: 257-301, 346-376)
+//   S += rel-pos terms                      utils.py:159-168
+//   P = round(softmax(S));  out = round(P . round(v)), heads merged, un-windowed on write
+//
+// This is what the windowed EventfulTokenwiseBlocks of ViTDet run on EVERY frame (attention there is dense), what
+// `Block` runs, and -- with the optional state outputs -- the first frame of an EventfulBlock clip.  One workgroup owns
+// 32 query rows of one (group, head): K is streamed through LDS in 128-key chunks for S, the 32 x Nk score tile stays
+// in LDS for the softmax (rows never leave the CU), V^T chunks reuse the K region for P.V.  Scores, probabilities and
+// the per-head values are never written to HBM unless the caller asks for the states.
+//
+// Arithmetic is that of the unfused kernels (K4 / K5 / K6): fp32-input MFMA for S (exact fp32 products), expf,
+// probabilities and values rounded to the store type T, P.V on the T-input MFMA (fp32: 32x32x2; bf16 / fp16: 32x32x16),
+// result rounded to T.
+#include "evt_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int AR = 32;     // query rows per workgroup
+constexpr int DH = 64;     // head dim
+constexpr int QP = DH + 4; // fp32 LDS pitch of the q / k tiles
+constexpr int KC = 128;    // keys per staged chunk
+
+struct DenseArgs {
+  const float* qkv; const float* rel_y; const float* rel_x;
+  const int32_t* tok_map; const float* pad_row;
+  float* out_f32; float* product; void* a_state; void* pv;
+  int groups_per_clip, clip_rows;
+  int G, H, N, D, gh, gw, qw;
+  float scale;
+};
+
+// P.V over keys [0, len) of the staged chunk (len % 16 == 0): a = P row of this lane, b = V^T row of this lane.
+template <typename T> struct PvSweep;
+template <> struct PvSweep<float> {
+  static __device__ __forceinline__ f32x16 run(const float* a, const float* b, int len, int lh, f32x16 acc) {
+    const int half = len >> 1;  // lane half lh covers k in [lh*half, lh*half + half), half % 8 == 0
+    for (int q = 0; q < half; q += 4) {
+      const float4 fa = *reinterpret_cast<const float4*>(a + lh * half + q);
+      const float4 fb = *reinterpret_cast<const float4*>(b + lh * half + q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct PvSweep<bf16_t> {
+  static __device__ __forceinline__ f32x16 run(const bf16_t* a, const bf16_t* b, int len, int lh, f32x16 acc) {
+    for (int kk = 0; kk < len; kk += 16) {
+      const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(a + kk + 8 * lh);
+      const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(b + kk + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct PvSweep<f16_t> {
+  static __device__ __forceinline__ f32x16 run(const f16_t* a, const f16_t* b, int len, int lh, f32x16 acc) {
+    for (int kk = 0; kk < len; kk += 16) {
+      const f16x8_t fa = *reinterpret_cast<const f16x8_t*>(a + kk + 8 * lh);
+      const f16x8_t fb = *reinterpret_cast<const f16x8_t*>(b + kk + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+__host__ __device__ inline int dense_sp(int N) { return ((N + 15) & ~15) + 4; }  // fp32 pitch of the score tile
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
+  constexpr int TPF = 4 / (int)sizeof(T);     // T elements per float slot
+  constexpr int VP = KC + 16 / (int)sizeof(T);  // V^T pitch in T elements (16-byte pad)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int SP = dense_sp(a.N);
+  float* Qs = reinterpret_cast<float*>(smem_raw);          // [AR][QP]  q rows (raw for rel-pos, then / scale)
+  float* Ks = Qs + AR * QP;                                // [KC][QP]  K chunk;  later V^T chunk [DH][VP] of T
+  T* Vt = reinterpret_cast<T*>(Ks);
+  float* red = Ks;                                         // [AR][DH]  epilogue
+  float* Ss = Ks + KC * QP;                                // [AR][SP]  scores, then P (T, pitch SP * TPF)
+  T* Ps = reinterpret_cast<T*>(Ss);
+  float* relv = Ss + AR * SP;                              // [AR][gh + gw]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int gh_ = blockIdx.y, g = gh_ / a.H, h = gh_ - g * a.H;
+  const int i0 = blockIdx.x * AR;
+  const int64_t rs = 3 * (int64_t)a.D;
+  const bool rel = a.rel_y != nullptr;
+  const int nrel = a.gh + a.gw;
+
+  // ---- q rows -------------------------------------------------------------------------------------------------
+  for (int e = tid; e < AR * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = e - r * (DH / 4), i = i0 + r;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < a.N)
+      q = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, i, a.N) +
+                                           h * DH + c4 * 4);
+    *reinterpret_cast<float4*>(Qs + r * QP + c4 * 4) = q;
+  }
+  __syncthreads();
+  if (rel) {
+    // 32 x (gh + gw) dots of the raw q rows with the table rows (utils.py:159-168), 8 threads per row
+    const int r = tid >> 3, sub = tid & 7, i = i0 + r;
+    if (i < a.N) {
+      const int yi = i / a.qw, xi = i - yi * a.qw;
+      const float* q = Qs + r * QP;
+      for (int e = sub; e < nrel; e += 8) {
+        const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * DH : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * DH;
+        float4 t[DH / 4];
+#pragma unroll
+        for (int d = 0; d < DH / 4; ++d) t[d] = *reinterpret_cast<const float4*>(tab + d * 4);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH / 4; d += 2) {
+          s0 += q[4 * d] * t[d].x + q[4 * d + 1] * t[d].y + q[4 * d + 2] * t[d].z + q[4 * d + 3] * t[d].w;
+          s1 += q[4 * d + 4] * t[d + 1].x + q[4 * d + 5] * t[d + 1].y + q[4 * d + 6] * t[d + 1].z + q[4 * d + 7] * t[d + 1].w;
+        }
+        relv[r * nrel + e] = s0 + s1;
+      }
+    }
+    __syncthreads();
+  }
+  {
+    // q / self.scale (blocks.py:514); a power-of-two scale makes the reciprocal multiply exact
+    const float inv = 1.0f / a.scale;
+    const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+    for (int e = tid; e < AR * DH; e += 256) {
+      float* p = Qs + (e >> 6) * QP + (e & 63);
+      *p = pow2 ? *p * inv : *p / a.scale;
+    }
+  }
+
+  // ---- S = q k^T: 128-key chunks, wave w owns key tile w of the chunk --------------------------------------------
+  for (int c0 = 0; c0 < a.N; c0 += KC) {
+    for (int e = tid; e < KC * (DH / 4); e += 256) {
+      const int r = e / (DH / 4), c4 = e - r * (DH / 4), j = c0 + r;
+      float4 k = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < a.N)
+        k = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, j, a.N) +
+                                             a.D + h * DH + c4 * 4);
+      *reinterpret_cast<float4*>(Ks + r * QP + c4 * 4) = k;
+    }
+    __syncthreads();
+    const int n0 = c0 + wave * 32;
+    if (n0 < a.N) {  // wave-uniform
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* qa = Qs + lr * QP + lh * (DH / 2);
+      const float* kb = Ks + (wave * 32 + lr) * QP + lh * (DH / 2);
+#pragma unroll
+      for (int q = 0; q < DH / 2; q += 4) {
+        const float4 fa = *reinterpret_cast<const float4*>(qa + q);
+        const float4 fb = *reinterpret_cast<const float4*>(kb + q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+      }
+      const int j = n0 + lr;
+      if (j < a.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          Ss[row * SP + j] = acc[r];
+          if (a.product != nullptr && i0 + row < a.N)
+            a.product[((int64_t)gh_ * a.N + i0 + row) * a.N + j] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- softmax: wave w owns rows 8w .. 8w+7; P overwrites the row's scores in place (as T) ------------------------
+  {
+    const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
+    const int npad = (a.N + 15) & ~15;
+    T* ast = reinterpret_cast<T*>(a.a_state);
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
+      const float* rv = relv + r * nrel;
+      float x[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        x[u] = -INFINITY;
+        if (j < a.N) {
+          float v = Ss[r * SP + j];
+          if (rel) { const int ky = fast_div(j, inv_gw); v = (v + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+          x[u] = v;
+        }
+        mx = fmaxf(mx, x[u]);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = (lane + 64 * u < a.N) ? expf(x[u] - mx) : 0.f;
+        sum += x[u];
+      }
+      sum = wave_sum(sum);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();   // every lane has read the fp32 row before anyone overwrites it with T
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * u;
+        if (j < npad) {
+          const float p = (j < a.N && i < a.N) ? Store<T>::round(x[u] / sum) : 0.f;
+          Store<T>::store(Ps + r * SP * TPF + j, p);
+          if (ast != nullptr && j < a.N && i < a.N) Store<T>::store(ast + ((int64_t)gh_ * a.N + i) * a.N + j, p);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P . V: V^T chunks of 128 keys in the K region; wave = (dh half, 64-key half of the chunk) --------------------
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int dt = wave & 1, kh = wave >> 1;
+  const int npad = (a.N + 15) & ~15;
+  for (int c0 = 0; c0 < a.N; c0 += KC) {
+    for (int e = tid; e < KC * (DH / 4); e += 256) {
+      const int c4 = e / KC, jj = e - c4 * KC, j = c0 + jj;   // consecutive threads -> consecutive keys: conflict-free writes
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < a.N)
+        v = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, j, a.N) +
+                                             2 * a.D + h * DH + c4 * 4);
+      Store<T>::store(Vt + (c4 * 4 + 0) * VP + jj, v.x);
+      Store<T>::store(Vt + (c4 * 4 + 1) * VP + jj, v.y);
+      Store<T>::store(Vt + (c4 * 4 + 2) * VP + jj, v.z);
+      Store<T>::store(Vt + (c4 * 4 + 3) * VP + jj, v.w);
+    }
+    __syncthreads();
+    const int k0 = c0 + kh * 64;
+    int len = npad - k0;
+    len = len > 64 ? 64 : len;
+    if (len > 0)
+      acc = PvSweep<T>::run(Ps + lr * SP * TPF + k0, Vt + (dt * 32 + lr) * VP + kh * 64, len, lh, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue: add the two key halves, round, merge heads, un-window ------------------------------------------
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * lh) * DH + dt * 32 + lr] = acc[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* p = red + ((r & 3) + 8 * (r >> 2) + 4 * lh) * DH + dt * 32 + lr;
+      *p = Store<T>::round(acc[r] + *p);
+    }
+  }
+  __syncthreads();
+  T* pv = reinterpret_cast<T*>(a.pv);
+  for (int e = tid; e < AR * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = e - r * (DH / 4), i = i0 + r;
+    if (i >= a.N) continue;
+    const float4 v = *reinterpret_cast<const float4*>(red + r * DH + c4 * 4);
+    if (pv != nullptr) {
+      T* p = pv + ((int64_t)g * a.N + i) * a.D + h * DH + c4 * 4;
+      Store<T>::store(p, v.x); Store<T>::store(p + 1, v.y); Store<T>::store(p + 2, v.z); Store<T>::store(p + 3, v.w);
+    }
+    if (a.out_f32 != nullptr) {
+      int64_t orow = (int64_t)g * a.N + i;
+      if (a.tok_map != nullptr) {
+        const int tr = a.tok_map[(int64_t)(g % a.groups_per_clip) * a.N + i];
+        if (tr < 0) continue;  // padding token: dropped on un-windowing (blocks.py:346-376)
+        orow = (int64_t)(g / a.groups_per_clip) * a.clip_rows + tr;
+      }
+      *reinterpret_cast<float4*>(a.out_f32 + orow * a.D + h * DH + c4 * 4) = v;
+    }
+  }
+}
+
+template <typename T>
+int launch_dense(const DenseArgs& a, void* stream) {
+  const size_t lds = ((size_t)AR * QP + (size_t)KC * QP + (size_t)AR * dense_sp(a.N) + (size_t)AR * (a.gh + a.gw)) * sizeof(float);
+  const dim3 grid((a.N + AR - 1) / AR, a.G * a.H);
+  if (grid.y == 0) return EVT_OK;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_dense_kernel<T>, grid, dim3(256), lds, evt_stream(stream), a);
+  return evt_check_launch("evt_attention_dense");
+}
+
+}  // namespace
+
+extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_attention_dense: null descriptor");
+  EVT_REQUIRE(d->qkv != nullptr && (d->out_f32 != nullptr || d->pv != nullptr), EVT_ERR_BAD_ARG, "evt_attention_dense: null qkv / no output");
+  EVT_REQUIRE(d->G >= 0 && d->H > 0 && d->N > 0 && d->D == d->H * 64, EVT_ERR_BAD_SHAPE,
+              "evt_attention_dense: head dim must be 64 (D=%d, H=%d); use evt_qk + evt_softmax_gate + evt_av", d->D, d->H);
+  EVT_REQUIRE(d->N <= 256, EVT_ERR_BAD_SHAPE, "evt_attention_dense: %d keys per group, at most 256 fit the score tile; use evt_qk + evt_softmax_gate + evt_av", d->N);
+  EVT_REQUIRE((d->rel_y == nullptr) == (d->rel_x == nullptr), EVT_ERR_BAD_ARG, "evt_attention_dense: rel_y/rel_x");
+  EVT_REQUIRE(d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_attention_dense: scale");
+  if (d->rel_y) {
+    EVT_REQUIRE(d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N && d->qw > 0 && d->N % d->qw == 0, EVT_ERR_BAD_SHAPE,
+                "evt_attention_dense: rel-pos key grid %dx%d / query width %d do not match N=%d", d->gh, d->gw, d->qw, d->N);
+  }
+  if (d->tok_map) {
+    EVT_REQUIRE(d->groups_per_clip > 0 && d->clip_rows > 0 && d->pad_row != nullptr && d->G % d->groups_per_clip == 0, EVT_ERR_BAD_ARG,
+                "evt_attention_dense: window map needs groups_per_clip, clip_rows, pad_row");
+    EVT_REQUIRE(d->pv == nullptr && d->a_state == nullptr && d->product == nullptr, EVT_ERR_BAD_ARG,
+                "evt_attention_dense: state outputs are for un-windowed attention");
+  }
+  DenseArgs a{d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row, d->out_f32, d->product, d->a_state, d->pv,
+              d->tok_map ? d->groups_per_clip : 1, d->tok_map ? d->clip_rows : d->N, d->G, d->H, d->N, d->D,
+              d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale};
+  EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, stream); });
+  return EVT_OK;
+}

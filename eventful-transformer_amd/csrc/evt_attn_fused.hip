@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   T* Ad = An + FR * P;                                 // [FR][P]
   T* Vd = Ad + FR * P;                                 // [dh][P]
   T* Vo = Vd + a.dh * P;                               // [dh][P]
-  const bool rel_lds = a.rel_y != nullptr;
   float* relv = reinterpret_cast<float*>(Vo + a.dh * P);  // [FR][gh+gw] rel-pos terms per row
-  float* qs = relv + FR * (a.gh + a.gw);               // [FR][dh]    q rows (rel-pos only)
-  float* et = qs + (rel_lds ? FR : 0) * a.dh;                           // [FR][EP] exp(x - max) (NREG > 0), later the
-  float* red1 = et;                                    // [FR][dh] round(a~ . dv~)   (aliases et)
-  float* red2 = et + FR * a.dh;                        // [FR][dh] round(da~ . v_old)
+  float* et = relv + FR * (a.gh + a.gw);               // [FR][EP] exp(x - max) (NREG > 0 only)
+  // The V tiles are idle before the chunk loop and after it; they double as
+  float* qs = reinterpret_cast<float*>(Vd);            // [FR][dh] q rows for the rel-pos dots (prologue)
+  float* red1 = reinterpret_cast<float*>(Vd);          // [FR][dh] round(a~ . dv~)          (epilogue)
+  float* red2 = red1 + FR * a.dh;                      // [FR][dh] round(da~ . v_old)       (2*FR*dh*4 <= 2*dh*P*sizeof(T))
   const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -198,6 +198,38 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       const float* rv = relv + r * nrel;
       const float* prow = prod + (int64_t)i * a.Nk;
       float mx = -INFINITY, sum = 0.f;
+      if ((a.Nk & 3) == 0) {
+        // 16-byte lane loads: 8 KB of the row in flight per wave (one step covers 2048 columns)
+        for (int j0 = 0; j0 < a.Nk; j0 += 2048) {
+          float4 x4[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + (lane + 64 * u) * 4;
+            x4[u] = (j < a.Nk) ? *reinterpret_cast<const float4*>(prow + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+          }
+          if (rel) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int j = j0 + (lane + 64 * u) * 4;
+              if (j < a.Nk) {
+                float* xe = reinterpret_cast<float*>(&x4[u]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int ky = fast_div(j + q, inv_gw); xe[q] = (xe[q] + rv[ky]) + rv[a.gh + j + q - ky * a.gw]; }
+              }
+            }
+          }
+          float cm = -INFINITY;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cm = fmaxf(cm, fmaxf(fmaxf(x4[u].x, x4[u].y), fmaxf(x4[u].z, x4[u].w)));
+          const float nm = fmaxf(mx, cm);
+          float part = 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            part += (fast_exp(x4[u].x - nm) + fast_exp(x4[u].y - nm)) + (fast_exp(x4[u].z - nm) + fast_exp(x4[u].w - nm));
+          sum = (nm == -INFINITY) ? 0.f : sum * fast_exp(mx - nm) + part;
+          mx = nm;
+        }
+      } else
       for (int j0 = 0; j0 < a.Nk; j0 += 512) {
         float x[8];
 #pragma unroll
@@ -369,10 +401,9 @@ template <typename T>
 int launch_fused(const FusedArgs& a, void* stream) {
   constexpr int P = Tile<T>::PITCH;
   const int nreg = (a.Nk + 63) / 64;
-  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.Nk | 1) : 0;        // exp tile (aliases the two
-  const size_t tile_r = (size_t)2 * FR * a.dh;                          // rounded-product tiles)
-  const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) +
-                     ((tile_e > tile_r ? tile_e : tile_r) + FR * (a.gh + a.gw) + (a.rel_y ? FR * a.dh : 0)) * sizeof(float);
+  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.Nk | 1) : 0;        // exp tile; q rows and the rounded-product
+  static_assert(2 * FR * sizeof(float) <= 2 * P * sizeof(T), "red tiles must fit in the V tiles");  // tiles alias Vd/Vo
+  const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) + (tile_e + FR * (a.gh + a.gw)) * sizeof(float);
   const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
   if (grid.y == 0) return EVT_OK;
   hipStream_t s = evt_stream(stream);

@@ -28,6 +28,8 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDT: padded LDS row (floats)
 constexpr int GEMM_THREADS = 256;
 
+constexpr int EVT_SPLITK_DYN_MAX_CLIPS = 32;  // device-side split-K choice reads every clip's count per workgroup
+
 struct LinArgs {
   const float* A; int64_t lda; const int32_t* a_idx; int a_rows;
   const float* W; const uint16_t* Wsplit; const float* bias;
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
     w_ok[j] = n < g.Nout;
     w_ptr[j] = g.W + (int64_t)(w_ok[j] ? n : 0) * g.K;
   }
+  // threshold policy: kcap = N but only count[b] rows are live -- tiles made of masked rows only have nothing to do
+  if (!__syncthreads_or(a_ok[0] | a_ok[1] | a_ok[2] | a_ok[3])) return;
 
   float4 ra[4], rw[4];
   auto fetch = [&](int k0) {
@@ -205,11 +209,33 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
   *lo = __builtin_convertvector(r, bf16x4_t);
 }
 
+// Split-K factor for `tiles` live 128x128 output tiles and nk k-tiles: only when the tile count leaves most of
+// the 256 CUs idle; every split keeps >= 4 k-tiles.  Evaluated on the host from the shape, or -- with a
+// per-clip count (threshold policy: kcap = N, few live rows) -- on the device from the counts, identically by
+// the GEMM workgroups and by splitk_finish_kernel.
+__host__ __device__ inline int splitk_for(int tiles, int nk) {
+  if (tiles <= 0 || tiles >= 128) return 1;
+  int s = (256 + tiles - 1) / tiles;
+  s = s < nk / 4 ? s : nk / 4;
+  s = s < 16 ? s : 16;
+  if (s < 2) return 1;
+  const int kps = (nk + s - 1) / s;
+  return (nk + kps - 1) / kps;  // drop empty trailing splits
+}
+
+// dyn != 0: live tiles = sum_b ceil(count[b] / 128) * tiles_n (exact when kcap % 128 == 0; any consistent
+// estimate is correct, it only has to be the same everywhere)
+__device__ __forceinline__ int splitk_dynamic(const int32_t* count, int B, int tiles_n, int nk) {
+  int live = 0;
+  for (int b = 0; b < B; ++b) live += (count[b] + 127) >> 7;
+  return splitk_for(live * tiles_n, nk);
+}
+
 // Tile configuration: TBM x TBN output tile, TBK k-tile, WM x WN waves each owning a 64x64 sub-tile
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
 template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit) {
+__global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
   constexpr int NT = WM * WN * 64;
   constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
   static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
@@ -220,6 +246,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   __bf16* Bhi = lds + 2 * TBM * TSP;
   __bf16* Blo = lds + 2 * TBM * TSP + TBN * TSP;
 
+  const int split = blockIdx.x / tiles_total;
+  if (dyn) {  // launched with the largest factor the shape allows; the counts decide how many splits work
+    ksplit = splitk_dynamic(g.count, g.B, tiles_n, (g.K + TBK - 1) / TBK);
+    if (split >= ksplit) return;
+  }
   // XCD-aware tile order (dispatch puts workgroup w on XCD w % 8).  map 0: each XCD owns a contiguous run of
   // row-major tiles (bijective for any tile count).  map 1 (tiles_n even, tiles_m % 4 == 0): each XCD owns a
   // (tiles_m/4) x (tiles_n/2) rectangle, so its half of W stays resident in its 4 MB L2 and every A panel is
@@ -242,6 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   const int m0 = bm * TBM, n0 = bn * TBN;
   const int M = g.B * g.kcap;
 
+  int live = 0;
   for (int r = tid; r < TBM; r += NT) {
     const int m = m0 + r;
     int64_t off = -1;
@@ -251,7 +283,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
         off = ((int64_t)b * g.o_rows + ((g.o_idx != nullptr) ? g.o_idx[m] : ii)) * g.ldo;
     }
     orow_off[r] = off;
+    live |= off >= 0;
   }
+  // threshold policy: kcap = N but only count[b] rows are live -- tiles made of masked rows only have nothing to do
+  // (with split-K their workspace rows stay unwritten; splitk_finish_kernel skips the same rows)
+  if (!__syncthreads_or(live)) return;
   // A staging: float4 chunks, TBK/4 per row; thread -> rows ar0 + j*AROWS
   constexpr int ACH = TBK / 4;           // float4 chunks per A row
   constexpr int AROWS = NT / ACH;        // rows covered per pass
@@ -328,7 +364,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
     for (int j = 0; j < AJ; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
   }
   // split-K: this workgroup contracts k-tiles [t0, nk) of the tile; ksplit == 1 is the whole K.
-  const int split = blockIdx.x / tiles_total;
   const int nk_all = (g.K + TBK - 1) / TBK, kps = (nk_all + ksplit - 1) / ksplit;
   const int t0 = split * kps, nk = min(nk_all, t0 + kps);
   const int lr = lane & 31, lh = lane >> 5;
@@ -410,20 +445,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   }
 }
 
-// Split-K factor for the default 128x128x32 tiling: only when the tile count leaves most of the 256 CUs idle;
-// every split keeps >= 4 k-tiles.  Depends on the shape alone so that reruns are bit-identical.
 int splitk_factor(int M, int K, int Nout) {
-  const int tiles = ((M + 127) / 128) * ((Nout + 127) / 128), nk = (K + 31) / 32;
-  if (tiles == 0 || tiles >= 128) return 1;
-  int s = std::min(std::min((256 + tiles - 1) / tiles, nk / 4), 16);
-  if (s < 2) return 1;
-  const int kps = (nk + s - 1) / s;
-  return (nk + kps - 1) / kps;  // drop empty trailing splits
+  return splitk_for(((M + 127) / 128) * ((Nout + 127) / 128), (K + 31) / 32);
 }
+// largest factor a launch with per-clip counts can ask for (one live row tile)
+int splitk_factor_max(int K, int Nout) { return splitk_for((Nout + 127) / 128, (K + 31) / 32); }
 
 // out[orow(m), n] = act(bias[n] + sum_s ws[s][m][n]), s ascending; one thread per 4 columns.
 template <int ACT>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int ksplit) {
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int ksplit, int dyn, int tiles_n) {
+  if (dyn) {
+    ksplit = splitk_dynamic(g.count, g.B, tiles_n, (g.K + 31) / 32);
+    if (ksplit == 1) return;  // the GEMM workgroups wrote `out` themselves
+  }
   const int n4 = g.Nout >> 2;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int M = g.B * g.kcap;
@@ -446,7 +480,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int
 }
 
 template <int TBM, int TBN, int TBK, int WM, int WN>
-void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1) {
+void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn = 0) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
   const dim3 grid(tiles_m * tiles_n * ksplit), block(WM * WN * 64);
@@ -454,15 +488,15 @@ void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1) {
   const int tile_map = (want_map == 1 && (tiles_n % 2) == 0 && (tiles_m % 4) == 0) ? 1 : 0;
   if (a.act == EVT_ACT_GELU_ERF)
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n, tile_map, ksplit);
+                       tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   else
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
-                       tiles_n, tiles_m * tiles_n, tile_map, ksplit);
+                       tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   if (ksplit > 1) {
     const int64_t work = (int64_t)M * (a.Nout / 4);
     const dim3 fg((unsigned)((work + 255) / 256));
-    if (a.act == EVT_ACT_GELU_ERF) hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_GELU_ERF>, fg, dim3(256), 0, s, a, ksplit);
-    else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit);
+    if (a.act == EVT_ACT_GELU_ERF) hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_GELU_ERF>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
+    else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
   }
 }
 
@@ -471,9 +505,11 @@ void launch_split(const LinArgs& a, hipStream_t s) {
   const int variant = forced < 0 ? 0 : forced;
   static const int splitk_on = getenv("EVT_GEMM_SPLITK") ? atoi(getenv("EVT_GEMM_SPLITK")) : 1;
   if (variant == 0 && splitk_on && a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {
-    const int M = a.B * a.kcap, ks = splitk_factor(M, a.K, a.Nout);
+    const int M = a.B * a.kcap;
+    const bool dyn = a.count != nullptr && a.B <= EVT_SPLITK_DYN_MAX_CLIPS;
+    const int ks = dyn ? splitk_factor_max(a.K, a.Nout) : splitk_factor(M, a.K, a.Nout);
     if (ks > 1 && (int64_t)ks * M * a.Nout * 4 <= a.ws_bytes) {
-      launch_split_cfg<128, 128, 32, 2, 2>(a, s, ks);
+      launch_split_cfg<128, 128, 32, 2, 2>(a, s, ks, dyn ? 1 : 0);
       return;
     }
   }
@@ -539,11 +575,12 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
   return launch_linear(a, stream);
 }
 
-extern "C" int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout) {
+extern "C" int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout, int32_t has_count) {
   if (B <= 0 || kcap <= 0 || K <= 0 || Nout <= 0) return 0;
   const int64_t M = (int64_t)B * kcap;
   if (M > (1 << 20)) return 0;
-  const int ks = splitk_factor((int)M, K, Nout);
+  const bool dyn = has_count && B <= EVT_SPLITK_DYN_MAX_CLIPS;
+  const int ks = dyn ? splitk_factor_max(K, Nout) : splitk_factor((int)M, K, Nout);
   return ks > 1 ? (int64_t)ks * M * Nout * 4 : 0;
 }
 

@@ -24,6 +24,7 @@ ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
+    "evt_attention_dense",
 )
 
 
@@ -91,6 +92,15 @@ class SoftmaxAvDesc(Structure):
     ]
 
 
+class AttnDenseDesc(Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("rel_y", c_void_p), ("rel_x", c_void_p), ("gh", c_int32), ("gw", c_int32), ("qw", c_int32),
+        ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("clip_rows", c_int32), ("pad_row", c_void_p),
+        ("out_f32", c_void_p), ("product", c_void_p), ("a_state", c_void_p), ("pv", c_void_p),
+        ("G", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("scale", c_float), ("store", c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -99,7 +109,7 @@ def _bind(lib):
     lib.evt_version.restype = c_int
     lib.evt_last_error_string.restype = c_char_p
     lib.evt_target_arch.restype = c_char_p
-    lib.evt_gated_linear_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32]
+    lib.evt_gated_linear_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.evt_gated_linear_workspace_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
@@ -116,6 +126,7 @@ def _bind(lib):
         "evt_pool_kv": [P, I, I, I, I, I, I, P, P],
         "evt_pool_index": [P, P, I, I, I, I, I, I, I, I, P, P, P],
         "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
+        "evt_attention_dense": [POINTER(AttnDenseDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -241,6 +252,7 @@ def _timed(flops, fn, launches=1):
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
 # (~1e-5 relative to fp32, ~5x the fp32-MFMA rate); "f32" = exact fp32-input MFMA.  EVT_GEMM overrides.
 GEMM_MODE = os.environ.get("EVT_GEMM", "split")
+DENSE_FUSED = os.environ.get("EVT_DENSE_FUSED", "1") != "0"   # K8 (evt_attention_dense) vs the K4+K5+K6 chain
 
 
 def split_weight(W):
@@ -253,17 +265,20 @@ def split_weight(W):
     return planes
 
 
-def _splitk_workspace(device, *shapes):
+SPLITK_WS_LIMIT = 1 << 30
+
+
+def _splitk_workspace(device, has_count, *shapes):
     """Split-K partial-sum workspace for small launches (evt_gated_linear_workspace_bytes); (None, 0) if unused."""
-    need = max(load().evt_gated_linear_workspace_bytes(*s) for s in shapes)
-    if need == 0:
+    need = max(load().evt_gated_linear_workspace_bytes(*s, int(has_count)) for s in shapes)
+    if need == 0 or need > SPLITK_WS_LIMIT:
         return None, 0
     return scratch("splitk_ws", (need // 4,), torch.float32, device), need
 
 
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
                  W_split=None):
-    ws, ws_bytes = _splitk_workspace(out.device, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
+    ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
                    _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes)
     _timed(2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
@@ -274,7 +289,7 @@ def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd,
     s1, s2 = W1_split, W2_split
     if s1 is None or s2 is None:
         s1 = s2 = None
-    ws, ws_bytes = _splitk_workspace(out.device, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
+    ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
                 _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes)
     _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
@@ -348,6 +363,19 @@ def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
                       N if Nk is None else Nk, gw if qw is None else qw)
     _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream()))
+
+
+def attention_dense_fits(N, D, H):
+    """K8 handles groups of <= 256 tokens at head dim 64."""
+    return D == 64 * H and 0 < N <= 256
+
+
+def attention_dense(qkv, G, H, N, D, scale, store, out_f32=None, rel_y=None, rel_x=None, gh=0, gw=0, qw=0, tok_map=None,
+                    groups_per_clip=1, clip_rows=0, pad_row=None, product=None, a_state=None, pv=None):
+    """K8: q.k^T + rel-pos + softmax + A.v of whole groups in one launch (scores never reach HBM)."""
+    d = AttnDenseDesc(_p(qkv), _p(rel_y), _p(rel_x), gh, gw, qw, _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
+                      _p(out_f32), _p(product), _p(a_state), _p(pv), G, H, N, D, float(scale), store)
+    _check(load().evt_attention_dense(ctypes.byref(d), _stream()))
 
 
 def av(a1, v1, lda, B, H, N, K, D, store, pv=None, out_f32=None, a2=None, v2=None, count=None, gated=False,

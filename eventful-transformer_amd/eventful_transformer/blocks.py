@@ -192,6 +192,15 @@ class Block(ExtendedModule):
             gpc, n = tok_map.shape
             G, pad = B * gpc, self.qkv.bias
             assert prod(self.input_size) == N, "windowed attention needs tokens == prod(input_size)"
+        if self.pool_size is None and _native.attention_dense_fits(n, D, H) and _native.DENSE_FUSED:
+            # K8: the whole group in one launch, no score / probability tensors in HBM
+            _native.attention_dense(qkv, G, H, n, D, self.scale, store, out_f32=out, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
+                                    qw=qw, tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
+            self.matmul.count_product(G * H * n * n, dh)
+            if self.relative_position is not None:
+                self.relative_position.count_fused(G, H)
+            self.matmul.count_product(G * H * n * dh, n)
+            return
         kv, nk = self._pool_kv(qkv, B, N) if self.window_size is None else (None, n)
         win = dict(tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
         prod_s = self._ws("attn_scores", (G, H, n, nk), torch.float32, qkv)

@@ -142,9 +142,13 @@ EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
  * 128x128 tiling yields fewer workgroups than the chip has CUs, the split-precision kernel divides K
  * among S workgroups per tile; each writes its fp32 partial tile to `workspace` and a second kernel
  * sums the S partials IN FIXED ORDER (bit-reproducible), adds bias, applies act and scatters through
- * o_idx.  S depends only on (B*kcap, K, Nout).  This returns the bytes K3 wants for a given shape
- * (0 = split-K not used); a smaller or null workspace silently selects the single-pass kernel. */
-EVT_API int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout);
+ * o_idx.  Without `count`, S depends only on (B*kcap, K, Nout).  With `count` (threshold policy:
+ * kcap = N but few live rows) and B <= 32, S is chosen ON THE DEVICE from the counts -- the launch
+ * covers the largest S the shape allows, dead tiles and surplus splits exit at once -- so S is a
+ * function of the data, still identical on every rerun.  This returns the bytes K3 wants for a
+ * given shape (0 = split-K not used); a smaller or null workspace silently selects the single-pass
+ * kernel. */
+EVT_API int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout, int32_t has_count);
 
 /* Split an fp32 weight matrix (n elements, n % 4 == 0) into two bf16 planes written back to back to
  * `out` (2*n bf16): hi = rne_bf16(w), lo = rne_bf16(w - hi).  With W_split set, K3/K7 compute
@@ -314,6 +318,35 @@ EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
 EVT_API int evt_pool_kv(const float* qkv, int B, int qh, int qw, int D, int p0, int p1, float* kv, void* stream);
 EVT_API int evt_pool_index(const int32_t* idx, const int32_t* count, int B, int kcap, int qw, int p0, int p1,
                            int kw, int Nk, int kcap_k, int32_t* idx_k, int32_t* count_k, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K8  Dense attention of one group (clip, or window of a partitioned clip) in ONE launch:
+ *       out[b, t, h*64+d] = round( round(softmax((q/scale) k^T + rel-pos)) . round(v) )
+ *     for groups of at most 256 tokens and head dim 64 (ViT-B: 14x14 windows, ViViT's 197 tokens).
+ *     Replaces Block._forward_attention (blocks.py:205-240) incl. window partition / un-partition
+ *     (blocks.py:257-301, 346-376: tok_map as in evt_qk, rows mapped to padding are dropped on
+ *     write) -- i.e. evt_qk + evt_softmax_gate + evt_v_gate + evt_av without the (G,H,N,N) score
+ *     and probability tensors ever reaching HBM.  Same arithmetic and rounding points as those.
+ *     Optional state outputs for the first frame of an EventfulBlock clip (un-windowed only):
+ *       product (G,H,N,N) fp32 = (q/scale) k^T   MatmulBuffer.forward_first        modules.py:224-230
+ *       a_state (G,H,N,N) store type = P          matmul_gate reference             modules.py:183-185
+ *       pv      (G,N,D)   store type = out        MatmulDeltaAccumulator first      modules.py:277-283
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_attn_dense_desc {
+  const float* qkv;                       /* packed (B, clip_rows, 3D): q | k | v per token row   */
+  const float* rel_y; const float* rel_x; /* nullable pair: (qh, gh, 64), (qw, gw, 64) tables     */
+  int32_t gh, gw, qw;                     /* key grid gh x gw (= N), query grid width             */
+  const int32_t* tok_map;                 /* nullable: (groups_per_clip, N) window map, -1 = pad  */
+  int32_t groups_per_clip, clip_rows;
+  const float* pad_row;                   /* qkv row of a padding token (the qkv bias)            */
+  float* out_f32;                         /* (B, clip_rows, D)                                    */
+  float* product; void* a_state; void* pv;/* nullable state outputs                               */
+  int32_t G, H, N, D;                     /* G groups of N tokens                                 */
+  float scale;
+  int32_t store;
+} evt_attn_dense_desc;
+
+EVT_API int evt_attention_dense(const evt_attn_dense_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -229,7 +229,7 @@ def test_splitk_small_launch(M, K, Nout, act):
     n = native()
     if n.GEMM_MODE != "split":
         pytest.skip("split-K belongs to the split-precision kernel")
-    assert n.load().evt_gated_linear_workspace_bytes(1, M, K, Nout) > 0
+    assert n.load().evt_gated_linear_workspace_bytes(1, M, K, Nout, 0) > 0
     g = torch.Generator().manual_seed(M + K + Nout)
     N = M + 60
     A = torch.randn(1, N, K, generator=g)
@@ -259,6 +259,41 @@ def test_splitk_small_launch(M, K, Nout, act):
     assert torch.allclose(outs[0], ref, atol=2e-4, rtol=1e-4), float((outs[0] - ref).abs().max())
     err = (outs[0][0, sel].double() - y).abs().max() / y.abs().max()
     assert err < 2e-5, float(err)
+
+
+@pytest.mark.parametrize("counts", [[100], [1000], [0], [130, 5, 1024]])
+def test_splitk_dynamic_counts(counts):
+    """Threshold-policy launches (kcap = N, per-clip counts on the device): the split-K factor is picked by the
+    workgroups from the counts -- few live tiles -> split + finish kernel, many -> single pass under the same
+    launch, none -> nothing written."""
+    n = native()
+    if n.GEMM_MODE != "split":
+        pytest.skip("split-K belongs to the split-precision kernel")
+    B, N, K, Nout = len(counts), 1024, 768, 2304
+    assert n.load().evt_gated_linear_workspace_bytes(B, N, K, Nout, 1) > 0
+    g = torch.Generator().manual_seed(sum(counts) + B)
+    A = torch.randn(B, N, K, generator=g)
+    W = torch.randn(Nout, K, generator=g) * 0.03
+    bias = torch.randn(Nout, generator=g)
+    idx = torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).int()
+    buf0 = torch.randn(B, N, Nout, generator=g)
+    ref = buf0.clone()
+    for b, c in enumerate(counts):
+        sel = idx[b, :c].long()
+        ref[b, sel] = torch.nn.functional.linear(A[b, sel].double(), W.double(), bias.double()).float()
+    Ad, Wd, bd, idxd = (t.to(DEV) for t in (A, W, bias, idx))
+    cd = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    Ws = n.split_weight(Wd)
+    outs = []
+    for _ in range(2):
+        buf = buf0.to(DEV)
+        n.gated_linear(Ad, K, idxd, N, Wd, bd, buf, Nout, idxd, N, cd, None, B, N, K, Nout, 0, W_split=Ws)
+        outs.append(buf.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(outs[0], ref, atol=2e-4, rtol=1e-4), float((outs[0] - ref).abs().max())
+    for b, c in enumerate(counts):   # rows past count[b] bit-unchanged
+        dead = idx[b, c:].long()
+        assert torch.equal(outs[0][b, dead], buf0[b, dead])
 
 
 def test_gated_mlp_matches_two_linears(gemm_mode):
@@ -433,3 +468,90 @@ def test_fused_softmax_av_gated_matches_oracle(cast, N, k, rel):
         err = float((out.cpu() - ref).abs().max())
         assert err <= tol, (cast, N, k, t, err)
         assert torch.equal(out.cpu(), pv.float().cpu())
+
+
+@pytest.mark.parametrize("cast,N,rel", [(None, 197, False), ("bfloat16", 197, False), (None, 196, True), ("float16", 100, True),
+                                        (None, 256, True), (None, 33, False)])
+def test_attention_dense_fused_vs_fp64(cast, N, rel):
+    """K8 (evt_attention_dense): one launch for q.k^T + rel-pos + softmax + A.v against an fp64 restatement of
+    blocks.py:205-240 with the reference's rounding points, plus its state outputs (first frame of a clip)."""
+    n = native()
+    B, H, dh = 2, 3, 64
+    D = H * dh
+    g = torch.Generator().manual_seed(N + (7 if rel else 0))
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    scale = float(np.sqrt(dh))
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    side = int(round(N ** 0.5))
+    ry = rx = None
+    if rel:
+        assert side * side == N
+        ry = torch.randn(side, side, dh, generator=g) * 0.2
+        rx = torch.randn(side, side, dh, generator=g) * 0.2
+    q, k, v = qkv.double().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = ((q.float() / scale).double()) @ k.transpose(-2, -1)
+    s32 = s.clone()
+    if rel:
+        qg = q.reshape(B, H, side, side, dh)
+        ty = torch.einsum("bhyxd,ykd->bhyxk", qg, ry.double())
+        tx = torch.einsum("bhyxd,xkd->bhyxk", qg, rx.double())
+        s = (s.view(B, H, side, side, side, side) + ty[..., :, None] + tx[..., None, :]).reshape(B, H, N, N)
+    p = torch.softmax(s, dim=-1).to(sdt)
+    vv = v.float().to(sdt)
+    want = (p.double() @ vv.double()).to(sdt).float().permute(0, 2, 1, 3).reshape(B, N, D)
+    out = torch.empty(B, N, D, device=DEV)
+    product = torch.empty(B, H, N, N, device=DEV)
+    a_state = torch.empty(B, H, N, N, dtype=sdt, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    kw = dict(rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=side, gw=side, qw=side) if rel else {}
+    n.attention_dense(qkv.to(DEV), B, H, N, D, scale, store, out_f32=out, product=product, a_state=a_state, pv=pv, **kw)
+    tol = {None: 2e-5, "bfloat16": 1.6e-2, "float16": 2e-3}[cast]   # one rounding step of the store type on O(1) values
+    assert torch.allclose(product.cpu().double(), s32, atol=1e-4, rtol=1e-5)
+    assert float((a_state.cpu().double() - p.double()).abs().max()) <= tol / 4
+    assert float((out.cpu() - want).abs().max()) <= tol, float((out.cpu() - want).abs().max())
+    assert torch.equal(pv.cpu().float(), out.cpu())
+    # the unfused chain (K4 + K5 + K6a + K6) on the same buffer: same rounding points
+    prod2 = torch.empty(B, H, N, N, device=DEV)
+    a2 = torch.empty(B, H, N, N, dtype=sdt, device=DEV)
+    v2 = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    out2 = torch.empty(B, N, D, device=DEV)
+    qd = qkv.to(DEV)
+    n.qk_packed(qd, B, N, D, H, scale, prod2)
+    n.softmax_gate(prod2, a2, B, H, N, N, D, store, qkv=qd, **kw)
+    n.v_gate(qd, None, None, B, N, D, 0, v2, None, None, store, False)
+    n.av(a2, v2, N, B, H, N, N, D, store, out_f32=out2)
+    assert float((out.cpu() - out2.cpu()).abs().max()) <= tol
+
+
+def test_attention_dense_windowed_block_matches_chain():
+    """Windowed dense attention (14x14 windows on a padded 20x20 grid, rel-pos): the K8 launch against the
+    K4+K5+K6 chain through the same Block, padding rows dropped on un-windowing."""
+    from eventful_transformer import _native, blocks
+    torch.manual_seed(5)
+    blk = blocks.Block(dim=128, heads=2, input_size=(20, 20), mlp_ratio=2, window_size=(14, 14), relative_embedding_size=(14, 14))
+    for p_ in blk.parameters():
+        torch.nn.init.normal_(p_, std=0.08)
+    blk = blk.eval().to(DEV)
+    x = torch.randn(2, 400, 128, device=DEV)
+    outs = []
+    try:
+        for fused in (True, False):
+            _native.DENSE_FUSED = fused
+            blk.reset()
+            with torch.inference_mode():
+                outs.append(blk(x).cpu())
+    finally:
+        _native.DENSE_FUSED = True
+    assert torch.isfinite(outs[0]).all()
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * float(outs[1].abs().max() + 1)
+
+
+def test_attention_dense_argument_errors():
+    n = native()
+    qkv = torch.zeros(1, 300, 3 * 64, device=DEV)
+    out = torch.zeros(1, 300, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="at most 256"):
+        n.attention_dense(qkv, 1, 1, 300, 64, 8.0, n.store_code(torch.float32), out_f32=out)
+    with pytest.raises(RuntimeError, match="head dim must be 64"):
+        n.attention_dense(qkv, 1, 2, 100, 64, 8.0, n.store_code(torch.float32), out_f32=out)

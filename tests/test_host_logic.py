@@ -43,11 +43,14 @@ def test_splitk_workspace_query_is_shape_only():
     """Split-K is chosen from (rows, K, Nout) alone: few-tile launches get S planes, chip-filling ones none."""
     from eventful_transformer import _native
     q = _native.load().evt_gated_linear_workspace_bytes
-    assert q(1, 256, 768, 2304) == 6 * 256 * 2304 * 4      # 36 tiles, 24 k-tiles -> 6 splits of 4
-    assert q(1, 256, 3072, 768) == 16 * 256 * 768 * 4      # 12 tiles, 96 k-tiles -> 16 splits of 6
-    assert q(256, 128, 768, 2304) == 0                     # 4608 tiles: single pass
-    assert q(1, 12, 64, 192) == 0                          # K too short to split
-    assert q(0, 128, 768, 768) == 0 and q(1, 128, 0, 768) == 0
+    assert q(1, 256, 768, 2304, 0) == 6 * 256 * 2304 * 4      # 36 tiles, 24 k-tiles -> 6 splits of 4
+    assert q(1, 256, 3072, 768, 0) == 16 * 256 * 768 * 4      # 12 tiles, 96 k-tiles -> 16 splits of 6
+    assert q(256, 128, 768, 2304, 0) == 0                     # 4608 tiles: single pass
+    assert q(1, 12, 64, 192, 0) == 0                          # K too short to split
+    assert q(0, 128, 768, 768, 0) == 0 and q(1, 128, 0, 768, 1) == 0
+    # per-clip counts: the device picks S, the workspace covers the largest one (a single live row tile)
+    assert q(1, 4096, 768, 2304, 1) == 6 * 4096 * 2304 * 4 and q(1, 4096, 768, 2304, 0) == 0
+    assert q(64, 4096, 768, 2304, 1) == 0                  # too many clips for the per-workgroup count scan
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
