@@ -6,7 +6,7 @@
 //
 // This is what the windowed EventfulTokenwiseBlocks of ViTDet run on EVERY frame (attention there is dense), what
 // `Block` runs, and -- with the optional state outputs -- the first frame of an EventfulBlock clip.  One workgroup owns
-// 32 query rows of one (group, head): K is streamed through LDS in 128-key chunks for S, the 32 x Nk score tile stays
+// 32 query rows of one (group, head): K is streamed through LDS in 64-key chunks for S, the 32 x Nk score tile stays
 // in LDS for the softmax (rows never leave the CU), V^T chunks reuse the K region for P.V.  Scores, probabilities and
 // the per-head values are never written to HBM unless the caller asks for the states.
 //
@@ -23,7 +23,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 constexpr int AR = 32;     // query rows per workgroup
 constexpr int DH = 64;     // head dim
 constexpr int QP = DH + 4; // fp32 LDS pitch of the q / k tiles
-constexpr int KC = 128;    // keys per staged chunk
+constexpr int KC = 64;     // keys per staged chunk
 
 struct DenseArgs {
   const float* qkv; const float* rel_y; const float* rel_x;
@@ -72,20 +72,26 @@ template <> struct PvSweep<f16_t> {
 };
 
 __host__ __device__ inline int dense_sp(int N) { return ((N + 15) & ~15) + 4; }  // fp32 pitch of the score tile
+__host__ __device__ inline int dense_tile_floats(int N) {                          // score tile; the q tile aliases it
+  const int s = AR * dense_sp(N), q = AR * QP;
+  return s > q ? s : q;
+}
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
-  constexpr int TPF = 4 / (int)sizeof(T);     // T elements per float slot
+  constexpr int TPF = 4 / (int)sizeof(T);       // T elements per float slot
   constexpr int VP = KC + 16 / (int)sizeof(T);  // V^T pitch in T elements (16-byte pad)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int SP = dense_sp(a.N);
-  float* Qs = reinterpret_cast<float*>(smem_raw);          // [AR][QP]  q rows (raw for rel-pos, then / scale)
-  float* Ks = Qs + AR * QP;                                // [KC][QP]  K chunk;  later V^T chunk [DH][VP] of T
+  float* Ks = reinterpret_cast<float*>(smem_raw);          // [KC][QP]  K chunk;  later V^T chunk [DH][VP] of T
   T* Vt = reinterpret_cast<T*>(Ks);
   float* red = Ks;                                         // [AR][DH]  epilogue
   float* Ss = Ks + KC * QP;                                // [AR][SP]  scores, then P (T, pitch SP * TPF)
+  float* Qs = Ss;                                          // [AR][QP]  q rows until their MFMA fragments sit in registers
   T* Ps = reinterpret_cast<T*>(Ss);
-  float* relv = Ss + AR * SP;                              // [AR][gh + gw]
+  float* relv = Ss + dense_tile_floats(a.N);               // [AR][gh + gw]
+  int* tmap = reinterpret_cast<int*>(relv + AR * (a.gh + a.gw));  // [N] clip row of each group token, -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -95,95 +101,188 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;
 
-  // ---- q rows -------------------------------------------------------------------------------------------------
-  for (int e = tid; e < AR * (DH / 4); e += 256) {
-    const int r = e / (DH / 4), c4 = e - r * (DH / 4), i = i0 + r;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < a.N)
-      q = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, i, a.N) +
-                                           h * DH + c4 * 4);
-    *reinterpret_cast<float4*>(Qs + r * QP + c4 * 4) = q;
+  // ---- window map of the group, once (every staging step below resolves rows through LDS, so its global loads
+  //      are independent and all in flight together) ---------------------------------------------------------------
+  for (int j = tid; j < a.N; j += 256)
+    tmap[j] = a.tok_map ? a.tok_map[(int64_t)(g % a.groups_per_clip) * a.N + j] : j;
+  __syncthreads();
+  const float* clip = a.qkv + (int64_t)(g / a.groups_per_clip) * a.clip_rows * rs;
+  auto row_ptr = [&](int j) -> const float* {   // j < N
+    const int r = tmap[j];
+    return r < 0 ? a.pad_row : clip + (int64_t)r * rs;
+  };
+
+  // Global loads are issued one phase ahead of their use (registers), so the chain of dependent memory latencies
+  // per workgroup is: window map -> q + K chunk 0 -> tables; everything else overlaps MFMA / softmax work.
+  constexpr int IT = KC * (DH / 4) / 256;   // float4 per thread per chunk
+  auto load_k = [&](int c0, float4* k) {     // thread -> (key r, channels c4*4..+3): coalesced 256-byte rows
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + 256 * it, r = e / (DH / 4), c4 = e - r * (DH / 4), j = c0 + r;
+      k[it] = (j < a.N) ? *reinterpret_cast<const float4*>(row_ptr(j) + a.D + h * DH + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_k = [&](const float4* k) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + 256 * it, r = e / (DH / 4), c4 = e - r * (DH / 4);
+      *reinterpret_cast<float4*>(Ks + r * QP + c4 * 4) = k[it];
+    }
+  };
+  auto load_v = [&](int c0, float4* v) {     // same coalesced mapping as K (a wave load touches 4 rows, not 64);
+#pragma unroll                                // the transposing LDS writes below pay a 4-way bank conflict instead
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + 256 * it, jj = e / (DH / 4), c4 = e - jj * (DH / 4), j = c0 + jj;
+      v[it] = (j < a.N) ? *reinterpret_cast<const float4*>(row_ptr(j) + 2 * a.D + h * DH + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_v = [&](const float4* v) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = tid + 256 * it, jj = e / (DH / 4), c4 = e - jj * (DH / 4);
+      Store<T>::store(Vt + (c4 * 4 + 0) * VP + jj, v[it].x);
+      Store<T>::store(Vt + (c4 * 4 + 1) * VP + jj, v[it].y);
+      Store<T>::store(Vt + (c4 * 4 + 2) * VP + jj, v[it].z);
+      Store<T>::store(Vt + (c4 * 4 + 3) * VP + jj, v[it].w);
+    }
+  };
+
+  // ---- q rows + K chunk 0 ---------------------------------------------------------------------------------------
+  float4 kr[IT];
+  {
+    float4 q[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + 256 * it, r = e / (DH / 4), c4 = e - r * (DH / 4), i = i0 + r;
+      q[it] = (i < a.N) ? *reinterpret_cast<const float4*>(row_ptr(i) + h * DH + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    load_k(0, kr);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + 256 * it, r = e / (DH / 4), c4 = e - r * (DH / 4);
+      *reinterpret_cast<float4*>(Qs + r * QP + c4 * 4) = q[it];
+    }
+    store_k(kr);
   }
   __syncthreads();
+  if (KC < a.N) load_k(KC, kr);   // K chunk 1 flies during the rel-pos dots and the first MFMA sweep
   if (rel) {
-    // 32 x (gh + gw) dots of the raw q rows with the table rows (utils.py:159-168), 8 threads per row
-    const int r = tid >> 3, sub = tid & 7, i = i0 + r;
-    if (i < a.N) {
-      const int yi = i / a.qw, xi = i - yi * a.qw;
-      const float* q = Qs + r * QP;
-      for (int e = sub; e < nrel; e += 8) {
-        const float* tab = (e < a.gh) ? a.rel_y + ((int64_t)yi * a.gh + e) * DH : a.rel_x + ((int64_t)xi * a.gw + (e - a.gh)) * DH;
-        float4 t[DH / 4];
+    // rel-pos terms of the 32 rows (utils.py:159-168), per TABLE ROW: (yi, ky) for the <= 32/qw + 2 query grid rows
+    // the tile touches, then (xi, kx) for every xi.  A 16-lane DPP row owns one 256-byte table row (one coalesced
+    // 16-byte load per lane, fetched once per workgroup) and dots it with the raw q rows that use it -- those with
+    // that yi / that xi -- reducing the 16 partial sums with row_shr DPP adds.
+    const int i_hi = min(i0 + AR, a.N) - 1;
+    const int y_lo = i0 / a.qw, ny = i_hi / a.qw - y_lo + 1;
+    const int items = ny * a.gh + a.qw * a.gw;
+    const int grp = tid >> 4, l16 = tid & 15;
+    constexpr int RB = 8;   // table rows in flight per 16-lane group
+    for (int w0 = grp; w0 < items; w0 += 16 * RB) {
+      float4 t[RB];
 #pragma unroll
-        for (int d = 0; d < DH / 4; ++d) t[d] = *reinterpret_cast<const float4*>(tab + d * 4);
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH / 4; d += 2) {
-          s0 += q[4 * d] * t[d].x + q[4 * d + 1] * t[d].y + q[4 * d + 2] * t[d].z + q[4 * d + 3] * t[d].w;
-          s1 += q[4 * d + 4] * t[d + 1].x + q[4 * d + 5] * t[d + 1].y + q[4 * d + 6] * t[d + 1].z + q[4 * d + 7] * t[d + 1].w;
+      for (int u = 0; u < RB; ++u) {
+        const int w = w0 + 16 * u;
+        t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w < items) {
+          const float* tab;
+          if (w < ny * a.gh) tab = a.rel_y + ((int64_t)y_lo * a.gh + w) * DH;        // (y_lo + w / gh, w % gh) is row y_lo*gh + w
+          else tab = a.rel_x + (int64_t)(w - ny * a.gh) * DH;
+          t[u] = *reinterpret_cast<const float4*>(tab + l16 * 4);
         }
-        relv[r * nrel + e] = s0 + s1;
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int w = w0 + 16 * u;
+        if (w >= items) break;   // uniform per 16-lane group (and the DPP row ops stay inside the group)
+        const bool isy = w < ny * a.gh;
+        int sel, e;
+        if (isy) { sel = y_lo + w / a.gh; e = w - (sel - y_lo) * a.gh; }
+        else { const int x = w - ny * a.gh; sel = x / a.gw; e = x - sel * a.gw + a.gh; }
+        int i = isy ? max(i0, sel * a.qw) : i0 + (sel - i0 % a.qw + a.qw) % a.qw;
+        const int i_end = isy ? min(i_hi, sel * a.qw + a.qw - 1) : i_hi;
+        const int step = isy ? 1 : a.qw;
+        for (; i <= i_end; i += 4 * step) {   // 4 independent q rows per pass: the LDS read -> FMA -> DPP chains overlap
+          float s[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int iv = min(i + v * step, i_end);
+            const float4 q = *reinterpret_cast<const float4*>(Qs + (iv - i0) * QP + l16 * 4);
+            s[v] = (q.x * t[u].x + q.y * t[u].y) + (q.z * t[u].z + q.w * t[u].w);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) s[v] = row16_sum_dpp(s[v]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (l16 == 15 && i + v * step <= i_end) relv[(i + v * step - i0) * nrel + e] = s[v];
+        }
       }
     }
-    __syncthreads();
   }
+  // ---- q MFMA fragments -> registers, scaled: q / self.scale (blocks.py:514); a power-of-two scale makes the
+  //      reciprocal multiply exact.  16x16x4 tiles: lane = (row l15 of a 16-row half, k group kg of 16 channels).
+  const int l15 = lane & 15, kg = lane >> 4;
+  float4 qf[2][4];
   {
-    // q / self.scale (blocks.py:514); a power-of-two scale makes the reciprocal multiply exact
     const float inv = 1.0f / a.scale;
     const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
-    for (int e = tid; e < AR * DH; e += 256) {
-      float* p = Qs + (e >> 6) * QP + (e & 63);
-      *p = pow2 ? *p * inv : *p / a.scale;
-    }
-  }
-
-  // ---- S = q k^T: 128-key chunks, wave w owns key tile w of the chunk --------------------------------------------
-  for (int c0 = 0; c0 < a.N; c0 += KC) {
-    for (int e = tid; e < KC * (DH / 4); e += 256) {
-      const int r = e / (DH / 4), c4 = e - r * (DH / 4), j = c0 + r;
-      float4 k = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < a.N)
-        k = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, j, a.N) +
-                                             a.D + h * DH + c4 * 4);
-      *reinterpret_cast<float4*>(Ks + r * QP + c4 * 4) = k;
-    }
-    __syncthreads();
-    const int n0 = c0 + wave * 32;
-    if (n0 < a.N) {  // wave-uniform
-      f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* qa = Qs + lr * QP + lh * (DH / 2);
-      const float* kb = Ks + (wave * 32 + lr) * QP + lh * (DH / 2);
+    for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
-      for (int q = 0; q < DH / 2; q += 4) {
-        const float4 fa = *reinterpret_cast<const float4*>(qa + q);
-        const float4 fb = *reinterpret_cast<const float4*>(kb + q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+      for (int m = 0; m < 4; ++m) {
+        float4 q = *reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QP + kg * 16 + 4 * m);
+        if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
+        else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
+        qf[hr][m] = q;
       }
-      const int j = n0 + lr;
-      if (j < a.N) {
+  }
+  __syncthreads();   // rel-pos dots and fragment reads are done: the q tile's storage becomes the score tile
+
+  // ---- S = q k^T: 64-key chunks, wave w owns keys 16w .. 16w+15 of the chunk for all 32 rows -------------------------
+  float4 vr[IT];
+  for (int c0 = 0; c0 < a.N; c0 += KC) {
+    if (c0 > 0) {
+      store_k(kr);
+      __syncthreads();
+    }
+    if (c0 + KC < a.N) { if (c0 > 0) load_k(c0 + KC, kr); }   // chunk 1 was issued above
+    else load_v(0, vr);                                        // last K chunk: V chunk 0 flies from here through the softmax
+    const int n0 = c0 + wave * 16;
+    if (n0 < a.N) {  // wave-uniform
+      f32x4_acc acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const float* kb = Ks + (wave * 16 + l15) * QP + kg * 16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          Ss[row * SP + j] = acc[r];
-          if (a.product != nullptr && i0 + row < a.N)
-            a.product[((int64_t)gh_ * a.N + i0 + row) * a.N + j] = acc[r];
+      for (int m = 0; m < 4; ++m) {
+        const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, acc[hr], 0, 0, 0);
         }
       }
+      const int j = n0 + l15;
+      if (j < a.N) {
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = hr * 16 + 4 * kg + r;
+            Ss[row * SP + j] = acc[hr][r];
+            if (a.product != nullptr && i0 + row < a.N)
+              a.product[((int64_t)gh_ * a.N + i0 + row) * a.N + j] = acc[hr][r];
+          }
+      }
     }
     __syncthreads();
   }
+  store_v(vr);   // the K region is free: V^T chunk 0 lands while the softmax runs (next barrier publishes both)
 
   // ---- softmax: wave w owns rows 8w .. 8w+7; P overwrites the row's scores in place (as T) ------------------------
   {
     const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
     const int npad = (a.N + 15) & ~15;
     T* ast = reinterpret_cast<T*>(a.a_state);
-#pragma unroll 1
+#pragma unroll 2
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
       const float* rv = relv + r * nrel;
@@ -200,14 +299,14 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
         }
         mx = fmaxf(mx, x[u]);
       }
-      mx = wave_max(mx);
+      mx = wave_max_dpp(mx);
       float sum = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         x[u] = (lane + 64 * u < a.N) ? expf(x[u] - mx) : 0.f;
         sum += x[u];
       }
-      sum = wave_sum(sum);
+      sum = wave_sum_dpp(sum);
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();   // every lane has read the fp32 row before anyone overwrites it with T
 #pragma unroll
@@ -223,30 +322,23 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
   }
   __syncthreads();
 
-  // ---- P . V: V^T chunks of 128 keys in the K region; wave = (dh half, 64-key half of the chunk) --------------------
+  // ---- P . V: V^T chunks of 64 keys in the K region; wave = (dh half, 32-key half of the chunk) ----------------------
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int dt = wave & 1, kh = wave >> 1;
   const int npad = (a.N + 15) & ~15;
   for (int c0 = 0; c0 < a.N; c0 += KC) {
-    for (int e = tid; e < KC * (DH / 4); e += 256) {
-      const int c4 = e / KC, jj = e - c4 * KC, j = c0 + jj;   // consecutive threads -> consecutive keys: conflict-free writes
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < a.N)
-        v = *reinterpret_cast<const float4*>(evt_token_row(a.qkv, rs, a.tok_map, a.groups_per_clip, a.clip_rows, a.pad_row, g, j, a.N) +
-                                             2 * a.D + h * DH + c4 * 4);
-      Store<T>::store(Vt + (c4 * 4 + 0) * VP + jj, v.x);
-      Store<T>::store(Vt + (c4 * 4 + 1) * VP + jj, v.y);
-      Store<T>::store(Vt + (c4 * 4 + 2) * VP + jj, v.z);
-      Store<T>::store(Vt + (c4 * 4 + 3) * VP + jj, v.w);
+    if (c0 > 0) {
+      store_v(vr);
+      __syncthreads();
     }
-    __syncthreads();
-    const int k0 = c0 + kh * 64;
+    if (c0 + KC < a.N) load_v(c0 + KC, vr);
+    const int k0 = c0 + kh * (KC / 2);
     int len = npad - k0;
-    len = len > 64 ? 64 : len;
+    len = len > KC / 2 ? KC / 2 : len;
     if (len > 0)
-      acc = PvSweep<T>::run(Ps + lr * SP * TPF + k0, Vt + (dt * 32 + lr) * VP + kh * 64, len, lh, acc);
+      acc = PvSweep<T>::run(Ps + lr * SP * TPF + k0, Vt + (dt * 32 + lr) * VP + kh * (KC / 2), len, lh, acc);
     __syncthreads();
   }
 
@@ -274,12 +366,9 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
       Store<T>::store(p, v.x); Store<T>::store(p + 1, v.y); Store<T>::store(p + 2, v.z); Store<T>::store(p + 3, v.w);
     }
     if (a.out_f32 != nullptr) {
-      int64_t orow = (int64_t)g * a.N + i;
-      if (a.tok_map != nullptr) {
-        const int tr = a.tok_map[(int64_t)(g % a.groups_per_clip) * a.N + i];
-        if (tr < 0) continue;  // padding token: dropped on un-windowing (blocks.py:346-376)
-        orow = (int64_t)(g / a.groups_per_clip) * a.clip_rows + tr;
-      }
+      const int tr = tmap[i];
+      if (tr < 0) continue;  // padding token: dropped on un-windowing (blocks.py:346-376)
+      const int64_t orow = (int64_t)(g / a.groups_per_clip) * a.clip_rows + tr;
       *reinterpret_cast<float4*>(a.out_f32 + orow * a.D + h * DH + c4 * 4) = v;
     }
   }
@@ -287,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
 
 template <typename T>
 int launch_dense(const DenseArgs& a, void* stream) {
-  const size_t lds = ((size_t)AR * QP + (size_t)KC * QP + (size_t)AR * dense_sp(a.N) + (size_t)AR * (a.gh + a.gw)) * sizeof(float);
+  const size_t lds = ((size_t)KC * QP + (size_t)dense_tile_floats(a.N) + (size_t)AR * (a.gh + a.gw) + a.N) * sizeof(float);
   const dim3 grid((a.N + AR - 1) / AR, a.G * a.H);
   if (grid.y == 0) return EVT_OK;
   if (lds > 64 * 1024)

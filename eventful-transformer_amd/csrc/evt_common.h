@@ -40,6 +40,37 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// DPP reductions (no LDS traffic, unlike ds_bpermute-based __shfl_xor): row_shr 1/2/4/8 leave the total of each
+// 16-lane row in its lane 15; row_bcast15 / row_bcast31 fold the four rows into lane 63.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float evt_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// total of each 16-lane row, valid in the row's lane 15
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+  v += evt_dpp<0x111, 0xf, 0xf>(0.f, v);
+  v += evt_dpp<0x112, 0xf, 0xf>(0.f, v);
+  v += evt_dpp<0x114, 0xf, 0xe>(0.f, v);
+  v += evt_dpp<0x118, 0xf, 0xc>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum_dpp(v);
+  v += evt_dpp<0x142, 0xa, 0xf>(0.f, v);
+  v += evt_dpp<0x143, 0xc, 0xf>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, evt_dpp<0x111, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, evt_dpp<0x112, 0xf, 0xf>(ninf, v));
+  v = fmaxf(v, evt_dpp<0x114, 0xf, 0xe>(ninf, v));
+  v = fmaxf(v, evt_dpp<0x118, 0xf, 0xc>(ninf, v));
+  v = fmaxf(v, evt_dpp<0x142, 0xa, 0xf>(ninf, v));
+  v = fmaxf(v, evt_dpp<0x143, 0xc, 0xf>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // j -> (j / gw, j % gw) without an integer division: (j + 0.5) / gw is at least 0.5/gw away from every
 // integer, far more than fp32 rounding for j < 2^20, gw <= 4096, so truncation is exact.
 __device__ __forceinline__ int fast_div(int j, float inv_gw) { return (int)(((float)j + 0.5f) * inv_gw); }
