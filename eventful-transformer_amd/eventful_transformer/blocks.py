@@ -452,10 +452,33 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
             self.relative_position.count_fused(B, H)
         return acc.product, kv, Nk, idx_k, count_k, cap_k
 
+    def _first_frame_fused(self, qkv, B, N, attn, a_state=None, pv=None):
+        """First frame of a clip through K8: q.k^T state, probabilities, A.v state and the block's attention output
+        from ONE launch (MatmulBuffer.forward_first, modules.py:224-230, + blocks.py:518-522 + modules.py:277-283).
+        Returns False when K8 does not cover the shape (pooled keys, > 256 tokens, head dim != 64)."""
+        D, H = self.dim, self.heads
+        acc = self.matmul_accumulator_1
+        if not (acc.first and self.pool_size is None and _native.DENSE_FUSED and _native.attention_dense_fits(N, D, H)):
+            return False
+        acc.first = False
+        acc.product = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+        ry, rx, gh, gw, qw = self._rel_tables()
+        _native.attention_dense(qkv, B, H, N, D, self.scale, _native.store_code(self._store_dtype()), out_f32=attn,
+                                rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw, product=acc.product, a_state=a_state, pv=pv)
+        acc.matmul.count_product(B * H * N * N, D // H)
+        if self.relative_position is not None:
+            self.relative_position.count_fused(B, H)
+        return True
+
     def _forward_attention(self, qkv, idx, count, cap, B, N):
         D, H = self.dim, self.heads
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
+        if idx is None:
+            attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+            if self._first_frame_fused(qkv, B, N, attn):
+                self.matmul.count_product(B * H * N * (D // H), N)
+                return attn
         product, kv, Nk, _, _, _ = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         a_s = self._ws("attn_probs", (B, H, N, Nk), sdt, qkv)
@@ -482,11 +505,23 @@ class EventfulBlock(EventfulMatmul1Block):
         dh = D // H
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
+        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+        vg, ag, acc = self.v_gate, self.matmul_gate, self.matmul_accumulator_2
+        if acc.first and idx is None and self.matmul_accumulator_1.first:
+            a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
+            pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            if self._first_frame_fused(qkv, B, N, attn, a_state=a_state, pv=pv):
+                vg.first = ag.first = acc.first = False
+                ag.p, acc._state = a_state, pv
+                vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+                vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+                acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+                self._v_full(qkv, None, B, N, N, vg._state, store)
+                acc.matmul.count_product(B * H * N * dh, N)
+                return attn
         product, kv, Nk, idx_k, count_k, cap_k = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         rel = dict(qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
-        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
-        vg, ag, acc = self.v_gate, self.matmul_gate, self.matmul_accumulator_2
         # value source for K6a: packed buffer, or the value half of the pooled buffer
         vsrc, vkw = (qkv, {}) if kv is None else (kv, dict(v_offset=D, v_rs=2 * D))
         if acc.first:
