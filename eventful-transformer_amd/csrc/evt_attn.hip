@@ -294,7 +294,17 @@ __global__ __launch_bounds__(256) void v_gate_kernel(const float* __restrict__ v
   const int g = (int)(r / rows), ii = (int)(r - (int64_t)g * rows);
   int tok = ii;
   if (gated) {
-    if (count != nullptr && ii >= count[g]) return;
+    if (count != nullptr && ii >= count[g]) {
+      if (transposed) {  // columns past count of the k-contiguous operands are defined (zero): the fused kernel
+#pragma unroll           // stages whole 64-column chunks
+        for (int q = 0; q < 4; ++q) {
+          const int64_t o = ((int64_t)g * D + c4 * 4 + q) * kcap + ii;
+          Store<T>::store(v_delta + o, 0.f);
+          Store<T>::store(v_old + o, 0.f);
+        }
+      }
+      return;
+    }
     tok = idx[(int64_t)g * kcap + ii];
   }
   const float* row = evt_token_row(vsrc, v_rs, tok_map, groups_per_clip, clip_rows, pad_row, g, tok, N);

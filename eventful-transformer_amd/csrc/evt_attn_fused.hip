@@ -112,6 +112,53 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.Nk;
   const int32_t* ix = a.idx + (int64_t)b * a.kcap;
 
+  // Everything the chunk loop and the epilogue read from HBM that does not depend on the softmax is requested up
+  // front (registers), so one workgroup waits for ~2 dependent round trips instead of one per phase: the index list
+  // first (tiny), then -- behind the row loads of phase 1 -- the old a~ values of the first PF chunks, the first
+  // dv~ / v_old chunk and the A.v state rows of the epilogue.
+  constexpr int PF = (NREG > 0) ? 2 : 0;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int VIT = 64 * TPW * (FKC / VEC) / 256;   // 16-byte V pieces per thread per chunk
+  int jpf[PF > 0 ? PF : 1];
+  float oldpf[PF > 0 ? PF : 1][8];
+#pragma unroll
+  for (int c = 0; c < PF; ++c) {   // PF > 0 is only launched with kcap > 0: ix[0] is readable
+    const int kk = c * FKC + lane;
+    const int j = ix[kk < cnt ? kk : 0];
+    jpf[c] = (kk < cnt) ? j : -1;
+  }
+  const T* Vg_d = reinterpret_cast<const T*>(a.v_delta_t) + (int64_t)bh * a.dh * a.kcap;
+  const T* Vg_o = reinterpret_cast<const T*>(a.v_old_t) + (int64_t)bh * a.dh * a.kcap;
+  const bool vvec = a.kcap > 0 && (a.kcap % VEC) == 0;
+  uint4 vpd[VIT], vpo[VIT];
+  auto load_v = [&](int k0) __attribute__((always_inline)) {
+    // chunk k0 of dv~^T / v_old^T (k contiguous) -> registers.  Columns in [count, kcap) hold zeros (evt_v_gate
+    // writes them) and meet a~ = da~ = 0 anyway; pieces past kcap are zeroed here.  Branch-free (clamped address +
+    // select) so that the loads stay where they are issued instead of being sunk next to their use.
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
+      const bool in = kk < a.kcap;   // kcap % VEC == 0: a piece is wholly in or out
+      const int64_t o = (int64_t)d * a.kcap + (in ? kk : 0);
+      const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+      vpd[it] = in ? xd : make_uint4(0, 0, 0, 0);
+      vpo[it] = in ? xo : make_uint4(0, 0, 0, 0);
+    }
+  };
+  T* pv = reinterpret_cast<T*>(a.pv);
+  constexpr int PIT = FR * (64 * TPW / 8) / 256;      // 8-channel state pieces per thread (epilogue)
+  union Pv8 { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; };
+  Pv8 pvr[PIT];
+  auto load_pv = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int e = tid + 256 * it, row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8, i = i0 + row;
+      const int64_t o = ((int64_t)b * a.N + (i < a.N ? i : a.N - 1)) * a.D + h * a.dh + c8;   // clamped: branch-free
+#pragma unroll
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) pvr[it].u[q] = reinterpret_cast<const uint4*>(pv + o)[q];
+    }
+  };
+
   // ---- phase 1: per-row softmax statistics; wave w owns rows w*8 .. w*8+7 -----------------------
   float rmax[8], rsum[8];
   if (rel) {
@@ -155,16 +202,34 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
       const float* prow = prod + (int64_t)(i < a.N ? i : 0) * a.Nk;
-      const float* rv = relv + r * nrel;
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
+        // branch-free: a clamped address keeps all 8*NREG loads of the wave in flight together (a predicated load
+        // inside `if (j < Nk)` compiles to load + s_waitcnt vmcnt(0) per element)
         const int j = lane + 64 * u;
-        float x = -INFINITY;
-        if (j < a.Nk) {
-          x = prow[j];
-          if (rel) { const int ky = fast_div(j, inv_gw); x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
+        const float x = prow[j < a.Nk ? j : a.Nk - 1];
+        xv[rr][u] = (j < a.Nk) ? x : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int i = i0 + wave * 8 + rr;
+        oldpf[c][rr] = Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + (jpf[c] >= 0 ? jpf[c] : 0));   // branch-free
+      }
+    if (vvec) load_v(0);
+    load_pv();
+    asm volatile("" ::: "memory");   // scheduling fence: the requests above are issued before the statistics below
+    if (rel) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const float* rv = relv + (wave * 8 + rr) * nrel;
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+          const int j = lane + 64 * u;
+          if (j < a.Nk) { const int ky = fast_div(j, inv_gw); xv[rr][u] = (xv[rr][u] + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
         }
-        xv[rr][u] = x;
       }
     }
 #pragma unroll
@@ -172,7 +237,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       float mx = xv[rr][0];
 #pragma unroll
       for (int u = 1; u < NREG; ++u) mx = fmaxf(mx, xv[rr][u]);
-      rmax[rr] = wave_max(mx);
+      rmax[rr] = wave_max_dpp(mx);
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -183,13 +248,15 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
         if (lane + 64 * u < a.Nk) et[(wave * 8 + rr) * EP + lane + 64 * u] = e;
         sum += e;
       }
-      rsum[rr] = wave_sum(sum);
+      rsum[rr] = wave_sum_dpp(sum);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();  // each wave only ever reads back its own 8 rows
   } else {
     // any N: ONE pass over the row with an online (running max / rescaled sum) softmax, 8 independent
     // 256-byte wave loads in flight per step so the cold HBM stream is not latency-serialised.
+    if (vvec) load_v(0);
+    load_pv();
 #pragma unroll 1
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
@@ -255,10 +322,10 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
         mx = nm;
       }
       // combine the 64 per-lane (max, sum) pairs
-      const float wmx = wave_max(mx);
+      const float wmx = wave_max_dpp(mx);
       sum = (mx == -INFINITY) ? 0.f : sum * fast_exp(mx - wmx);
       rmax[rr] = wmx;
-      rsum[rr] = wave_sum(sum);
+      rsum[rr] = wave_sum_dpp(sum);
     }
   }
 
@@ -270,65 +337,53 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   const int prodsel = wave >> 1;  // 0: a~ . dv~   1: da~ . v_old
   const int half = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  const T* Vg_d = reinterpret_cast<const T*>(a.v_delta_t) + (int64_t)bh * a.dh * a.kcap;
-  const T* Vg_o = reinterpret_cast<const T*>(a.v_old_t) + (int64_t)bh * a.dh * a.kcap;
 
-  for (int k0 = 0; k0 < cnt; k0 += FKC) {
-    // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
-    constexpr int NU = FKC / 64;
-    int jc[NU];
+  static_assert(FKC == 64, "one selected column per lane and chunk");
+  // softmax normaliser as a reciprocal, one IEEE division per row instead of one per gathered element: e * (1/sum)
+  // is within 1 ulp of e / sum before the rounding to the store type
+  float rinv[8];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int kk = k0 + lane + 64 * u;
-      jc[u] = (kk < cnt) ? ix[kk] : -1;
+  for (int rr = 0; rr < 8; ++rr) rinv[rr] = 1.0f / rsum[rr];
+  // One chunk of 64 selected columns.  jcol: this lane's column (-1 past count); oldp: the 8 old a~ values of the
+  // lane's column if they were requested ahead, else nullptr (loaded here, all 8 in flight, clamped addresses).
+  auto do_chunk = [&](int k0, int jcol, const float* oldp) __attribute__((always_inline)) {
+    // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
+    const int js = jcol >= 0 ? jcol : 0;
+    float oldv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int i = i0 + wave * 8 + rr;
+      oldv[rr] = oldp ? oldp[rr] : Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + js);
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
-      const bool live = i < a.N;
-      const float* prow = prod + (int64_t)i * a.Nk;
-      const float* rv = relv + r * nrel;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int jj = lane + 64 * u, j = jc[u];
-        float an = 0.f, ad = 0.f;
-        if (live && j >= 0) {
-          float e;
-          if (NREG > 0) {
-            e = et[r * EP + j];
-          } else {
-            float x = prow[j];
-            if (rel) { const int ky = fast_div(j, inv_gw); x = (x + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
-            e = fast_exp(x - rmax[rr]);
-          }
-          an = Store<T>::round(e / rsum[rr]);
-          const float old = Store<T>::load(st + (int64_t)i * a.Nk + j);
-          ad = Store<T>::round(an - old);
-          Store<T>::store(st + (int64_t)i * a.Nk + j, an);
-        }
-        Store<T>::store(An + r * P + jj, an);
-        Store<T>::store(Ad + r * P + jj, ad);
+      const bool ok = i < a.N && jcol >= 0;
+      float e;
+      if (NREG > 0) {
+        e = et[r * EP + js];
+      } else {
+        float x = prod[(int64_t)(i < a.N ? i : 0) * a.Nk + js];
+        if (rel) { const float* rv = relv + r * nrel; const int ky = fast_div(js, inv_gw); x = (x + rv[ky]) + rv[a.gh + js - ky * a.gw]; }
+        e = fast_exp(x - rmax[rr]);
       }
+      float an = Store<T>::round(e * rinv[rr]);
+      float ad = Store<T>::round(an - oldv[rr]);
+      if (ok) Store<T>::store(st + (int64_t)i * a.Nk + jcol, an);
+      an = ok ? an : 0.f;
+      ad = ok ? ad : 0.f;
+      Store<T>::store(An + r * P + lane, an);
+      Store<T>::store(Ad + r * P + lane, ad);
     }
-    // ---- phase 2b: stage the chunk of dv~^T and v_old^T (k contiguous), zero beyond count -------
-    constexpr int VEC = 16 / (int)sizeof(T);
-    if ((a.kcap % VEC) == 0) {
-      for (int e = tid; e < a.dh * (FKC / VEC); e += 256) {
-        const int d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
-        union { uint4 u; T t[VEC]; } xd, xo;
-        xd.u = make_uint4(0, 0, 0, 0); xo.u = xd.u;
-        if (kk < cnt) {  // kk + VEC <= kcap because kcap % VEC == 0
-          xd.u = *reinterpret_cast<const uint4*>(Vg_d + (int64_t)d * a.kcap + kk);
-          xo.u = *reinterpret_cast<const uint4*>(Vg_o + (int64_t)d * a.kcap + kk);
-          if (kk + VEC > cnt) {
+    // ---- phase 2b: stage the chunk of dv~^T and v_old^T (k contiguous; requested one chunk ahead) ----
+    if (vvec) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q)
-              if (kk + q >= cnt) { Store<T>::store(&xd.t[q], 0.f); Store<T>::store(&xo.t[q], 0.f); }
-          }
-        }
-        *reinterpret_cast<uint4*>(Vd + d * P + jj) = xd.u;
-        *reinterpret_cast<uint4*>(Vo + d * P + jj) = xo.u;
+      for (int it = 0; it < VIT; ++it) {
+        const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC;
+        *reinterpret_cast<uint4*>(Vd + d * P + jj) = vpd[it];
+        *reinterpret_cast<uint4*>(Vo + d * P + jj) = vpo[it];
       }
+      if (k0 + FKC < cnt) load_v(k0 + FKC);   // flies during the MFMA sweep of this chunk
     } else {
       for (int e = tid; e < a.dh * FKC; e += 256) {
         const int d = e / FKC, jj = e - d * FKC, kk = k0 + jj;
@@ -349,6 +404,15 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     for (int t = 0; t < TPW; ++t)
       acc[t] = Tile<T>::sweep(At, Vt + ((half + 2 * t) * 32 + lr) * P, lh, acc[t]);
     __syncthreads();
+  };
+  if (PF > 0) {
+    if (cnt > 0) do_chunk(0, jpf[0], oldpf[0]);
+    if (cnt > FKC) do_chunk(FKC, jpf[PF > 1 ? 1 : 0], oldpf[PF > 1 ? 1 : 0]);
+  }
+  for (int k0 = PF * FKC; k0 < cnt; k0 += FKC) {
+    const int kk = k0 + lane;
+    const int j = ix[kk < cnt ? kk : 0];
+    do_chunk(k0, kk < cnt ? j : -1, nullptr);
   }
 
   // ---- phase 4: state += round(acc1); state += round(acc2); heads merged on write ---------------
@@ -365,16 +429,14 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       }
   }
   __syncthreads();
-  T* pv = reinterpret_cast<T*>(a.pv);
-  for (int e = tid; e < FR * (a.dh / 8); e += 256) {
-    const int row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8;
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int e = tid + 256 * it, row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8;
     const int i = i0 + row;
     if (i >= a.N) continue;
     const int64_t o = ((int64_t)b * a.N + i) * a.D + h * a.dh + c8;
-    union { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; } st8;
+    Pv8 st8 = pvr[it];
     union { float4 v[2]; float f[8]; } o8;
-#pragma unroll
-    for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) st8.u[q] = reinterpret_cast<const uint4*>(pv + o)[q];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[row * a.dh + c8 + q]);  // += a~ . dv~
@@ -408,10 +470,10 @@ int launch_fused(const FusedArgs& a, void* stream) {
   if (grid.y == 0) return EVT_OK;
   hipStream_t s = evt_stream(stream);
   if (a.dh == 64) {
-    if (nreg <= 4) launch_fused_inst<T, 1, 4>(a, grid, lds, s);
+    if (nreg <= 4 && a.kcap > 0) launch_fused_inst<T, 1, 4>(a, grid, lds, s);
     else launch_fused_inst<T, 1, 0>(a, grid, lds, s);
   } else {
-    if (nreg <= 4) launch_fused_inst<T, 2, 4>(a, grid, lds, s);
+    if (nreg <= 4 && a.kcap > 0) launch_fused_inst<T, 2, 4>(a, grid, lds, s);
     else launch_fused_inst<T, 2, 0>(a, grid, lds, s);
   }
   return evt_check_launch("evt_softmax_av_gated");

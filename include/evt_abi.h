@@ -249,7 +249,8 @@ EVT_API int evt_softmax_gate(const evt_softmax_desc* d, void* stream);
  *   v points at the value slice of token 0 (qkv + 2D of the packed buffer, or kv + D of the pooled
  *   buffer of evt_pool_kv), rows v_rs elements apart; pad_row likewise points at its value slice.  v_state: (B,N,D); v_delta, v_old: (B,kcap,D) with heads
  *   side by side (h*dh + d), or, with `transposed`, (B,H,dh,kcap) = (B,D,kcap) with k contiguous
- *   (the operand layout of evt_softmax_av_gated); all in `store` type.
+ *   (the operand layout of evt_softmax_av_gated; columns [count, kcap) are written as zeros); all
+ *   in `store` type.
  * ------------------------------------------------------------------------------------------ */
 EVT_API int evt_v_gate(const float* v, int64_t v_rs, const int32_t* idx, const int32_t* count, int B, int N,
                int D, int kcap, void* v_state, void* v_delta, void* v_old, int store, int gated,
