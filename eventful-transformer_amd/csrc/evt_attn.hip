@@ -29,6 +29,7 @@ struct QkArgs {
   int G, H, Nq, Nk, dh;
   float scale;
   int delta;  // 0: full; 1: rows+cols delta (blockIdx.z selects the part)
+  int split;  // 1: bf16 hi/lo split-precision MFMA
 };
 
 __device__ __forceinline__ const float* qk_row(const float* base, int64_t bs, int64_t rs, const int32_t* tok_map,
@@ -43,9 +44,31 @@ constexpr int QT = 128;   // output tile edge
 constexpr int QKC = 32;   // head-dim chunk staged per pass (LDS 2 x 128 x 36 floats = 36 KB -> 4 workgroups / CU)
 constexpr int QLD = QKC + 4;
 
+typedef __bf16 qk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 qk_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float qk_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int QSP = QKC + 8;  // bf16 pitch of the split planes (80 bytes: conflict-free 16-byte reads)
+
+// x = hi + lo, hi = rne_bf16(x), lo = rne_bf16(x - hi): the split-precision operands of evt_linear.hip
+__device__ __forceinline__ void qk_split4(const float4 v, qk_bf16x4* hi, qk_bf16x4* lo) {
+  const qk_f32x4 x = {v.x, v.y, v.z, v.w};
+  const qk_bf16x4 hh = __builtin_convertvector(x, qk_bf16x4);
+  *hi = hh;
+  *lo = __builtin_convertvector(x - __builtin_convertvector(hh, qk_f32x4), qk_bf16x4);
+}
+
+// SPLIT = false: fp32-input MFMA (exact fp32 products).  SPLIT = true: q and k are split into bf16 hi/lo planes while
+// they are staged and (q/scale).k = lo.hi + hi.lo + hi.hi runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (~1e-5 relative, K = head dim only; 5x less matrix-pipe time than the 32x32x2 fp32 MFMA that bounds this kernel).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[QT * QLD];
-  __shared__ __attribute__((aligned(16))) float Bs[QT * QLD];
+  __shared__ __attribute__((aligned(16))) float lds_raw[SPLIT ? (4 * QT * QSP) / 2 : 2 * QT * QLD];
+  float* As = lds_raw;
+  float* Bs = lds_raw + QT * QLD;
+  __bf16* Ahi = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Alo = Ahi + QT * QSP;
+  __bf16* Bhi = Alo + QT * QSP;
+  __bf16* Blo = Bhi + QT * QSP;
   __shared__ int rmap[QT];
   __shared__ int cmap[QT];
 
@@ -67,20 +90,48 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
   }
   if (m0 >= m_lim || n0 >= n_lim) return;
 
-  // staging assignment: thread -> rows r0 + 32 j (j = 0..3), one float4 at column c4 * 4 of the chunk
+  // staging assignment: thread -> rows r0 + 32 j (j = 0..3), one float4 at column c4 * 4 of the chunk.
+  // Index lists and the window map are read with clamped addresses inside UNIFORM branches, so the 4 loads of a
+  // list are in flight together (a per-element `cond ? list[m] : -1` compiles to load + s_waitcnt vmcnt(0) each:
+  // ~20 serialised round trips before the first MFMA).
   const int r0 = tid >> 3, c4 = tid & 7;
+  const int32_t* msrc = (part == 1) ? a.idx_q + (int64_t)b * a.kcap_q
+                      : (part == 2 && a.idx_q_rest) ? a.idx_q_rest + (int64_t)b * a.Nq : nullptr;
+  const int32_t* nsrc = (part == 2) ? a.idx_k + (int64_t)b * a.kcap_k : nullptr;
+  int tmv[4], tnv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 32 * j, n = n0 + r0 + 32 * j;
+    tmv[j] = m < m_lim ? m : m_lim - 1;   // m0 < m_lim, n0 < n_lim: the clamps are valid positions
+    tnv[j] = n < n_lim ? n : n_lim - 1;
+  }
+  if (msrc != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tmv[j] = msrc[tmv[j]];
+  }
+  if (nsrc != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tnv[j] = nsrc[tnv[j]];
+  }
+  int rqv[4], rkv[4];   // clip rows (window map applied), -1 = padding vector
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { rqv[j] = tmv[j]; rkv[j] = tnv[j]; }
+  if (a.tok_map != nullptr) {
+    const int32_t* wmap_q = a.tok_map + (int64_t)(g % a.groups_per_clip) * a.Nq;
+    const int32_t* wmap_k = a.tok_map + (int64_t)(g % a.groups_per_clip) * a.Nk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rqv[j] = wmap_q[tmv[j]]; rkv[j] = wmap_k[tnv[j]]; }
+  }
+  const int64_t clip = a.tok_map ? (int64_t)(g / a.groups_per_clip) : (int64_t)g;
   const float* qp[4];
   const float* kp[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = r0 + 32 * j;
-    const int m = m0 + r, n = n0 + r;
-    const int tm = (m < m_lim) ? ((part == 1) ? a.idx_q[(int64_t)b * a.kcap_q + m]
-                                              : (part == 2 && a.idx_q_rest) ? a.idx_q_rest[(int64_t)b * a.Nq + m] : m) : -1;
-    const int tn = (n < n_lim) ? ((part == 2) ? a.idx_k[(int64_t)b * a.kcap_k + n] : n) : -1;
-    if (c4 == 0) { rmap[r] = tm; cmap[r] = tn; }
-    qp[j] = (tm >= 0) ? qk_row(a.q, a.q_bs, a.q_rs, a.tok_map, a.groups_per_clip, a.pad_q, g, tm, a.Nq) + h * a.q_hs : nullptr;
-    kp[j] = (tn >= 0) ? qk_row(a.k, a.k_bs, a.k_rs, a.tok_map, a.groups_per_clip, a.pad_k, g, tn, a.Nk) + h * a.k_hs : nullptr;
+    const bool mv = (m0 + r) < m_lim, nv = (n0 + r) < n_lim;
+    if (c4 == 0) { rmap[r] = mv ? tmv[j] : -1; cmap[r] = nv ? tnv[j] : -1; }
+    qp[j] = !mv ? nullptr : (rqv[j] < 0 ? a.pad_q : a.q + clip * a.q_bs + (int64_t)rqv[j] * a.q_rs) + h * a.q_hs;
+    kp[j] = !nv ? nullptr : (rkv[j] < 0 ? a.pad_k : a.k + clip * a.k_bs + (int64_t)rkv[j] * a.k_rs) + h * a.k_hs;
   }
   // q / self.scale (blocks.py:514): a power-of-two scale (dh = 16, 64, 256) makes x * (1/scale) exact
   const float inv = 1.0f / a.scale;
@@ -120,11 +171,46 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
       float4 qa = rq[j];
       if (pow2) { qa.x *= inv; qa.y *= inv; qa.z *= inv; qa.w *= inv; }
       else { qa.x /= a.scale; qa.y /= a.scale; qa.z /= a.scale; qa.w /= a.scale; }
-      *reinterpret_cast<float4*>(As + (r0 + 32 * j) * QLD + c4 * 4) = qa;
-      *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * QLD + c4 * 4) = rk[j];
+      if (SPLIT) {
+        qk_bf16x4 hq, lq, hk, lk;
+        qk_split4(qa, &hq, &lq);
+        qk_split4(rk[j], &hk, &lk);
+        const int o = (r0 + 32 * j) * QSP + c4 * 4;
+        *reinterpret_cast<qk_bf16x4*>(Ahi + o) = hq;
+        *reinterpret_cast<qk_bf16x4*>(Alo + o) = lq;
+        *reinterpret_cast<qk_bf16x4*>(Bhi + o) = hk;
+        *reinterpret_cast<qk_bf16x4*>(Blo + o) = lk;
+      } else {
+        *reinterpret_cast<float4*>(As + (r0 + 32 * j) * QLD + c4 * 4) = qa;
+        *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * QLD + c4 * 4) = rk[j];
+      }
     }
     __syncthreads();
     if (d0 + QKC < a.dh) fetch(d0 + QKC);
+    if (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < QKC; ks += 16) {
+        qk_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ao = (wm * 64 + i * 32 + lr) * QSP + ks + 8 * lh;
+          const int bo = (wn * 64 + i * 32 + lr) * QSP + ks + 8 * lh;
+          ah[i] = *reinterpret_cast<const qk_bf16x8*>(Ahi + ao);
+          al[i] = *reinterpret_cast<const qk_bf16x8*>(Alo + ao);
+          bh[i] = *reinterpret_cast<const qk_bf16x8*>(Bhi + bo);
+          bl[i] = *reinterpret_cast<const qk_bf16x8*>(Blo + bo);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (!(live_m[i] && live_n[j])) continue;  // wave-uniform
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
     // lane half lh covers k in [16 lh, 16 lh + 16) of the chunk (k order is free inside a sum)
 #pragma unroll
     for (int q = 0; q < QKC / 2; q += 4) {
@@ -144,6 +230,7 @@ __global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
+    }
     }
     __syncthreads();
   }
@@ -176,7 +263,8 @@ int launch_qk(const QkArgs& a, void* stream) {
     grid = dim3(ntk, ntq, a.G * a.H);
   }
   if (grid.x == 0 || grid.y == 0 || grid.z == 0) return EVT_OK;
-  hipLaunchKernelGGL(qk_kernel, grid, dim3(256), 0, evt_stream(stream), a);
+  if (a.split) hipLaunchKernelGGL(qk_kernel<true>, grid, dim3(256), 0, evt_stream(stream), a);
+  else hipLaunchKernelGGL(qk_kernel<false>, grid, dim3(256), 0, evt_stream(stream), a);
   return evt_check_launch("evt_qk");
 }
 
@@ -590,7 +678,7 @@ extern "C" int evt_qk(const evt_qk_desc* d, void* stream) {
   QkArgs a{d->q, d->q_bs, d->q_hs, d->q_rs, d->k, d->k_bs, d->k_hs, d->k_rs, d->product,
            d->idx_q, d->count_q, d->kcap_q, d->delta ? d->idx_q_rest : nullptr, d->idx_k, d->count_k, d->kcap_k,
            d->tok_map, d->tok_map ? d->groups_per_clip : 1, d->pad_q, d->pad_k,
-           d->G, d->H, d->Nq, d->Nk, d->dh, d->scale, d->delta};
+           d->G, d->H, d->Nq, d->Nk, d->dh, d->scale, d->delta, d->split ? 1 : 0};
   return launch_qk(a, stream);
 }
 

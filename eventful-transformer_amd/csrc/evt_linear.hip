@@ -51,6 +51,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = g.B * g.kcap;
+  __shared__ int64_t orow_off[BM];  // output row offset (elements) of each tile row, -1 = masked row
+  for (int r = tid; r < BM; r += GEMM_THREADS) {
+    const int m = m0 + r;
+    int64_t off = -1;
+    if (m < M) {
+      const int b = m / g.kcap, ii = m - b * g.kcap;
+      if (g.count == nullptr || ii < g.count[b])
+        off = ((int64_t)b * g.o_rows + ((g.o_idx != nullptr) ? g.o_idx[m] : ii)) * g.ldo;
+    }
+    orow_off[r] = off;
+  }
 
   // ---- staging assignment: thread -> (row r0 + 32*j, 16-byte column c4) for j = 0..3
   const int r0 = tid >> 3, c4 = tid & 7;
@@ -162,26 +173,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // The bias loads are pinned before the store loop (empty asm reading the registers): with a load still pending inside
+  // the predicated store blocks the compiler re-waits `vmcnt(0)` in every block, and on gfx9 vmcnt also counts stores
+  // -- every store would wait for the previous one to be acknowledged.
+  float bv[2];
+  int ncol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ncol[j] = n0 + wn * 64 + j * 32 + lr;
+    bv[j] = ncol[j] < g.Nout ? g.bias[ncol[j]] : 0.f;
+  }
+  asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));   // pin: see above
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bv[j];
+        if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+        acc[i][j][r] = v;
+      }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-      const int b = m / g.kcap, ii = m - b * g.kcap;
-      if (g.count != nullptr && ii >= g.count[b]) continue;
-      const int dst = (g.o_idx != nullptr) ? g.o_idx[m] : ii;
-      float* orow = g.out + ((int64_t)b * g.o_rows + dst) * g.ldo;
+      const int64_t off = orow_off[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      if (off < 0) continue;
+      float* orow = g.out + off;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + lr;
-        if (n < g.Nout) {
-          float v = acc[i][j][r] + g.bias[n];
-          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-          orow[n] = v;
-        }
-      }
+      for (int j = 0; j < 2; ++j)
+        if (ncol[j] < g.Nout) orow[ncol[j]] = acc[i][j][r];
     }
   }
 }
@@ -404,13 +427,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
     __syncthreads();
   }
 
-  float bv[2];
   int ncol[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    ncol[j] = n0 + wn * 64 + j * 32 + lr;
-    bv[j] = ncol[j] < g.Nout ? g.bias[ncol[j]] : 0.f;
-  }
+  for (int j = 0; j < 2; ++j) ncol[j] = n0 + wn * 64 + j * 32 + lr;
   if (ksplit > 1) {
     // raw partial tile -> workspace plane `split`, compact row m; bias / act / scatter in splitk_finish_kernel
     float* wsp = g.ws + (int64_t)split * M * g.Nout;
@@ -426,6 +445,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
       }
     return;
   }
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bv[j] = ncol[j] < g.Nout ? g.bias[ncol[j]] : 0.f;
+  // The bias registers are pinned HERE (the empty asm reads them, so the load wait lands before the store loop).
+  // With the load still pending inside the predicated store blocks the compiler re-waits `vmcnt(0)` in every block,
+  // and on gfx9 vmcnt also counts stores -- every store then waited for the previous one to be acknowledged.
+  asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bv[j];
+        if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+        acc[i][j][r] = v;
+      }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -434,13 +470,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
       if (off < 0) continue;
       float* orow = g.out + off;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (ncol[j] < g.Nout) {
-          float v = acc[i][j][r] + bv[j];
-          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-          orow[ncol[j]] = v;
-        }
-      }
+      for (int j = 0; j < 2; ++j)
+        if (ncol[j] < g.Nout) orow[ncol[j]] = acc[i][j][r];
     }
   }
 }

@@ -57,7 +57,7 @@ class QkDesc(Structure):
         ("idx_k", c_void_p), ("count_k", c_void_p), ("kcap_k", c_int32),
         ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("pad_q", c_void_p), ("pad_k", c_void_p),
         ("G", c_int32), ("H", c_int32), ("Nq", c_int32), ("Nk", c_int32), ("dh", c_int32),
-        ("scale", c_float), ("delta", c_int32),
+        ("scale", c_float), ("delta", c_int32), ("split", c_int32),
     ]
 
 
@@ -252,6 +252,7 @@ def _timed(flops, fn, launches=1):
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
 # (~1e-5 relative to fp32, ~5x the fp32-MFMA rate); "f32" = exact fp32-input MFMA.  EVT_GEMM overrides.
 GEMM_MODE = os.environ.get("EVT_GEMM", "split")
+QK_SPLIT = os.environ.get("EVT_QK_SPLIT", "1" if GEMM_MODE == "split" else "0") != "0"   # K4 on the bf16x3 split MFMA
 DENSE_FUSED = os.environ.get("EVT_DENSE_FUSED", "1") != "0"   # K8 (evt_attention_dense) vs the K4+K5+K6 chain
 
 
@@ -313,7 +314,7 @@ def qk_packed(qkv, B, N, D, H, scale, product, idx=None, count=None, kcap=0, tok
     d = QkDesc(_p(qkv), rows * 3 * D, dh, 3 * D, kptr, k_bs, dh, k_rs, _p(product),
                _p(idx), _p(count), kcap, _p(idx_rest), _p(idx_k), _p(count_k), kcap_k, _p(tok_map), groups_per_clip,
                _p(pad_row), None if pad_row is None else _ptr_off(pad_row, D), B, H, N, Nk_, dh, float(scale),
-               int(idx is not None))
+               int(idx is not None), int(QK_SPLIT))
     _check(load().evt_qk(ctypes.byref(d), _stream()))
 
 
@@ -323,7 +324,7 @@ def qk_strided(q, k, product, scale, idx_q=None, count_q=None, kcap_q=0, idx_k=N
     Nk = k.shape[2]
     d = QkDesc(_p(q), H * Nq * dh, Nq * dh, dh, _p(k), H * Nk * dh, Nk * dh, dh, _p(product),
                _p(idx_q), _p(count_q), kcap_q, None, _p(idx_k), _p(count_k), kcap_k, None, 1, None, None,
-               B, H, Nq, Nk, dh, float(scale), int(idx_q is not None))
+               B, H, Nq, Nk, dh, float(scale), int(idx_q is not None), 0)   # stand-alone MatmulBuffer API: exact fp32 products
     _check(load().evt_qk(ctypes.byref(d), _stream()))
 
 

@@ -206,6 +206,8 @@ typedef struct evt_qk_desc {
   int32_t G, H, Nq, Nk, dh;
   float scale;
   int32_t delta;
+  int32_t split;   /* 0: fp32-input MFMA (exact fp32 products); 1: q, k split into bf16 hi/lo planes on the fly,
+                      (q/scale).k = lo.hi + hi.lo + hi.hi on the bf16 MFMA, fp32 accumulate (~1e-5 relative) */
 } evt_qk_desc;
 
 EVT_API int evt_qk(const evt_qk_desc* d, void* stream);
