@@ -186,16 +186,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
   }
   asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));   // pin: see above
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bv[j];
-        if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-        acc[i][j][r] = v;
-      }
-#pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -203,8 +193,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
       if (off < 0) continue;
       float* orow = g.out + off;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (ncol[j] < g.Nout) orow[ncol[j]] = acc[i][j][r];
+      for (int j = 0; j < 2; ++j) {
+        if (ncol[j] < g.Nout) {
+          float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
+          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+          orow[ncol[j]] = v;
+        }
+      }
     }
   }
 }
@@ -453,16 +448,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
   // and on gfx9 vmcnt also counts stores -- every store then waited for the previous one to be acknowledged.
   asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bv[j];
-        if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-        acc[i][j][r] = v;
-      }
-#pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -470,8 +455,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gated_linear_split_kernel(const 
       if (off < 0) continue;
       float* orow = g.out + off;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (ncol[j] < g.Nout) orow[ncol[j]] = acc[i][j][r];
+      for (int j = 0; j < 2; ++j) {
+        if (ncol[j] < g.Nout) {
+          float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
+          if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+          orow[ncol[j]] = v;
+        }
+      }
     }
   }
 }
