@@ -72,7 +72,11 @@ class Block(ExtendedModule):
                  relative_embedding_size=None, matmul_2_cast=None, pool_size=None, window_size=None):
         super().__init__()
         if ats_fraction is not None:
-            raise NotImplementedError("ats_fraction (adaptive token sampling) is not built yet in the MI355X path")
+            # The reference reduces its ATS scores over the BATCH axis (`scores.sum(dim=-3)` on a (B, H, N) tensor,
+            # blocks.py:163, commented "sum scores over heads"): it only executes when batch == heads, and then gives
+            # clip b the selection of head b computed from all clips.  There is no behaviour to be identical to.
+            raise NotImplementedError("ats_fraction: the reference's adaptive token sampling reduces over the batch axis "
+                                      "(blocks.py:163) and only runs when batch == heads; not reproduced in the MI355X path")
         if pool_size is not None and window_size is not None:
             raise NotImplementedError("pool_size together with window_size is not built in the MI355X path "
                                       "(the reference's configs pool only the global blocks)")
