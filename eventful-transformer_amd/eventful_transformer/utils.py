@@ -47,6 +47,34 @@ class DropPath(ExtendedModule):
         return x.div(1.0 - self.drop_rate) * keep.to(x.dtype)
 
 
+def _cubic_weights(in_size, out_size, device):
+    """(out_size, in_size) matrix of ATen's bicubic taps along one axis (align_corners=False, A = -0.75, border
+    indices clamped: UpSampleBicubic2d / upsample_get_cubic_coefficients)."""
+    A = -0.75
+    # source coordinate in fp32 exactly as ATen forms it (area_pixel_compute_scale / _source_index, cubic=true)
+    scale = torch.tensor(in_size, dtype=torch.float32) / torch.tensor(out_size, dtype=torch.float32)
+    src = scale * (torch.arange(out_size, dtype=torch.float32) + 0.5) - 0.5
+    i0 = torch.floor(src)
+    t = (src - i0).double()
+    conv1 = lambda x: ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0
+    conv2 = lambda x: ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A
+    taps = torch.stack([conv2(t + 1.0), conv1(t), conv1(1.0 - t), conv2(2.0 - t)], dim=1)
+    idx = (i0.long().unsqueeze(1) + torch.arange(-1, 3)).clamp_(0, in_size - 1)
+    w = torch.zeros(out_size, in_size, dtype=torch.float64)
+    w.scatter_add_(1, idx, taps)
+    return w.to(torch.float32).to(device)
+
+
+def bicubic_resize(grid, size):
+    """`F.interpolate(grid, size, mode="bicubic", align_corners=False)` for (N, C, H, W) as two small matmuls with the
+    same taps (bicubic is separable).  ATen's HIP kernel gives one thread per output pixel a loop over all N*C planes:
+    ~1 ms for a 64-channel 64x64 rel-pos table, 8 tables per ViTDet reset; this is two GEMMs of a few MFLOP.
+    Same weights, different summation order: agrees to ~1e-6 (tests/test_host_logic.py)."""
+    wy = _cubic_weights(grid.shape[-2], size[0], grid.device)
+    wx = _cubic_weights(grid.shape[-1], size[1], grid.device)
+    return torch.einsum("oh,nchw,pw->ncop", wy, grid, wx)
+
+
 class PositionEncoding(ExtendedModule):
     """Learned absolute position encoding, bicubically resized to the input grid once and cached in
     eval mode (utils.py:32-105).  `sized()` hands the cached (1,N,D) table to the backbone, which
@@ -90,7 +118,7 @@ class PositionEncoding(ExtendedModule):
         if self.has_class_token:  # the class token comes first (vivit.py:296)
             cls, enc = enc[:, :1], enc[:, 1:]
         grid = enc.transpose(1, 2).reshape(enc.shape[0], enc.shape[2], *self.encoding_size)
-        grid = func.interpolate(grid, self.input_size, mode="bicubic", align_corners=False)
+        grid = bicubic_resize(grid, self.input_size)   # utils.py:93-97 (F.interpolate bicubic)
         enc = grid.flatten(start_dim=2).transpose(1, 2)
         if cls is not None:
             enc = torch.concat([cls, enc], dim=1)
@@ -148,8 +176,7 @@ class RelativePositionEmbedding(ExtendedModule):
         steps = torch.arange(size, device=embedding.device)
         rel = embedding.detach()[steps.unsqueeze(1) - steps.unsqueeze(0) + (size - 1)]
         if self.embedding_size != self.attention_size:
-            rel = func.interpolate(rel.transpose(0, 2).unsqueeze(0), self.attention_size, mode="bicubic",
-                                   align_corners=False)
+            rel = bicubic_resize(rel.transpose(0, 2).unsqueeze(0), self.attention_size)   # utils.py:176-183
             rel = rel.squeeze(0).transpose(0, 2)
         if self.pool_size is not None:
             rel = func.avg_pool1d(rel.transpose(1, 2), self.pool_size[dim]).transpose(1, 2)

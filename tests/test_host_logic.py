@@ -174,3 +174,18 @@ def test_counts_arithmetic():
     assert dict(sum([a, b])) == {"x": 4, "y": 2}
     assert dict_csv_header(a + b) == "x,y" and dict_csv_line(a + b) == "4,2"
     assert numeric_tuple(3, 2) == (3, 3) and numeric_tuple([1, 2], 2) == (1, 2)
+
+
+def test_bicubic_resize_matches_aten():
+    """utils.bicubic_resize (two matmuls with ATen's cubic taps) against F.interpolate(mode="bicubic"), the call the
+    reference makes for rel-pos tables and position encodings (utils.py:93-97,176-183)."""
+    import torch.nn.functional as F
+    from eventful_transformer.utils import bicubic_resize
+    g = torch.Generator().manual_seed(0)
+    for shape, size in [((1, 64, 64, 64), (42, 42)), ((1, 768, 14, 14), (42, 42)), ((1, 16, 8, 8), (6, 6)),
+                        ((1, 32, 14, 14), (64, 64)), ((2, 8, 7, 5), (9, 11)), ((1, 4, 4, 4), (1, 3)), ((1, 8, 9, 9), (9, 9))]:
+        x = torch.randn(*shape, generator=g)
+        want = F.interpolate(x, size, mode="bicubic", align_corners=False)
+        got = bicubic_resize(x, size)
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) < 1e-5, (shape, size)
