@@ -27,7 +27,7 @@ def build(force=False, verbose=True):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-fvisibility=hidden", "-o", OUT] + srcs
+           "-fvisibility=hidden", "-o", OUT] + os.environ.get("EVT_HIPCC_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

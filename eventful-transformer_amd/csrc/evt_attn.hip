@@ -61,7 +61,7 @@ __device__ __forceinline__ void qk_split4(const float4 v, qk_bf16x4* hi, qk_bf16
 // they are staged and (q/scale).k = lo.hi + hi.lo + hi.hi runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
 // (~1e-5 relative, K = head dim only; 5x less matrix-pipe time than the 32x32x2 fp32 MFMA that bounds this kernel).
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void qk_kernel(const QkArgs a) {
+__global__ __launch_bounds__(256, 3) void qk_kernel(const QkArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[SPLIT ? (4 * QT * QSP) / 2 : 2 * QT * QLD];
   float* As = lds_raw;
   float* Bs = lds_raw + QT * QLD;
