@@ -100,6 +100,12 @@ def main():
                      ("TF", 2.0 * 2 * B * N * k * D)),
         "softmax_full": (lambda: n.softmax_gate(product, ap_, B, H, N, N, D, store), ("GB/s", B * H * N * N * (4 + es))),
         "av_full": (lambda: n.av(ap_, vp, N, B, H, N, N, D, store, pv=pv, out_f32=out), ("TF", 2.0 * B * N * N * D)),
+        # K8: first frame of a clip in one launch (q.k^T state + probabilities + A.v state + output)
+        "attention_dense_states": (lambda: n.attention_dense(qkv, B, H, N, D, 8.0, store, out_f32=out, product=product,
+                                                             a_state=ap_, pv=pv),
+                                   ("GB/s", B * H * N * N * (4 + es) + B * N * D * (12 + 4 + es))),
+        "attention_dense": (lambda: n.attention_dense(qkv, B, H, N, D, 8.0, store, out_f32=out),
+                            ("TF", 4.0 * B * N * N * D)),
     }
     only = [s for s in a.only.split(",") if s]
     print(f"# B={B} N={N} k={k} D={D} cast={a.cast}")

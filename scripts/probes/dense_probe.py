@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase timing of evt_attention_dense (EVT_DENSE_DBG=1..4 cuts the kernel after a phase)."""
+"""Timing of evt_attention_dense on a ViTDet window partition (grid 42 or 64, 14x14 windows, rel-pos; `norel` drops the
+tables).  The phase numbers in DESIGN.md came from temporary early-return hooks in the kernel, not kept in the product."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "eventful-transformer_amd"))
@@ -26,4 +27,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(50): run()
 e1.record(); torch.cuda.synchronize()
-print(f"grid {grid} groups {gpc} dbg={os.environ.get('EVT_DENSE_DBG','0')}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+print(f"grid {grid} groups {gpc} norel={norel}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
