@@ -256,7 +256,7 @@ __device__ __forceinline__ int splitk_dynamic(const int32_t* count, int B, int t
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
 template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? EVT_GEMM_MIN_BLOCKS : 1)) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM_MIN_BLOCKS : 1)) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
   constexpr int NT = WM * WN * 64;
   constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
   static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
@@ -544,7 +544,6 @@ void launch_split(const LinArgs& a, hipStream_t s) {
     case 4: launch_split_cfg<128, 256, 32, 2, 4>(a, s); break;
     case 5: launch_split_cfg<256, 256, 32, 4, 4>(a, s); break;
     case 6: launch_split_cfg<64, 64, 32, 1, 1>(a, s); break;
-    case 7: launch_split_cfg<128, 128, 16, 2, 2>(a, s); break;
     default: launch_split_cfg<128, 128, 32, 2, 2>(a, s); break;
   }
 }
