@@ -20,6 +20,7 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
+ABI_VERSION = 2   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
@@ -146,6 +147,9 @@ def load():
             )
         lib = ctypes.CDLL(LIB_PATH)
         _bind(lib)
+        if lib.evt_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {lib.evt_version()}, this package binds version {ABI_VERSION}: "
+                               "rebuild it with `python eventful-transformer_amd/build.py --force`")
         _lib = lib
     return _lib
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 1
+#define EVT_ABI_VERSION 2   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
