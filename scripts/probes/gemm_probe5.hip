@@ -32,7 +32,10 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
 #endif
 }
 
-__global__ __launch_bounds__(256) void k(const float* A, const uint16_t* W, float* out, int M, int K, int Nout, int tiles_n) {
+#ifndef MINB
+#define MINB 1
+#endif
+__global__ __launch_bounds__(256, MINB) void k(const float* A, const uint16_t* W, float* out, int M, int K, int Nout, int tiles_n) {
   __shared__ __attribute__((aligned(1024))) char ldsw[2][2 * W_BYTES];   // [buffer][hi plane | lo plane]
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * TBM * TSP];
   __bf16* Ahi = lds; __bf16* Alo = lds + TBM * TSP;

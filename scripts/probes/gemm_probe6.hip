@@ -35,7 +35,10 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* l
 }
 struct Regs { float4 a[AJ]; uint4 h[WJ], l[WJ]; };
 
-__global__ __launch_bounds__(256) void k(const float* A, const uint16_t* W, float* out, int M, int K, int Nout, int tiles_n) {
+#ifndef MINB
+#define MINB 1
+#endif
+__global__ __launch_bounds__(256, MINB) void k(const float* A, const uint16_t* W, float* out, int M, int K, int Nout, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   constexpr int BUF = 2 * (TBM + TBN) * TSP;
   const int tile = blockIdx.x, bm = tile / tiles_n, bn = tile - bm * tiles_n;
