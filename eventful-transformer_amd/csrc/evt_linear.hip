@@ -222,12 +222,25 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// hi = rne_bf16(x), lo = rne_bf16(x - hi) for 4 values.  Written pairwise so that the fp32 image of hi comes from the
+// PACKED conversion by a shift / mask (12 VALU per float4: 4 v_cvt_pk, 2 shifts, 2 ands, 4 subs) instead of hipcc's
+// four extra single-element conversions (16).
 __device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* lo) {
-  const f32x4_t x = {v.x, v.y, v.z, v.w};
-  const bf16x4_t h = __builtin_convertvector(x, bf16x4_t);
-  const f32x4_t r = x - __builtin_convertvector(h, f32x4_t);
-  *hi = h;
-  *lo = __builtin_convertvector(r, bf16x4_t);
+  union { bf16x2_t b; uint32_t u; } h01, h23, l01, l23;
+  h01.b = __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t);
+  h23.b = __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t);
+  const float r0 = v.x - __uint_as_float(h01.u << 16), r1 = v.y - __uint_as_float(h01.u & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(h23.u << 16), r3 = v.w - __uint_as_float(h23.u & 0xffff0000u);
+  l01.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
+  l23.b = __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t);
+  union { uint2 u; bf16x4_t b; } H, L;
+  H.u = make_uint2(h01.u, h23.u);
+  L.u = make_uint2(l01.u, l23.u);
+  *hi = H.b;
+  *lo = L.b;
 }
 
 // Split-K factor for `tiles` live 128x128 output tiles and nk k-tiles: only when the tile count leaves most of
@@ -338,14 +351,32 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   const uint16_t* wlo = g.Wsplit + (int64_t)g.Nout * g.K;
   const int wr0 = tid / WCH, wc8 = (tid % WCH) * 8;
 
+  int64_t w_off[WJ];   // element offset of this thread's weight rows (clamped to the last row past Nout)
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const int n = n0 + wr0 + WROWS * j;
+    w_off[j] = (int64_t)(n < g.Nout ? n : g.Nout - 1) * g.K;
+  }
   float4 ra[AJ];
   uint4 rwh[WJ], rwl[WJ];
   auto fetch = [&](int k0) {
     const int kc = k0 + ac4 * 4;
+    const int kw = k0 + wc8;
+    if (k0 + TBK <= g.K) {
+      // Whole k-tile inside K (always, when K % TBK == 0): unconditional loads, no per-load branch.  Masked rows
+      // (a_ptr = A) and weight rows past Nout (clamped) contribute to accumulators that the epilogue never stores.
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kc);
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        rwh[j] = *reinterpret_cast<const uint4*>(whi + w_off[j] + kw);
+        rwl[j] = *reinterpret_cast<const uint4*>(wlo + w_off[j] + kw);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < AJ; ++j)
       ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int kw = k0 + wc8;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const int n = n0 + wr0 + WROWS * j;

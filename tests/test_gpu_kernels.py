@@ -179,7 +179,7 @@ def test_split_gemm_error_vs_fp64():
 
 @pytest.mark.parametrize("B,N,K,Nout,k,act", [(2, 197, 768, 2304, 128, 0), (1, 37, 64, 192, 12, 0),
                                               (3, 50, 256, 64, 50, 1), (1, 300, 768, 3072, 131, 1),
-                                              (2, 64, 3072, 768, 64, 0)])
+                                              (2, 64, 3072, 768, 64, 0), (1, 50, 72, 136, 20, 0), (5, 300, 200, 520, 140, 1)])
 def test_gated_linear(B, N, K, Nout, k, act, gemm_mode):
     n = native()
     g = torch.Generator().manual_seed(B * 1000 + N + K + Nout)
