@@ -345,3 +345,27 @@ def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed):
     assert graphed._first is not None and graphed._inc is not None
     with pytest.raises(RuntimeError, match="differs from the captured"):
         graphed(clips[0][0][:1])
+
+
+def test_vivit_sized_backbone_reruns_are_bit_identical():
+    """I7 at the benchmark's shapes (N = 197, D = 768, 12 heads, bf16 A.v cast, k = 128; 2 blocks, 3 clips x 4 frames):
+    every kernel on the path -- K8 with state outputs on the first frame, split-precision K3/K4, the fused K5+K6,
+    split-K for this small batch -- is deterministic, so two runs from reset() agree bit for bit."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+
+    torch.manual_seed(11)
+    bb = ViTBackbone(block_config=dict(dim=768, heads=12, mlp_ratio=4, matmul_2_cast="bfloat16"), depth=2,
+                     position_encoding_size=(14, 14), input_size=(14, 14), block_class="EventfulBlock", has_class_token=True)
+    for p_ in bb.parameters():
+        torch.nn.init.normal_(p_, std=0.02)
+    bb = bb.eval().to(DEV)
+    H.set_policies(bb, policies.TokenNormTopK, k=128)
+    xs = O.make_token_stream(3, 197, 768, 4, 128, seed=77, small=0.01).to(DEV)
+    runs = []
+    with torch.inference_mode():
+        for _ in range(2):
+            bb.reset()
+            runs.append(torch.stack([bb(xs[t]).clone() for t in range(xs.shape[0])]))
+    assert torch.isfinite(runs[0]).all()
+    assert torch.equal(runs[0], runs[1])
