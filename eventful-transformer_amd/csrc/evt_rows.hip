@@ -20,20 +20,38 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
   const int64_t base = (int64_t)row * D;
   const int64_t rbase = (int64_t)(res_rows > 0 ? row % res_rows : row) * D;  // broadcast over clips
   const int nvec = D >> 2;
-  float4 v[NV];
+  // Every operand of the row is requested up front, through clamped addresses (no per-element branch, so the loads
+  // of all NV chunks are in flight together): x, the residual, the gate reference p -- which does not depend on the
+  // LayerNorm result -- and the LN weights.  The statistics then run while the later loads are still landing.
+  const bool want_norm = norms != nullptr;
+  const bool has_p = want_norm && p != nullptr;
+  int cc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) cc[i] = min(lane + i * 64, nvec - 1) * 4;
+  float4 v[NV], r[NV], pr[NV], lw[NV], lb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(x + base + cc[i]);
+  if (has_p) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) pr[i] = *reinterpret_cast<const float4*>(p + base + cc[i]);
+  }
+  if (ln_w != nullptr) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      lw[i] = *reinterpret_cast<const float4*>(ln_w + cc[i]);
+      lb[i] = *reinterpret_cast<const float4*>(ln_b + cc[i]);
+    }
+  }
+  if (res != nullptr) {   // last: hipcc merges the residual adds (and their wait) into this block
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(res + rbase + cc[i]);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c4 = lane + i * 64;
-    if (c4 < nvec) {
-      v[i] = *reinterpret_cast<const float4*>(x + base + c4 * 4);
-      if (res != nullptr) {
-        const float4 r = *reinterpret_cast<const float4*>(res + rbase + c4 * 4);
-        v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
-      }
-      if (sum_out != nullptr) *reinterpret_cast<float4*>(sum_out + base + c4 * 4) = v[i];
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const bool in = lane + i * 64 < nvec;
+    if (res != nullptr) { v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w; }
+    if (!in) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sum_out != nullptr && in) *reinterpret_cast<float4*>(sum_out + base + cc[i]) = v[i];
   }
   if (ln_w != nullptr) {
     float s = 0.f;
@@ -43,8 +61,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + i * 64;
-      if (c4 < nvec) {
+      if (lane + i * 64 < nvec) {
         const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
         q += (a * a + b * b) + (c * c + d * d);
       }
@@ -52,33 +69,24 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + i * 64;
-      if (c4 < nvec) {
-        const float4 w = *reinterpret_cast<const float4*>(ln_w + c4 * 4);
-        const float4 b = *reinterpret_cast<const float4*>(ln_b + c4 * 4);
-        v[i].x = (v[i].x - mean) * rstd * w.x + b.x;
-        v[i].y = (v[i].y - mean) * rstd * w.y + b.y;
-        v[i].z = (v[i].z - mean) * rstd * w.z + b.z;
-        v[i].w = (v[i].w - mean) * rstd * w.w + b.w;
-      }
+      v[i].x = (v[i].x - mean) * rstd * lw[i].x + lb[i].x;
+      v[i].y = (v[i].y - mean) * rstd * lw[i].y + lb[i].y;
+      v[i].z = (v[i].z - mean) * rstd * lw[i].z + lb[i].z;
+      v[i].w = (v[i].w - mean) * rstd * lw[i].w + lb[i].w;
     }
   }
   if (c_out != nullptr) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + i * 64;
-      if (c4 < nvec) *reinterpret_cast<float4*>(c_out + base + c4 * 4) = v[i];
-    }
+    for (int i = 0; i < NV; ++i)
+      if (lane + i * 64 < nvec) *reinterpret_cast<float4*>(c_out + base + cc[i]) = v[i];
   }
-  if (norms != nullptr) {
+  if (want_norm) {
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c4 = lane + i * 64;
-      if (c4 < nvec) {
-        const float4 r = (p != nullptr) ? *reinterpret_cast<const float4*>(p + base + c4 * 4)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float a = v[i].x - r.x, b = v[i].y - r.y, c = v[i].z - r.z, d = v[i].w - r.w;
+      if (lane + i * 64 < nvec) {
+        const float4 z = has_p ? pr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float a = v[i].x - z.x, b = v[i].y - z.y, c = v[i].z - z.z, d = v[i].w - z.w;
         q += (a * a + b * b) + (c * c + d * d);
       }
     }
