@@ -291,7 +291,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
                                                   (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
             "data": "synthetic", "per_gpu": round(value / world, 2),
-            "config": {"workload": f"ViViT-B spatial 16x224^2 (N=197, D=768, 12 EventfulBlocks) top-k r={args.k}, "
+            "config": {"workload": f"ViViT-B spatial {args.frames}x224^2 (N=197, D=768, 12 EventfulBlocks) top-k r={args.k}, "
                                    f"T={args.frames} frames/clip incl. dense first frame, matmul_2_cast={cast}",
                        "clips_per_gpu": args.clips, "frames_per_step": args.clips * args.frames,
                        "parallelism": f"clip-sharded x{world}", "launch": "hip-graph replay" if args.graphs else "eager"},
