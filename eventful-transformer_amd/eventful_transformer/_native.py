@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevt_hip.so")
+LIB_PATH = os.environ.get("EVT_LIB", os.path.join(_HERE, "libevt_hip.so"))   # EVT_LIB: A/B another build of the same ABI
 
 EVT_F32, EVT_BF16, EVT_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
