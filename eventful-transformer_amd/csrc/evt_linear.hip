@@ -28,6 +28,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDT: padded LDS row (floats)
 constexpr int GEMM_THREADS = 256;
 
+#ifndef EVT_GEMM_PRIO
+#define EVT_GEMM_PRIO 1
+#endif
 #ifndef EVT_GEMM_MIN_BLOCKS
 #define EVT_GEMM_MIN_BLOCKS 3   // 158 VGPRs, 3 x 42 KB LDS: three workgroups per CU (+8 % over two; measured)
 #endif
@@ -366,12 +369,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       // Whole k-tile inside K (always, when K % TBK == 0): unconditional loads, no per-load branch.  Masked rows
       // (a_ptr = A) and weight rows past Nout (clamped) contribute to accumulators that the epilogue never stores.
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kc);
-#pragma unroll
       for (int j = 0; j < WJ; ++j) {
         rwh[j] = *reinterpret_cast<const uint4*>(whi + w_off[j] + kw);
         rwl[j] = *reinterpret_cast<const uint4*>(wlo + w_off[j] + kw);
       }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kc);
       return;
     }
 #pragma unroll
@@ -428,9 +431,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       for (int j = 0; j < AJ; ++j)
         if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
     }
+    if (t + 1 < nk) fetch((t + 1) * TBK);   // before the barrier: the requests do not wait for the slowest wave's staging
     __syncthreads();
-    if (t + 1 < nk) fetch((t + 1) * TBK);
-    __builtin_amdgcn_s_setprio(1);
+    if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < TBK; ks += 16) {
       bf16x8_t ah[2], al[2], bh[2], bl[2];
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
