@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: frames/sec of the ViViT-B spatial model on the gated-token (Eventful) path.
+"""Headline benchmark: frames/sec of the gated-token (Eventful) path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B] [--frames T] [--k R] [--cast bfloat16|none]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--clips B] [--total-clips C] ...
 
-Workload (BASELINE.json configs[1]): ViViT-B factorised-encoder SPATIAL model, Kinetics shape
-16 x 224^2 -> T = 16 backbone frames of 196 patch tokens + class token (N = 197), D = 768, 12
-`EventfulBlock`s, top-k r = 128, reference `matmul_2_cast="bfloat16"` semantics for the A.v stage
-(fp32 everywhere else).  Random-init weights (seeded normal std 0.02), synthetic token clips already
-resident in HBM.  One STEP = one batch of B clips taken through all T frames the way
-`FactorizedViViT._forward_view` does (vivit.py:146-147): reset(), frame 0 dense, frames 1..T-1 gated;
-per frame: prepend class token, backbone, final LayerNorm, take token 0 (vivit.py:293-303).
+Workloads (BASELINE.json configs):
+  vivit16     (default, configs[1]) ViViT-B factorised-encoder SPATIAL model, Kinetics shape 16 x 224^2: T = 16
+              backbone frames of 196 patch tokens + class token (N = 197), D = 768, 12 `EventfulBlock`s, top-k
+              r = 128, reference `matmul_2_cast="bfloat16"` semantics for the A.v stage (fp32 everywhere else).
+  vivit32     (configs[3]) same model, T = 32 frames, r = 64.
+  vivit_dense (configs[0] on the GPU) same model with dense `Block`s (gating off).
+  vitdet672   (configs[2]) ViTDet-B backbone, 672^2 (N = 1764), top-k r = 256, fp32, ONE video stream.
+  vitdet1024  (configs[4]) ViTDet-B backbone, 1024^2 (N = 4096), threshold policy (variable r), bf16 A.v in the
+              global blocks, ONE video stream (the reference's threshold policy asserts batch 1, policies.py:25).
 
-Multi-GPU (--gpus N under torch.distributed.run): clips are independent, so every rank runs its own
-B clips ("weak" scaling, no data-path collective); RCCL only broadcasts the weights from rank 0 and
-reduces the timing.  value = whole-job frames/s = N * B * T * K / max-over-ranks time.
+Random-init weights (seeded normal std 0.02), synthetic token clips already resident in HBM.  One STEP = one
+pass of the clip set through all T frames the way `FactorizedViViT._forward_view` does (vivit.py:146-147):
+reset(), frame 0 dense, frames 1..T-1 gated; per frame: class token, backbone, final LayerNorm, token 0.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the MFMA gated-linear GEMM, timed
-with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = torch-CPU port of the
-reference, timed on the host cores in this same run).
+Multi-GPU: clips are independent (utils/evaluate.py:29-32), so the clip set is sharded clip i -> rank i mod N
+with NO data-path collective; RCCL only broadcasts the weights from rank 0 and max-reduces the elapsed time.
+The default is STRONG scaling: a fixed set of --total-clips (2048) clips, processed by each rank in resident
+batches of --clips (256); `--total-clips 0` gives weak scaling (--clips per GPU).  `--gpus N` from a plain
+shell starts the N ranks itself (torch.distributed.run children, before anything touches the GPU); under an
+external torchrun (WORLD_SIZE set) it runs as one rank.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel timed live with HIP events on the launch
+stream), `check` (clip 0 of the timed model against the CPU oracle, after the timed region), `cpu_baseline`
+(the CPU oracle on this box's host cores, same run) and `exact_fp32_frames_s` (the EVT_GEMM=f32 arithmetic).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,18 +48,52 @@ METRIC = "frames/sec/GPU ViViT-B 16x224^2 r=128; gate-index bit-exact vs ref"
 DIM, DEPTH, HEADS, TOKENS = 768, 12, 12, 196
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured copy ceiling)
+VITDET_WINDOWED = (0, 1, 3, 4, 6, 7, 9, 10)   # configs/models/vitdet_b_coco.yml:13
+
+WORKLOADS = {
+    #              kind      block class      frames  k     cast        grid
+    "vivit16":     ("vivit", "EventfulBlock", 16,     128,  "bfloat16", 14),
+    "vivit32":     ("vivit", "EventfulBlock", 32,     64,   "bfloat16", 14),
+    "vivit_dense": ("vivit", "Block",         16,     0,    None,       14),
+    "vitdet672":   ("vitdet", "EventfulBlock", 12,    256,  None,       42),
+    "vitdet1024":  ("vitdet", "EventfulBlock", 8,     0,    "bfloat16", 64),
+}
 
 
+# ------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` from a plain shell
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv, backend_env=None):
+    """Start n ranks of this script under torch.distributed.run as a CHILD process and relay its output and
+    exit code.  Called before anything in this process touches the GPU (a fresh child, never an exec)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(backend_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameters and synthetic inputs
+# ------------------------------------------------------------------------------------------------------
 def seeded_state_dict(seed=77, std=0.02):
-    """Same version-stable generator as the parity tests (numpy RandomState)."""
+    """ViViT-B spatial sub-model parameters under the reference's state_dict names (ViViTSubModel,
+    vivit.py:272-291).  Version-stable generator (numpy RandomState), as in the parity tests."""
     rs = np.random.RandomState(seed)
 
     def n(*shape, s=std):
         return torch.from_numpy((rs.standard_normal(shape) * s).astype(np.float32))
 
-    sd = {"position_encoding.encoding": n(1, TOKENS + 1, DIM)}
+    sd = {"backbone.position_encoding.encoding": n(1, TOKENS + 1, DIM)}
     for i in range(DEPTH):
-        p = f"blocks.{i}."
+        p = f"backbone.blocks.{i}."
         sd[p + "input_layer_norm.weight"] = 1.0 + n(DIM, s=0.05)
         sd[p + "input_layer_norm.bias"] = n(DIM, s=0.05)
         sd[p + "qkv.weight"], sd[p + "qkv.bias"] = n(3 * DIM, DIM), n(3 * DIM)
@@ -56,64 +102,103 @@ def seeded_state_dict(seed=77, std=0.02):
         sd[p + "mlp_layer_norm.bias"] = n(DIM, s=0.05)
         sd[p + "mlp_1.weight"], sd[p + "mlp_1.bias"] = n(4 * DIM, DIM), n(4 * DIM)
         sd[p + "mlp_2.weight"], sd[p + "mlp_2.bias"] = n(DIM, 4 * DIM), n(DIM)
-    extra = {"class_token": n(1, 1, DIM), "ln.weight": 1.0 + n(DIM, s=0.05), "ln.bias": n(DIM, s=0.05)}
-    return sd, extra
+    sd["class_token"] = n(1, 1, DIM)
+    sd["layer_norm.weight"], sd["layer_norm.bias"] = 1.0 + n(DIM, s=0.05), n(DIM, s=0.05)
+    return sd
 
 
-def synthetic_clips(batch, frames, k, seed, device):
-    """(T, B, 196, D) token clips: frame 0 ~ N(0,1); each later frame re-randomises exactly k patches per
-    clip and jitters the rest by N(0, 0.01^2).  Generated on the device (torch.Generator)."""
+def vitdet_state_dict(seed=91, std=0.02):
+    """ViTDet-B backbone parameters (vitdet_b_coco.yml: 12 blocks, rel-pos tables 64x64 global / 14x14 windowed)."""
+    rs = np.random.RandomState(seed)
+
+    def n(*shape, s=std):
+        return torch.from_numpy((rs.standard_normal(shape) * s).astype(np.float32))
+
+    sd = {"position_encoding.encoding": n(1, 14 * 14, DIM)}
+    for i in range(DEPTH):
+        p = f"blocks.{i}."
+        rel = 14 if i in VITDET_WINDOWED else 64
+        sd[p + "input_layer_norm.weight"], sd[p + "input_layer_norm.bias"] = 1.0 + n(DIM, s=0.05), n(DIM, s=0.05)
+        sd[p + "qkv.weight"], sd[p + "qkv.bias"] = n(3 * DIM, DIM), n(3 * DIM)
+        sd[p + "projection.weight"], sd[p + "projection.bias"] = n(DIM, DIM), n(DIM)
+        sd[p + "mlp_layer_norm.weight"], sd[p + "mlp_layer_norm.bias"] = 1.0 + n(DIM, s=0.05), n(DIM, s=0.05)
+        sd[p + "mlp_1.weight"], sd[p + "mlp_1.bias"] = n(4 * DIM, DIM), n(4 * DIM)
+        sd[p + "mlp_2.weight"], sd[p + "mlp_2.bias"] = n(DIM, 4 * DIM), n(DIM)
+        sd[p + "relative_position.y_embedding"] = n(2 * rel - 1, 64)
+        sd[p + "relative_position.x_embedding"] = n(2 * rel - 1, 64)
+    return sd
+
+
+def synthetic_clips(batch, frames, k, seed, device, tokens=TOKENS):
+    """(T, B, tokens, D) token clips: frame 0 ~ N(0,1); each later frame re-randomises exactly k patches per
+    clip and jitters the rest by N(0, 0.01^2).  Generated on `device` (torch.Generator)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    cur = torch.randn(batch, TOKENS, DIM, generator=g, device=device)
+    cur = torch.randn(batch, tokens, DIM, generator=g, device=device)
     out = [cur]
     for _ in range(1, frames):
-        cur = cur + 0.01 * torch.randn(batch, TOKENS, DIM, generator=g, device=device)
-        pick = torch.rand(batch, TOKENS, generator=g, device=device).argsort(dim=1)[:, :k]
-        fresh = torch.randn(batch, k, DIM, generator=g, device=device)
-        cur = cur.scatter(1, pick.unsqueeze(-1).expand(-1, -1, DIM), fresh)
+        cur = cur + 0.01 * torch.randn(batch, tokens, DIM, generator=g, device=device)
+        if k > 0:
+            pick = torch.rand(batch, tokens, generator=g, device=device).argsort(dim=1)[:, :k]
+            fresh = torch.randn(batch, k, DIM, generator=g, device=device)
+            cur = cur.scatter(1, pick.unsqueeze(-1).expand(-1, -1, DIM), fresh)
         out.append(cur)
     return torch.stack(out)
 
 
-class SpatialModel:
-    """ViViTSubModel.forward of the reference (vivit.py:293-303) around our ViTBackbone."""
+def threshold_stream(frames, seed, device, tokens, frac=0.1, big=0.5, small=1e-3):
+    """(T, 1, tokens, D): each frame ~10 % of the tokens move by N(0, 0.5^2), the rest by N(0, 1e-3^2)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    cur = torch.randn(1, tokens, DIM, generator=g, device=device)
+    out = [cur]
+    for _ in range(1, frames):
+        cur = cur + small * torch.randn(1, tokens, DIM, generator=g, device=device)
+        pick = torch.rand(1, tokens, generator=g, device=device).argsort(dim=1)[:, : int(frac * tokens)]
+        bump = big * torch.randn(1, pick.shape[1], DIM, generator=g, device=device)
+        cur = cur.scatter_add(1, pick.unsqueeze(-1).expand(-1, -1, DIM), bump)
+        out.append(cur)
+    return torch.stack(out)
 
-    def __init__(self, sd, extra, cast, k, device):
+
+# ------------------------------------------------------------------------------------------------------
+# product models
+# ------------------------------------------------------------------------------------------------------
+def set_policies(model, factory):
+    """utils/misc.py:140-143: one fresh policy object per gate."""
+    from eventful_transformer.modules import SimpleSTGTGate, TokenDeltaGate, TokenGate
+
+    for cls in (SimpleSTGTGate, TokenDeltaGate, TokenGate):
+        for gate in model.modules_of_type(cls):
+            gate.policy = factory()
+
+
+class SpatialModel:
+    """The ViViT spatial sub-model (models/vivit.py::ViViTSubModel of this package) stepped through a clip the way
+    `FactorizedViViT._forward_view` does (vivit.py:146-147)."""
+
+    def __init__(self, sd, cast, k, device, block_class="EventfulBlock"):
         from eventful_transformer import policies
-        from eventful_transformer.backbones import ViTBackbone
-        from eventful_transformer.modules import SimpleSTGTGate, TokenDeltaGate, TokenGate
+        from models.vivit import ViViTSubModel
 
         cfg = dict(dim=DIM, heads=HEADS, mlp_ratio=4)
         if cast:
             cfg["matmul_2_cast"] = cast
-        bb = ViTBackbone(block_config=cfg, depth=DEPTH, position_encoding_size=(14, 14), input_size=(14, 14),
-                         block_class="EventfulBlock", has_class_token=True)
-        bb.load_state_dict(sd, strict=True)
-        self.backbone = bb.eval().to(device)
-        for cls in (SimpleSTGTGate, TokenDeltaGate, TokenGate):  # utils/misc.py:140-143
-            for gate in self.backbone.modules_of_type(cls):
-                gate.policy = policies.TokenNormTopK(k=k)
-        self.class_token = extra["class_token"].to(device)
-        self.ln_w, self.ln_b = extra["ln.weight"].to(device), extra["ln.bias"].to(device)
+        net = ViViTSubModel((14, 14), dict(block_config=cfg, depth=DEPTH, position_encoding_size=(14, 14),
+                                           block_class=block_class))
+        net.load_state_dict(sd, strict=True)
+        self.net = net.eval().to(device)
+        self.backbone = self.net.backbone
+        if k > 0:
+            set_policies(self.net, lambda: policies.TokenNormTopK(k=k))
         self.graphs = None
 
     def reset(self):
-        self.backbone.reset()
+        self.net.reset()
 
     def frame(self, x):
-        from eventful_transformer import _native
-
-        B = x.shape[0]
-        x = torch.concat([self.class_token.expand(B, 1, DIM), x], dim=1)
-        y = self.backbone(x)
-        # LayerNorm is row-wise: normalising only the class-token rows equals layer_norm(y)[:, 0]
-        cls_rows = y[:, 0].contiguous()
-        out = torch.empty_like(cls_rows)
-        _native.row_pass(cls_rows, B, DIM, ln_w=self.ln_w, ln_b=self.ln_b, eps=1e-6, c_out=out)
-        return out
+        return self.net(x)
 
     def clip(self, clips):
-        """vivit.py:146-147: reset, then one backbone call per time step."""
+        """vivit.py:146-147: reset, then one sub-model call per time step -> (B, T, D) class embeddings."""
         if self.graphs is not None:  # HIP-graph replay of the same launches (eventful_transformer/graphs.py)
             self.graphs.reset()
             return torch.stack([self.graphs(clips[t]).clone() for t in range(clips.shape[0])], dim=1)
@@ -123,45 +208,204 @@ class SpatialModel:
     def use_graphs(self):
         from eventful_transformer.graphs import FrameGraphs
 
-        self.graphs = FrameGraphs(self.backbone, forward=self.frame)
+        self.graphs = FrameGraphs(self.net)
 
 
-def cpu_baseline(sd, extra, cast, k, frames, budget_s=20.0):
-    """CPU column: the oracle (a torch-CPU port of the reference's op sequence, pinned bit-exact to the
-    reference by tests/golden) on this box's host cores.  Bounded sample: whole single clips (B=1, T
-    frames, first dense frame included) until ~budget_s, after one warm-up clip."""
+class DetModel:
+    """ViTDet-B backbone on one video stream: `model.reset()` then `backbone(x)` per frame
+    (scripts/time/vitdet_vid.py:27-38)."""
+
+    def __init__(self, sd, cast, policy_factory, grid, device):
+        from eventful_transformer.backbones import ViTBackbone
+
+        cfg = dict(dim=DIM, heads=HEADS, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14))
+        if cast:
+            cfg["matmul_2_cast"] = cast
+        bb = ViTBackbone(block_config=cfg, depth=DEPTH, position_encoding_size=(14, 14), input_size=(grid, grid),
+                         block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
+                         window_indices=VITDET_WINDOWED, windowed_overrides=(dict(matmul_2_cast=None) if cast else None))
+        bb.load_state_dict(sd, strict=True)
+        self.net = self.backbone = bb.eval().to(device)
+        set_policies(bb, policy_factory)
+        self.graphs = None
+
+    def reset(self):
+        self.net.reset()
+
+    def clip(self, clips):
+        self.reset()
+        y = None
+        for t in range(clips.shape[0]):
+            y = self.net(clips[t])
+        return y
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU oracle legs (test infrastructure used as the checker / the reported CPU baseline, never as the product)
+# ------------------------------------------------------------------------------------------------------
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import eventful_oracle as O
 
-    threads = min(8, os.cpu_count() or 1)  # the reference's own CPU setting (configs/time/*/_cpu.yml: threads 8)
-    torch.set_num_threads(threads)
+    return O
+
+
+def vivit_oracle_model(sd, cast, k, kind="EventfulBlock"):
+    O = _oracle()
+    blocks = []
+    for i in range(DEPTH):
+        pre = f"backbone.blocks.{i}."
+        params = {key[len(pre):]: v for key, v in sd.items() if key.startswith(pre)}
+        blocks.append(O.BlockOracle(kind, params, DIM, HEADS, (14, 14), matmul_2_cast=cast))
+    bb = O.BackboneOracle(blocks, sd["backbone.position_encoding.encoding"], (14, 14), (14, 14), True)
+    if k > 0:
+        bb.set_policy(lambda: O.TopK(k))
+    return O.ViViTSpatialOracle(bb, sd["class_token"], sd["layer_norm.weight"], sd["layer_norm.bias"]), blocks
+
+
+def vitdet_oracle_model(sd, cast, policy, grid):
+    O = _oracle()
     blocks = []
     for i in range(DEPTH):
         pre = f"blocks.{i}."
         params = {key[len(pre):]: v for key, v in sd.items() if key.startswith(pre)}
-        blocks.append(O.BlockOracle("EventfulBlock", params, DIM, HEADS, (14, 14), matmul_2_cast=cast))
-    bb = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
-    bb.set_policy(lambda: O.TopK(k))
-    model = O.ViViTSpatialOracle(bb, extra["class_token"], extra["ln.weight"], extra["ln.bias"])
+        if i in VITDET_WINDOWED:
+            blocks.append(O.BlockOracle("EventfulTokenwiseBlock", params, DIM, HEADS, (grid, grid), window_size=(14, 14),
+                                        relative_embedding_size=(64, 64)))
+        else:
+            blocks.append(O.BlockOracle("EventfulBlock", params, DIM, HEADS, (grid, grid),
+                                        relative_embedding_size=(64, 64), matmul_2_cast=cast))
+    bb = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (grid, grid), False)
+    bb.set_policy((lambda: O.TopK(policy[1])) if policy[0] == "topk" else (lambda: O.Threshold(policy[1])))
+    return bb, blocks
+
+
+def _time_clips(run, frames, budget_s, max_clips=50):
+    run()  # warm-up clip
+    n, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= max_clips:
+            return n, el
+
+
+def cpu_baseline_vivit(sd, cast, k, frames, kind="EventfulBlock", budget_s=12.0):
+    """CPU column: the oracle (a torch-CPU port of the reference's op sequence, pinned bit-exact to the reference
+    by tests/golden) on this box's host cores.  Bounded sample: whole single clips (B=1, T frames, first dense
+    frame included).  Reported at 8 threads (the reference's own CPU setting, configs/time/*/_cpu.yml) and, when
+    the box has more, at all cores; plus the dense config-1 figure (ViViT-B with `Block`, gating off)."""
+    cores = os.cpu_count() or 1
     clip = synthetic_clips(1, frames, k, 1234, torch.device("cpu"))
-    with torch.inference_mode():
+
+    def sample(model_kind, threads, budget):
+        torch.set_num_threads(threads)
+        model, _ = vivit_oracle_model(sd, cast if model_kind != "Block" else None, k if model_kind != "Block" else 0, model_kind)
+
         def run():
             model.reset()
             for t in range(frames):
                 model.forward(clip[t])
-        run()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            run()
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or n >= 50:
-                break
-    return {"value": round(n * frames / el, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} clips x {frames} frames, B=1, ViViT-B spatial k={k} cast={cast}, torch-CPU oracle, "
-                      f"{threads} threads, {el:.1f}s"}
+        with torch.inference_mode():
+            n, el = _time_clips(run, frames, budget)
+        return round(n * frames / el, 3), f"{n} clips x {frames} frames in {el:.1f}s"
+
+    t8 = min(8, cores)
+    v8, s8 = sample(kind, t8, budget_s)
+    out = {"value": v8, "unit": "frames/s", "cores": t8, "kind": "port",
+           "sample": f"{s8}, B=1, ViViT-B spatial {kind} k={k} cast={cast}, torch-CPU oracle, {t8} threads"}
+    if cores > t8:
+        va, sa = sample(kind, cores, budget_s * 0.6)
+        out["all_cores"] = {"value": va, "cores": cores, "sample": sa}
+    else:
+        out["all_cores"] = {"value": v8, "cores": cores, "sample": "host has no more than 8 cores: same run"}
+    if kind != "Block":
+        vd, sdn = sample("Block", t8, budget_s * 0.5)
+        out["dense_config1"] = {"value": vd, "unit": "frames/s", "cores": t8,
+                                "sample": f"{sdn}, ViViT-B spatial dense `Block` (BASELINE configs[0]), {t8} threads"}
+    return out
 
 
+def cpu_baseline_vitdet(sd, cast, policy, grid, stream_cpu):
+    """One first frame + the incremental frames of `stream_cpu` (bounded) through the oracle, 8 threads."""
+    cores = os.cpu_count() or 1
+    t8 = min(8, cores)
+    torch.set_num_threads(t8)
+    bb, _ = vitdet_oracle_model(sd, cast, policy, grid)
+    times = []
+    with torch.inference_mode():
+        for t in range(stream_cpu.shape[0]):
+            t0 = time.perf_counter()
+            bb.forward(stream_cpu[t].clone())
+            times.append(time.perf_counter() - t0)
+    nf = times[1:]
+    return {"value": round(len(nf) / sum(nf), 4), "unit": "frames/s", "cores": t8, "kind": "port",
+            "first_frame_s": round(times[0], 2),
+            "sample": f"1 first + {len(nf)} incremental frames, ViTDet-B backbone {grid * 16}^2 {policy}, cast={cast}, "
+                      f"torch-CPU oracle, {t8} threads, non-first frames only"}
+
+
+def topk_margin(e, k):
+    n = torch.linalg.vector_norm(e.double(), dim=-1)
+    s = n.sort(dim=-1, descending=True)[0]
+    if k >= s.shape[-1]:
+        return 1.0
+    return float(((s[..., k - 1] - s[..., k]) / s[..., k - 1]).min())
+
+
+def self_check_vivit(model, clips, sd, cast, k, margin_bar=1e-3):
+    """Runs the timed model once more on the same resident batch (identical launches), reads back clip 0's
+    class embeddings and -- through forward hooks on the blocks -- clip 0's three gate index sets per block per
+    frame, and compares them with the CPU oracle run on clip 0 free-running."""
+    from eventful_transformer import _native
+
+    T, B = clips.shape[0], clips.shape[1]
+    dev = clips.device
+    got_idx = []
+    hooks = []
+    if k > 0:
+        def grab(_m, _i, _o):
+            got_idx.append([_native.scratch(f"idx_{g}", (B, k), torch.int32, dev)[0].cpu().long().clone()
+                            for g in ("qkv", "projection", "mlp")])
+        hooks = [blk.register_forward_hook(grab) for blk in model.backbone.blocks]
+    with torch.inference_mode():
+        feats = model.clip(clips)[0].cpu()   # (T, D) of clip 0
+    for h in hooks:
+        h.remove()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    oracle, oblocks = vivit_oracle_model(sd, cast, k, "EventfulBlock" if k > 0 else "Block")
+    x0 = clips[:, :1].cpu()
+    worst, checked, equal_on_margin, equal_all, total = 0.0, 0, 0, 0, 0
+    with torch.inference_mode():
+        oracle.reset()
+        for t in range(T):
+            ref = oracle.forward(x0[t])
+            worst = max(worst, float((feats[t] - ref[0]).abs().max()))
+            if t == 0 or k == 0:
+                continue
+            for bi, ob in enumerate(oblocks):
+                mine = got_idx[t * DEPTH + bi]
+                for gi, (gname, tkey) in enumerate((("qkv_gate", "qkv_index"), ("projection_gate", "projection_index"),
+                                                    ("mlp_gate", "mlp_index"))):
+                    want = ob.trace[tkey].sort(dim=-1)[0][0]
+                    same = bool(torch.equal(mine[gi], want))
+                    total += 1
+                    equal_all += same
+                    if topk_margin(ob.policy[gname].last_input, k) >= margin_bar:
+                        checked += 1
+                        equal_on_margin += same
+    tol = 1e-3 if cast is None else 5e-2
+    return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol,
+            "gates_checked": checked, "index_sets_equal": bool(checked == equal_on_margin),
+            "gates_total": total, "agreement_rate_all_margins": round(equal_all / total, 4) if total else None,
+            "margin_bar": margin_bar, "mode": "free-running vs CPU oracle (gates with reference margin >= bar must agree)",
+            "ok": bool(worst <= tol and checked == equal_on_margin)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# distributed plumbing (also exercised on gloo/CPU by tests/test_dist_cpu.py)
+# ------------------------------------------------------------------------------------------------------
 def broadcast_weights(sd, extra, device, rank):
     """Rank 0's weights -> every rank, as ONE flat-buffer broadcast (RCCL over xGMI on the GPU box; the
     same code runs on gloo/CPU in tests/test_dist_cpu.py).  Non-zero ranks' values are overwritten."""
@@ -184,8 +428,40 @@ def max_over_ranks(seconds, device):
 
 
 def clips_for_rank(total_clips, world, rank):
-    """Clip i -> rank i mod world; used when a FIXED clip set is split (strong scaling)."""
+    """Clip i -> rank i mod world: the fixed clip set of a strong-scaling run."""
     return list(range(rank, total_clips, world))
+
+
+def batches_for_rank(total_clips, world, rank, resident):
+    """This rank's share of the clip set, cut into resident batches of at most `resident` clips."""
+    mine = clips_for_rank(total_clips, world, rank)
+    return [mine[i:i + resident] for i in range(0, len(mine), resident)]
+
+
+# ------------------------------------------------------------------------------------------------------
+def gemm_source_hash():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "eventful-transformer_amd", "csrc", "evt_linear*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(clips, frames, k, cast, gemm_mode):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r*/pmc_traffic_B<clips>.json whose
+    workload AND GEMM source hash match this tree (FETCH_SIZE / WRITE_SIZE cannot be read in-process; a stale
+    file is reported as null, never replayed)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_B{clips}.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            wl = pmc["workload"]
+            if (wl["clips"], wl["frames"], wl["k"], wl["cast"], wl["gemm"]) != (clips, frames, k, cast, gemm_mode):
+                continue
+            if pmc.get("gemm_source_sha16") != gemm_source_hash():
+                continue
+            return pmc["gated_linear_hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -193,24 +469,43 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=256, help="clips resident per GPU (B); 256 clips = ~32 GB of per-clip state")
-    ap.add_argument("--frames", type=int, default=16, help="backbone frames per clip (T)")
-    ap.add_argument("--k", type=int, default=128)
-    ap.add_argument("--cast", default="bfloat16")
+    ap.add_argument("--workload", default="vivit16", choices=sorted(WORKLOADS))
+    ap.add_argument("--clips", type=int, default=256, help="clips resident per GPU per batch (B); 256 clips = ~32 GB of per-clip state")
+    ap.add_argument("--total-clips", type=int, default=None,
+                    help="fixed clip set split over the ranks (strong scaling; default 8 x --clips); 0 = weak scaling, "
+                         "--clips per GPU")
+    ap.add_argument("--frames", type=int, default=None, help="backbone frames per clip (T)")
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--threshold", type=float, default=1.0, help="vitdet1024: TokenNormThreshold threshold")
+    ap.add_argument("--cast", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the EVT_GEMM=f32 side measurement")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel's launches with HIP events")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the per-frame launches (small --clips: "
                     "host-bound otherwise); implies --no-kernel-events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test)")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing test only: no GPU, a stub step (tests/test_dist_cpu.py)")
     args = ap.parse_args()
-    cast = None if args.cast in ("none", "fp32", "None") else args.cast
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    kind, block_class, frames, k, cast, grid = WORKLOADS[args.workload]
+    frames = args.frames if args.frames is not None else frames
+    k = args.k if args.k is not None else k
+    if args.cast is not None:
+        cast = None if args.cast in ("none", "fp32", "None") else args.cast
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -218,88 +513,191 @@ def main():
 
     _native.load()  # fail loudly here if the HIP library is missing
 
-    # Weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective).
-    sd, extra = seeded_state_dict()
+    # ---- clip set and its sharding ---------------------------------------------------------------------
+    if kind == "vitdet":
+        resident, total, scaling = 1, world, "weak"   # one video stream per GPU: videos shard like clips
+    else:
+        resident = args.clips
+        total = 8 * resident if args.total_clips is None else args.total_clips
+        scaling = "strong" if total > 0 else "weak"
+        if total == 0:
+            total = world * resident
+    my_batches = batches_for_rank(total, world, rank, resident)
+
+    # ---- weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective) ------
+    sd = seeded_state_dict() if kind == "vivit" else vitdet_state_dict()
     if world > 1:
-        broadcast_weights(sd, extra, device, rank)
-    model = SpatialModel(sd, extra, cast, args.k, device)
+        broadcast_weights(sd, {}, device, rank)
+    if kind == "vivit":
+        model = SpatialModel(sd, cast, k, device, block_class=block_class)
+        data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device) for b in my_batches]
+        policy = ("topk", k)
+    else:
+        from eventful_transformer import policies
+        if args.workload == "vitdet672":
+            policy = ("topk", k)
+            model = DetModel(sd, cast, lambda: policies.TokenNormTopK(k=k), grid, device)
+            data = [synthetic_clips(1, frames, k, 1000 + b[0], device, tokens=grid * grid) for b in my_batches]
+        else:
+            policy = ("thr", args.threshold)
+            model = DetModel(sd, cast, lambda: policies.TokenNormThreshold(threshold=args.threshold), grid, device)
+            data = [threshold_stream(frames, 1000 + b[0], device, grid * grid) for b in my_batches]
     if args.graphs:
         model.use_graphs()
         args.no_kernel_events = True
-    clips = synthetic_clips(args.clips, args.frames, args.k, 1000 + rank, device)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        out = None
+        for clips in data:
+            out = model.clip(clips)
+        return out
+
+    timed_kernel = "gemm" if kind == "vivit" else "attn"
     with torch.inference_mode():
         for _ in range(args.warmup):
-            model.clip(clips)
+            step()
         events = None if args.no_kernel_events else []
-        _native.GEMM_EVENTS = events
+        _native.set_kernel_events(timed_kernel, events)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model.clip(clips)
+            step()
         sync_all()
         elapsed = time.perf_counter() - t0
-        _native.GEMM_EVENTS = None
+        _native.set_kernel_events(timed_kernel, None)
 
     if world > 1:
         elapsed = max_over_ranks(elapsed, device)
-
-    frames_total = world * args.clips * args.frames * args.steps
+    clips_per_step = total
+    frames_total = clips_per_step * frames * args.steps
     value = frames_total / elapsed
 
-    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
-    # read in-process); profiles/*/pmc_traffic_*.json holds the per-launch figure for the workload it names.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_B{args.clips}.json")))
-        wl = pmc["workload"]
-        if (wl["clips"], wl["frames"], wl["k"], wl["cast"], wl["gemm"]) == (args.clips, args.frames, args.k, cast, _native.GEMM_MODE):
-            traffic = pmc["gated_linear_hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
     roofline = None
     if events:
         ms = sum(ev[0].elapsed_time(ev[1]) for ev in events)
-        flops = sum(ev[2] for ev in events)
+        work = sum(ev[2] for ev in events)
         launches = sum(ev[3] for ev in events)
-        achieved = flops / (ms * 1e-3) / 1e12
-        split = _native.GEMM_MODE == "split"
-        # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
-        # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
-        # of `frac`; `mfma_issue_frac` = issued bf16 MFMA FLOP/s over the same peak (matrix-pipe utilisation).
-        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        roofline = {"bound": "mfma",
-                    "kernel": ("gated_linear_split_kernel" if split else "gated_linear_kernel") +
-                              " (evt_gated_linear / evt_gated_mlp)",
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01/pmc_traffic_B<clips>.json",
-                    "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
-                    "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
-                    "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+        if timed_kernel == "gemm":
+            achieved = work / (ms * 1e-3) / 1e12
+            split = _native.GEMM_MODE == "split"
+            # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
+            # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
+            # of `frac`; `mfma_issue_frac` = issued bf16 MFMA FLOP/s over the same peak (matrix-pipe utilisation).
+            peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            traffic, traffic_src = pmc_traffic(resident, frames, k, cast, _native.GEMM_MODE)
+            roofline = {"bound": "mfma", "kernel": _native.gemm_kernel_name() + " (evt_gated_linear / evt_gated_mlp)",
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_note": (f"HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), {traffic_src}"
+                                         if traffic_src else "no PMC file under profiles/ matches this tree's GEMM source: null"),
+                        "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
+                        "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
+                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+        else:
+            achieved = work / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "softmax_av_gated_kernel / attn_dense_kernel (global-block attention)",
+                        "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                        "algorithmic_bytes": "N^2 state read once + gate-reference gather/scatter + A.v state RMW per launch",
+                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
 
+    line = None
     if rank == 0:
+        wl = {"vivit": f"ViViT-B spatial {frames}x224^2 (N=197, D=768, 12 {block_class}s)" +
+                       (f" top-k r={k}" if k else " dense") + f", T={frames} frames/clip incl. dense first frame, matmul_2_cast={cast}",
+              "vitdet": f"ViTDet-B backbone {grid * 16}^2 (N={grid * grid}, 4 global EventfulBlocks + 8 windowed "
+                        f"EventfulTokenwiseBlocks) policy={policy}, T={frames} frames/video incl. first, matmul_2_cast={cast}, "
+                        "one video stream per GPU"}[kind]
         line = {
-            "metric": METRIC, "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if args.workload == "vivit16" else f"frames/sec/GPU {args.workload}",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
-                                                  (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
+            "scaling": scaling, "vs_baseline": None,
+            "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
+                      (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
             "data": "synthetic", "per_gpu": round(value / world, 2),
-            "config": {"workload": f"ViViT-B spatial {args.frames}x224^2 (N=197, D=768, 12 EventfulBlocks) top-k r={args.k}, "
-                                   f"T={args.frames} frames/clip incl. dense first frame, matmul_2_cast={cast}",
-                       "clips_per_gpu": args.clips, "frames_per_step": args.clips * args.frames,
-                       "parallelism": f"clip-sharded x{world}", "launch": "hip-graph replay" if args.graphs else "eager"},
+            "config": {"workload": wl, "clips_per_step": clips_per_step, "resident_clips_per_gpu": resident,
+                       "batches_per_gpu_per_step": len(my_batches), "frames_per_step": clips_per_step * frames,
+                       "parallelism": f"clip-sharded x{world} (clip i -> rank i mod {world})",
+                       "launch": "hip-graph replay" if args.graphs else "eager"},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, extra, cast, args.k, args.frames)
+    # ---- after the timed region, rank 0 at N = 1 only: self-check, exact-fp32 side number, CPU baseline ------
+    if rank == 0 and world == 1:
+        if not args.no_check and kind == "vivit":
+            line["check"] = self_check_vivit(model, data[0], sd, cast, k)
+        if not args.no_exact and kind == "vivit" and _native.GEMM_MODE == "split":
+            line["exact_fp32_frames_s"] = exact_fp32_rate(model, data[0], frames)
+        if not args.no_cpu_baseline:
+            if kind == "vivit":
+                line["cpu_baseline"] = cpu_baseline_vivit(sd, cast, k, frames, kind=block_class)
+            else:
+                n_cpu = 3 if grid <= 42 else 2
+                line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu].cpu())
+    if rank == 0:
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def exact_fp32_rate(model, clips, frames):
+    """The same resident batch with the gated linears and q.k^T on the exact fp32-input MFMA (EVT_GEMM=f32
+    arithmetic): one warm-up pass + two timed passes."""
+    from eventful_transformer import _native
+
+    saved = (_native.GEMM_MODE, _native.QK_SPLIT)
+    _native.GEMM_MODE, _native.QK_SPLIT = "f32", False
+    try:
+        with torch.inference_mode():
+            model.clip(clips)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                model.clip(clips)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+    finally:
+        _native.GEMM_MODE, _native.QK_SPLIT = saved
+        model.reset()
+    return round(2 * clips.shape[1] * frames / el, 1)
+
+
+def dry_run(args, world, rank):
+    """Plumbing only (CPU, gloo): sharding + broadcast + max-reduce + the single JSON line, with a stub step."""
+    if world > 1:
+        dist.init_process_group(args.backend)
+    dev = torch.device("cpu")
+    sd = {"w": torch.full((4,), float(rank + 1))}
+    if world > 1:
+        broadcast_weights(sd, {}, dev, rank)
+    total = 8 * args.clips if args.total_clips is None else args.total_clips
+    scaling = "strong" if total > 0 else "weak"
+    if total == 0:
+        total = world * args.clips
+    mine = batches_for_rank(total, world, rank, args.clips)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for b in mine:
+            time.sleep(0.001 * len(b))
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = max_over_ranks(elapsed, dev)
+        counts = [None] * world
+        dist.all_gather_object(counts, sum(len(b) for b in mine))
+    else:
+        counts = [sum(len(b) for b in mine)]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": round(total * args.steps / elapsed, 2), "unit": "clips/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling,
+                          "clips_per_rank": counts, "weights_from_rank0": bool(float(sd["w"][0]) == 1.0),
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

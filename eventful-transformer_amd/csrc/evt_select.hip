@@ -122,6 +122,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
                   int32_t* rest, void* stream) {
   const size_t lds = (size_t)(N + 256 + 8 + 4) * sizeof(uint32_t);
+  if (lds > 64 * 1024)  // N near SEL_MAX_N: above the 64 KB default dynamic-LDS limit
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), lds, evt_stream(stream), norms, N, k, thr, mode, kcap,
                      idx, count, rest);
   return evt_check_launch("evt_select");

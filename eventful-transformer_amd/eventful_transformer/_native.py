@@ -238,19 +238,32 @@ def scatter_rows(x, buf, idx, count, B, N, F, kcap):
     _check(load().evt_scatter_rows(_p(x), _p(buf), _p(idx), _p(count), B, N, F, kcap, _stream()))
 
 
-# bench.py sets this to a list to bracket every launch of the dominant kernel with HIP events on the
-# launch stream: entries are (start_event, end_event, algorithmic_flops).
-GEMM_EVENTS = None
+# bench.py brackets every launch of a workload's dominant kernel family with HIP events on the launch stream:
+# set_kernel_events("gemm" | "attn", list) -> entries (start_event, end_event, algorithmic work, launches), where
+# work is FLOP for "gemm" (K3/K7) and bytes for "attn" (the global-block attention kernels K5+K6 / K8).
+_EVENTS = {}
 
 
-def _timed(flops, fn, launches=1):
-    if GEMM_EVENTS is None:
+def set_kernel_events(family, sink):
+    if sink is None:
+        _EVENTS.pop(family, None)
+    else:
+        _EVENTS[family] = sink
+
+
+def _timed(family, work, fn, launches=1):
+    sink = _EVENTS.get(family)
+    if sink is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
-    GEMM_EVENTS.append((s, e, flops, launches))
+    sink.append((s, e, work, launches))
+
+
+def gemm_kernel_name():
+    return "gated_linear_split_kernel" if GEMM_MODE == "split" else "gated_linear_kernel"
 
 
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
@@ -286,7 +299,7 @@ def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count,
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
                    _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes)
-    _timed(2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
+    _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
@@ -297,7 +310,7 @@ def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd,
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
                 _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes)
-    _timed(4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
+    _timed("gemm", 4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
 
 
 def _ptr_off(t, elems):
@@ -367,7 +380,11 @@ def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv,
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
                       N if Nk is None else Nk, gw if qw is None else qw)
-    _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream()))
+    # algorithmic bytes: q.k^T state read once, gate-reference columns read + rewritten, v delta / old reads,
+    # A.v state read-modify-write, fp32 output
+    es, nk = product.element_size() if store == EVT_F32 else 2, (N if Nk is None else Nk)
+    work = B * (4.0 * H * N * nk + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D + 4.0 * N * D)
+    _timed("attn", work, lambda: _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream())))
 
 
 def attention_dense_fits(N, D, H):
@@ -380,7 +397,12 @@ def attention_dense(qkv, G, H, N, D, scale, store, out_f32=None, rel_y=None, rel
     """K8: q.k^T + rel-pos + softmax + A.v of whole groups in one launch (scores never reach HBM)."""
     d = AttnDenseDesc(_p(qkv), _p(rel_y), _p(rel_x), gh, gw, qw, _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
                       _p(out_f32), _p(product), _p(a_state), _p(pv), G, H, N, D, float(scale), store)
-    _check(load().evt_attention_dense(ctypes.byref(d), _stream()))
+    es = 4 if store == EVT_F32 else 2
+    work = G * (12.0 * N * D + 4.0 * N * D) + (G * H * N * N * (4.0 + es) + G * N * D * es if product is not None else 0.0)
+    if product is not None:   # only the state-producing (global-block) form is part of the "attn" family
+        _timed("attn", work, lambda: _check(load().evt_attention_dense(ctypes.byref(d), _stream())))
+    else:
+        _check(load().evt_attention_dense(ctypes.byref(d), _stream()))
 
 
 def av(a1, v1, lda, B, H, N, K, D, store, pv=None, out_f32=None, a2=None, v2=None, count=None, gated=False,

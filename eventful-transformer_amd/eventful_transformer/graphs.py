@@ -24,6 +24,7 @@ import torch
 
 from eventful_transformer import _native
 from eventful_transformer.counting import CountedLinear
+from eventful_transformer.utils import PositionEncoding, RelativePositionEmbedding
 
 
 class FrameGraphs:
@@ -76,9 +77,16 @@ class FrameGraphs:
                 self.model.reset()
                 self._fwd(self._x)           # eager once: scratch pool, split weight planes, window maps
                 self.model.reset()
-                for m in self.model.modules():   # reset() dropped the bf16 weight planes: rebuild them outside the graph
+                # reset() dropped every cache that is rebuilt lazily: the bf16 weight planes, the rel-pos tables and the
+                # sized position encoding.  Rebuild them OUTSIDE the capture -- the bicubic resize creates host tensors
+                # and copies them to the device, which must not become graph nodes reading freed host memory.
+                for m in self.model.modules():
                     if isinstance(m, CountedLinear):
                         m.split_planes()
+                    elif isinstance(m, RelativePositionEmbedding):
+                        m.tables()
+                    elif isinstance(m, PositionEncoding):
+                        m.sized()
                 self._first = self._capture()
             graph, y = self._first
             graph.replay()

@@ -7,7 +7,7 @@ box).  For every case it (1) builds the reference module, loads the seeded param
 does, (2) runs it, (3) runs `oracle/eventful_oracle.py` on the same inputs and asserts the two
 agree BIT-FOR-BIT (same ATen CPU kernels), and (4) stores inputs-by-seed + expected outputs.
 
-Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vitdet672|vitdet1024]
+Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vivit_k64|vitdet672|vitdet1024|counts]
 """
 import argparse
 import hashlib
@@ -243,55 +243,70 @@ def block_params_of(sd, i):
     return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
 
 
+def _vivit_case(pack, mode, cast, steps, k, seed=77):
+    """One ViViT-B spatial sub-model run (197 tokens, 12 EventfulBlocks, top-k `k`, `steps` frames) through the REAL
+    reference backbone and the oracle; stores features, index sets and margins under the `mode__` prefix."""
+    dim, depth, heads, N = 768, 12, 12, 196
+    sd = backbone_params(depth, dim, 4, seed, N + 1)
+    rs = np.random.RandomState(seed + 1)
+    cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
+    ln_w = torch.from_numpy((1 + rs.standard_normal(dim) * 0.05).astype(np.float32))
+    ln_b = torch.from_numpy((rs.standard_normal(dim) * 0.05).astype(np.float32))
+    cfg = dict(dim=dim, heads=heads, mlp_ratio=4)
+    if cast:
+        cfg["matmul_2_cast"] = cast
+    ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(14, 14),
+                      block_class="EventfulBlock", has_class_token=True).eval()
+    ref.load_state_dict(sd, strict=True)
+    ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
+    blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast=cast)
+              for i in range(depth)]
+    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
+    ob.set_policy(lambda: O.TopK(k))
+    model = O.ViViTSpatialOracle(ob, cls, ln_w, ln_b)
+    xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2, small=0.01)
+    feats, idx_all, margins = [], [], []
+    t0 = time.time()
+    with torch.inference_mode():
+        for t in range(steps):
+            # reference: vivit.py:293-303 restated inline around the REAL backbone
+            x = torch.concat([cls.expand(1, 1, dim), xs[t]], dim=1)
+            y = torch.nn.functional.layer_norm(ref(x), (dim,), ln_w, ln_b, 1e-6)[:, 0]
+            y_o = model.forward(xs[t])
+            assert torch.equal(y, y_o), (mode, t, float((y - y_o).abs().max()))
+            feats.append(y.clone())
+            if t > 0:
+                for bi, blk in enumerate(ref.blocks):
+                    for g in ("qkv_gate", "projection_gate", "mlp_gate"):
+                        pol = getattr(blk, g).policy
+                        idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
+                        margins.append(topk_margin(pol.last_input, k))
+    print(f"vivit {mode}: {steps} steps k={k} {time.time() - t0:.1f}s min margin {min(margins):.2e} "
+          f"median {float(np.median(margins)):.2e}")
+    pack[f"{mode}__features"] = torch.stack(feats).numpy()
+    pack[f"{mode}__idx"] = np.stack(idx_all).reshape(steps - 1, depth, 3, 1, k)
+    pack[f"{mode}__margins"] = np.asarray(margins).reshape(steps - 1, depth, 3)
+    pack[f"{mode}__seed"] = np.int64(seed)
+    pack[f"{mode}__k"] = np.int64(k)
+    pack[f"{mode}__sha_qkv0"] = np.bytes_(sha(sd["blocks.0.qkv.weight"]))
+    pack[f"{mode}__sha_x"] = np.bytes_(sha(xs))
+
+
 def gen_vivit():
     """ViViT-B spatial sub-model (BASELINE configs 1/2): 197 tokens, 12 EventfulBlocks, k=128."""
-    dim, depth, heads, N, k = 768, 12, 12, 196, 128
     pack = {"torch_version": np.bytes_(torch.__version__)}
     for mode, cast, steps in (("fp32", None, 6), ("bf16", "bfloat16", 6)):
-        seed = 77
-        sd = backbone_params(depth, dim, 4, seed, N + 1)
-        rs = np.random.RandomState(seed + 1)
-        cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
-        ln_w = torch.from_numpy((1 + rs.standard_normal(dim) * 0.05).astype(np.float32))
-        ln_b = torch.from_numpy((rs.standard_normal(dim) * 0.05).astype(np.float32))
-        cfg = dict(dim=dim, heads=heads, mlp_ratio=4)
-        if cast:
-            cfg["matmul_2_cast"] = cast
-        ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(14, 14),
-                          block_class="EventfulBlock", has_class_token=True).eval()
-        ref.load_state_dict(sd, strict=True)
-        ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
-        blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast=cast)
-                  for i in range(depth)]
-        ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
-        ob.set_policy(lambda: O.TopK(k))
-        model = O.ViViTSpatialOracle(ob, cls, ln_w, ln_b)
-        xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2, small=0.01)
-        feats, idx_all, margins = [], [], []
-        t0 = time.time()
-        with torch.inference_mode():
-            for t in range(steps):
-                # reference: vivit.py:293-303 restated inline around the REAL backbone
-                x = torch.concat([cls.expand(1, 1, dim), xs[t]], dim=1)
-                y = torch.nn.functional.layer_norm(ref(x), (dim,), ln_w, ln_b, 1e-6)[:, 0]
-                y_o = model.forward(xs[t])
-                assert torch.equal(y, y_o), (mode, t, float((y - y_o).abs().max()))
-                feats.append(y.clone())
-                if t > 0:
-                    for bi, blk in enumerate(ref.blocks):
-                        for g in ("qkv_gate", "projection_gate", "mlp_gate"):
-                            pol = getattr(blk, g).policy
-                            idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
-                            margins.append(topk_margin(pol.last_input, k))
-        print(f"vivit {mode}: {steps} steps {time.time() - t0:.1f}s min margin {min(margins):.2e} "
-              f"median {float(np.median(margins)):.2e}")
-        pack[f"{mode}__features"] = torch.stack(feats).numpy()
-        pack[f"{mode}__idx"] = np.stack(idx_all).reshape(steps - 1, depth, 3, 1, k)
-        pack[f"{mode}__margins"] = np.asarray(margins).reshape(steps - 1, depth, 3)
-        pack[f"{mode}__seed"] = np.int64(seed)
-        pack[f"{mode}__sha_qkv0"] = np.bytes_(sha(sd["blocks.0.qkv.weight"]))
-        pack[f"{mode}__sha_x"] = np.bytes_(sha(xs))
+        _vivit_case(pack, mode, cast, steps, 128)
     np.savez_compressed(os.path.join(OUT, "vivit_b.npz"), **pack)
+
+
+def gen_vivit_k64():
+    """BASELINE config 4 shape: the same sub-model stepped through T = 32 frames with top-k r = 64 (bf16 A.v cast,
+    the reference's timing setting, and fp32)."""
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    for mode, cast in (("fp32", None), ("bf16", "bfloat16")):
+        _vivit_case(pack, mode, cast, 32, 64)
+    np.savez_compressed(os.path.join(OUT, "vivit_b_k64.npz"), **pack)
 
 
 def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed):
@@ -410,7 +425,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vitdet672": gen_vitdet672,
+    todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
             "vitdet1024": gen_vitdet1024, "counts": gen_counts}
     for name, fn in todo.items():
         if args.only in (None, name):

@@ -27,7 +27,16 @@ def _built_library():
     sys.path.insert(0, PKG_ROOT)
     import build as evt_build  # eventful-transformer_amd/build.py
 
+    import shutil
+
     lib = os.path.join(PKG_ROOT, "eventful_transformer", "libevt_hip.so")
-    if not os.path.exists(lib):
-        evt_build.build()
+    if evt_build.needs_build():
+        # stale or missing: rebuild (a no-op when up to date).  Without hipcc a stale library is an error, not
+        # something to test against silently.
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            evt_build.build()
+        elif not os.path.exists(lib):
+            raise RuntimeError("libevt_hip.so is missing and hipcc is not available")
+        else:
+            raise RuntimeError("libevt_hip.so is older than csrc/ and hipcc is not available to rebuild it")
     yield

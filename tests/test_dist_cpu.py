@@ -49,3 +49,33 @@ def test_two_rank_gloo_plumbing():
     assert all(ok for _, ok, _, _ in res)
     assert [t for _, _, t, _ in res] == [2.0, 2.0]              # MAX over ranks
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]  # clip i -> rank i mod world, disjoint cover
+
+
+def test_bench_launcher_starts_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` without torchrun: the launcher path starts the two ranks itself (child
+    torch.distributed.run), shards a fixed clip set clip i -> rank i mod 2 (strong scaling), broadcasts rank 0's
+    weights and prints ONE JSON line.  --dry-run/--backend gloo keeps it on the CPU with a stub step."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+                          "--clips", "3", "--total-clips", "7", "--dry-run", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["clips_per_rank"] == [4, 3] and line["weights_from_rank0"] is True
+
+
+def test_batches_for_rank_cover_the_clip_set():
+    import bench
+    for total, world, resident in [(2048, 8, 256), (2048, 1, 256), (7, 2, 3), (5, 8, 256)]:
+        seen = []
+        for r in range(world):
+            for b in bench.batches_for_rank(total, world, r, resident):
+                assert 0 < len(b) <= resident and all(c % world == r for c in b)
+                seen += b
+        assert sorted(seen) == list(range(total))

@@ -189,3 +189,13 @@ def test_bicubic_resize_matches_aten():
         got = bicubic_resize(x, size)
         assert got.shape == want.shape
         assert float((got - want).abs().max()) < 1e-5, (shape, size)
+
+
+def test_graft_entry_build_hook():
+    """The driver's build hook: compiles every HIP source for gfx950 and checks the ABI of the freshly built library."""
+    import __graft_entry__ as entry
+
+    entry.build()
+    from eventful_transformer import _native
+
+    assert _native.load().evt_version() == _native.ABI_VERSION

@@ -83,13 +83,16 @@ def test_invariants_small():
             assert torch.equal(buf[mask], before[mask])  # I2: untouched rows bit-unchanged
 
 
-@pytest.mark.parametrize("mode,cast", [("fp32", None), ("bf16", "bfloat16")])
-def test_vivit_b_features(golden_dir, mode, cast):
-    g = H.load_npz(os.path.join(golden_dir, "vivit_b.npz"))
-    model, sd, *_ = H.vivit_oracle(cast, seed=int(g[f"{mode}__seed"]))
+@pytest.mark.parametrize("fixture,k,mode,cast", [("vivit_b.npz", 128, "fp32", None), ("vivit_b.npz", 128, "bf16", "bfloat16"),
+                                                 ("vivit_b_k64.npz", 64, "bf16", "bfloat16")])
+def test_vivit_b_features(golden_dir, fixture, k, mode, cast):
+    """ViViT-B spatial sub-model, free-running oracle vs the reference's golden features / index sets: BASELINE
+    config 2 (k = 128, 6 frames) and config 4's shape (k = 64, T = 32 frames)."""
+    g = H.load_npz(os.path.join(golden_dir, fixture))
+    model, sd, *_ = H.vivit_oracle(cast, seed=int(g[f"{mode}__seed"]), k=k)
     feats = torch.from_numpy(g[f"{mode}__features"])
     idx = g[f"{mode}__idx"]
-    xs = O.make_token_stream(1, 196, 768, feats.shape[0], 128, seed=int(g[f"{mode}__seed"]) + 2, small=0.01)
+    xs = O.make_token_stream(1, 196, 768, feats.shape[0], k, seed=int(g[f"{mode}__seed"]) + 2, small=0.01)
     with torch.inference_mode():
         for t in range(feats.shape[0]):
             y = model.forward(xs[t])
