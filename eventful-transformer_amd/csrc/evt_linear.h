@@ -1,0 +1,47 @@
+// evt_linear.h -- types and helpers of the gated-linear kernels (evt_linear.hip).
+#pragma once
+#include "evt_common.h"
+
+struct LinArgs {
+  const float* A; int64_t lda; const int32_t* a_idx; int a_rows;
+  const float* W; const uint16_t* Wsplit; const float* bias;
+  float* out; int64_t ldo; const int32_t* o_idx; int o_rows;
+  const int32_t* count; float* p_upd;
+  int B, kcap, K, Nout, act;
+  float* ws; int64_t ws_bytes;
+};
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------
+// Split weights, "hl32" layout (evt_split_weights): every fp32 weight w is written w = hi + lo + O(2^-17 |w|) with
+// hi = rne_bf16(w), lo = rne_bf16(w - hi).  A row of K weights is stored as ceil(K / 32) groups of 128 bytes:
+// [32 x bf16 hi | 32 x bf16 lo] of 32 consecutive k (zero-filled past K), so one 32-wide k-tile of a row is ONE
+// aligned 128-byte line holding both planes.  Row pitch in bf16 elements:
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t hl32_pitch(int K) { return (int64_t)((K + 31) / 32) * 64; }
+// element offset (bf16 units, relative to the row) of the hi value of column k; the lo value sits 32 elements later
+__host__ __device__ inline int hl32_hi(int k) { return (k >> 5) * 64 + (k & 31); }
+
+// hi = rne_bf16(x), lo = rne_bf16(x - hi) for 4 values.  Written pairwise so that the fp32 image of hi comes from the
+// PACKED conversion by a shift / mask (12 VALU per float4: 4 v_cvt_pk, 2 shifts, 2 ands, 4 subs) instead of hipcc's
+// four extra single-element conversions (16).
+__device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* lo) {
+  union { bf16x2_t b; uint32_t u; } h01, h23, l01, l23;
+  h01.b = __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t);
+  h23.b = __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t);
+  const float r0 = v.x - __uint_as_float(h01.u << 16), r1 = v.y - __uint_as_float(h01.u & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(h23.u << 16), r3 = v.w - __uint_as_float(h23.u & 0xffff0000u);
+  l01.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
+  l23.b = __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t);
+  union { uint2 u; bf16x4_t b; } H, L;
+  H.u = make_uint2(h01.u, h23.u);
+  L.u = make_uint2(l01.u, l23.u);
+  *hi = H.b;
+  *lo = L.b;
+}

@@ -19,7 +19,7 @@
 // k-tile, two LDS buffers).  The epilogue adds bias, applies exact-erf GELU if asked, and scatters
 // rows through o_idx (TokenBuffer update fused); column-block 0 also refreshes the gate reference
 // rows (p_upd) from the A tile it already holds.
-#include "evt_common.h"
+#include "evt_linear.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -35,17 +35,6 @@ constexpr int GEMM_THREADS = 256;
 #define EVT_GEMM_MIN_BLOCKS 3   // 158 VGPRs, 3 x 42 KB LDS: three workgroups per CU (+8 % over two; measured)
 #endif
 constexpr int EVT_SPLITK_DYN_MAX_CLIPS = 32;  // device-side split-K choice reads every clip's count per workgroup
-
-struct LinArgs {
-  const float* A; int64_t lda; const int32_t* a_idx; int a_rows;
-  const float* W; const uint16_t* Wsplit; const float* bias;
-  float* out; int64_t ldo; const int32_t* o_idx; int o_rows;
-  const int32_t* count; float* p_upd;
-  int B, kcap, K, Nout, act;
-  float* ws; int64_t ws_bytes;
-};
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int ACT>
 __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArgs g) {
@@ -122,15 +111,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
 
   const int nk = (g.K + BK - 1) / BK;
   fetch(0);
-  // Gate reference refresh (K2 fused): column-block 0 owns the full A rows over the k loop.
-  const bool do_upd = (g.p_upd != nullptr) && (blockIdx.x == 0);
+  // Gate reference refresh (K2 fused): every column block stages the same A rows; block x writes back the k-tiles
+  // t with t % gridDim.x == x (dealt out so that no block waits for store acknowledgements in every k-tile).
+  const bool do_upd = g.p_upd != nullptr;
+  const int upd_n = gridDim.x, upd_x = blockIdx.x;
   float* u_ptr[4];
   if (do_upd) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) u_ptr[j] = g.p_upd + (a_ptr[j] - g.A);
   }
   stage(0);
-  if (do_upd) {
+  if (do_upd && upd_x == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (a_ok[j] && c4 * 4 < g.K) *reinterpret_cast<float4*>(u_ptr[j] + c4 * 4) = ra[j];
@@ -169,7 +160,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
     }
     if (t + 1 < nk) {
       stage(cur ^ 1);
-      if (do_upd) {
+      if (do_upd && ((t + 1) % upd_n) == upd_x) {
         const int kc = (t + 1) * BK + c4 * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -203,6 +194,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
         if (ncol[j] < g.Nout) {
           float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
           if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+#ifdef EVT_ABLATE_STORE   // timing experiment only: keep the arithmetic, drop (almost) every store
+          if (v == 12345.678f)
+#endif
           orow[ncol[j]] = v;
         }
       }
@@ -221,31 +215,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
 // Same tiling as the fp32 kernel: 128x128x32, 2x2 waves of 2x2 32x32 accumulators, A rows gathered
 // through a_idx during staging, scatter epilogue, p_upd refresh by column-block 0.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// hi = rne_bf16(x), lo = rne_bf16(x - hi) for 4 values.  Written pairwise so that the fp32 image of hi comes from the
-// PACKED conversion by a shift / mask (12 VALU per float4: 4 v_cvt_pk, 2 shifts, 2 ands, 4 subs) instead of hipcc's
-// four extra single-element conversions (16).
-__device__ __forceinline__ void split4(const float4 v, bf16x4_t* hi, bf16x4_t* lo) {
-  union { bf16x2_t b; uint32_t u; } h01, h23, l01, l23;
-  h01.b = __builtin_convertvector((f32x2_t){v.x, v.y}, bf16x2_t);
-  h23.b = __builtin_convertvector((f32x2_t){v.z, v.w}, bf16x2_t);
-  const float r0 = v.x - __uint_as_float(h01.u << 16), r1 = v.y - __uint_as_float(h01.u & 0xffff0000u);
-  const float r2 = v.z - __uint_as_float(h23.u << 16), r3 = v.w - __uint_as_float(h23.u & 0xffff0000u);
-  l01.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
-  l23.b = __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t);
-  union { uint2 u; bf16x4_t b; } H, L;
-  H.u = make_uint2(h01.u, h23.u);
-  L.u = make_uint2(l01.u, l23.u);
-  *hi = H.b;
-  *lo = L.b;
-}
-
 // Split-K factor for `tiles` live 128x128 output tiles and nk k-tiles: only when the tile count leaves most of
 // the 256 CUs idle; every split keeps >= 4 k-tiles.  Evaluated on the host from the shape, or -- with a
 // per-clip count (threshold policy: kcap = N, few live rows) -- on the device from the counts, identically by
@@ -350,21 +319,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   constexpr int WCH = TBK / 8;
   constexpr int WROWS = NT / WCH;
   constexpr int WJ = TBN / WROWS;
+  // weights in the hl32 layout (evt_linear.h): hi and lo of 32 consecutive k share one 128-byte line; rows are
+  // zero-filled up to a multiple of 32, so whole k-tiles can always be read
   const uint16_t* whi = g.Wsplit;
-  const uint16_t* wlo = g.Wsplit + (int64_t)g.Nout * g.K;
+  const uint16_t* wlo = g.Wsplit + 32;
+  const int64_t wpitch = hl32_pitch(g.K);
   const int wr0 = tid / WCH, wc8 = (tid % WCH) * 8;
 
   int64_t w_off[WJ];   // element offset of this thread's weight rows (clamped to the last row past Nout)
 #pragma unroll
   for (int j = 0; j < WJ; ++j) {
     const int n = n0 + wr0 + WROWS * j;
-    w_off[j] = (int64_t)(n < g.Nout ? n : g.Nout - 1) * g.K;
+    w_off[j] = (int64_t)(n < g.Nout ? n : g.Nout - 1) * wpitch;
   }
   float4 ra[AJ];
   uint4 rwh[WJ], rwl[WJ];
   auto fetch = [&](int k0) {
     const int kc = k0 + ac4 * 4;
-    const int kw = k0 + wc8;
+    const int kw = hl32_hi(k0 + wc8);
     if (k0 + TBK <= g.K) {
       // Whole k-tile inside K (always, when K % TBK == 0): unconditional loads, no per-load branch.  Masked rows
       // (a_ptr = A) and weight rows past Nout (clamped) contribute to accumulators that the epilogue never stores.
@@ -380,13 +352,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
 #pragma unroll
     for (int j = 0; j < AJ; ++j)
       ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool kin = k0 + wc8 < g.K;  // K % 8 == 0 is required by the launcher; the planes are zero past K anyway
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      const int n = n0 + wr0 + WROWS * j;
-      const bool ok = n < g.Nout && kw < g.K;  // K % 8 == 0 is required by the launcher
-      const int64_t o = (int64_t)n * g.K + kw;
-      rwh[j] = ok ? *reinterpret_cast<const uint4*>(whi + o) : make_uint4(0, 0, 0, 0);
-      rwl[j] = ok ? *reinterpret_cast<const uint4*>(wlo + o) : make_uint4(0, 0, 0, 0);
+      rwh[j] = kin ? *reinterpret_cast<const uint4*>(whi + w_off[j] + kw) : make_uint4(0, 0, 0, 0);
+      rwl[j] = kin ? *reinterpret_cast<const uint4*>(wlo + w_off[j] + kw) : make_uint4(0, 0, 0, 0);
     }
   };
   auto stage = [&]() {
@@ -412,7 +382,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const bool do_upd = (g.p_upd != nullptr) && (bn == 0);
+  // Gate reference refresh (K2 fused).  Every column tile of a row tile stages the same activation rows, so the
+  // refresh is dealt out over them: column tile bn writes back the k-tiles t with t % tiles_n == bn.  (All of it
+  // in column tile 0 made those tiles -- one in tiles_n -- wait for 4 store acknowledgements in every k-tile:
+  // +94 us on the 451 us QKV launch at B = 256.)
+  const bool do_upd = g.p_upd != nullptr;
   float* u_ptr[AJ];
   if (do_upd) {
 #pragma unroll
@@ -425,7 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   fetch(t0 * TBK);
   for (int t = t0; t < nk; ++t) {
     stage();
-    if (do_upd) {
+    if (do_upd && (t % tiles_n) == bn) {
       const int kc = t * TBK + ac4 * 4;
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
@@ -496,6 +470,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
         if (ncol[j] < g.Nout) {
           float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
           if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+#ifdef EVT_ABLATE_STORE   // timing experiment only: keep the arithmetic, drop (almost) every store
+          if (v == 12345.678f)
+#endif
           orow[ncol[j]] = v;
         }
       }
@@ -582,24 +559,30 @@ void launch_split(const LinArgs& a, hipStream_t s) {
   }
 }
 
-// fp32 (rows, cols) -> bf16 hi plane followed by bf16 lo plane, hi = rne(x), lo = rne(x - hi).
+// fp32 (rows, cols) -> hl32 planes (evt_linear.h): one thread per 4 consecutive columns of a row; groups past `cols`
+// are zero-filled.
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
-                                                            int64_t n) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  bf16x4_t h, l;
-  if (i + 4 <= n) {
-    split4(*reinterpret_cast<const float4*>(w + i), &h, &l);
-    *reinterpret_cast<bf16x4_t*>(out + i) = h;
-    *reinterpret_cast<bf16x4_t*>(out + n + i) = l;
-  } else {
-    for (int64_t q = i; q < n; ++q) {
-      const __bf16 hh = (__bf16)w[q];
-      const __bf16 ll = (__bf16)(w[q] - (float)hh);
-      reinterpret_cast<__bf16*>(out)[q] = hh;
-      reinterpret_cast<__bf16*>(out)[n + q] = ll;
-    }
+                                                            int64_t rows, int cols) {
+  const int64_t pitch = hl32_pitch(cols);
+  const int quads = (int)(pitch / 2 / 4);   // 4-column groups per (padded) row
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * quads) return;
+  const int64_t r = t / quads;
+  const int k = (int)(t - r * quads) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* src = w + r * cols + k;
+  if (k + 4 <= cols && ((r * cols + k) & 3) == 0) v = *reinterpret_cast<const float4*>(src);
+  else {
+    if (k < cols) v.x = src[0];
+    if (k + 1 < cols) v.y = src[1];
+    if (k + 2 < cols) v.z = src[2];
+    if (k + 3 < cols) v.w = src[3];
   }
+  bf16x4_t h, l;
+  split4(v, &h, &l);
+  uint16_t* dst = out + r * pitch + hl32_hi(k);
+  *reinterpret_cast<bf16x4_t*>(dst) = h;
+  *reinterpret_cast<bf16x4_t*>(dst + 32) = l;
 }
 
 int launch_linear(const LinArgs& a, void* stream) {
@@ -659,11 +642,17 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
   return launch_linear(fc2, stream);
 }
 
-extern "C" int evt_split_weights(const float* w, void* out, int64_t n, void* stream) {
-  EVT_REQUIRE(w != nullptr && out != nullptr && n >= 0, EVT_ERR_BAD_ARG, "evt_split_weights: bad arguments");
-  EVT_REQUIRE((n & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_split_weights: element count must be a multiple of 4");
-  if (n == 0) return EVT_OK;
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, evt_stream(stream), w,
-                     (uint16_t*)out, n);
+extern "C" int evt_split_weights(const float* w, void* out, int64_t rows, int64_t cols, void* stream) {
+  EVT_REQUIRE(w != nullptr && out != nullptr && rows >= 0 && cols > 0, EVT_ERR_BAD_ARG, "evt_split_weights: bad arguments");
+  EVT_REQUIRE(cols <= (1 << 24), EVT_ERR_BAD_SHAPE, "evt_split_weights: cols=%lld too large", (long long)cols);
+  if (rows == 0) return EVT_OK;
+  const int64_t work = rows * (hl32_pitch((int)cols) / 8);
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, evt_stream(stream), w,
+                     (uint16_t*)out, rows, (int)cols);
   return evt_check_launch("evt_split_weights");
+}
+
+extern "C" int64_t evt_split_weights_bytes(int64_t rows, int64_t cols) {
+  if (rows < 0 || cols <= 0) return 0;
+  return rows * hl32_pitch((int)cols) * 2;
 }

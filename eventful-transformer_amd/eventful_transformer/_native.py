@@ -20,11 +20,11 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 2   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 3   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
+    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense",
 )
 
@@ -112,6 +112,8 @@ def _bind(lib):
     lib.evt_target_arch.restype = c_char_p
     lib.evt_gated_linear_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.evt_gated_linear_workspace_bytes.restype = c_int64
+    lib.evt_split_weights_bytes.argtypes = [c_int64, c_int64]
+    lib.evt_split_weights_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
@@ -120,7 +122,7 @@ def _bind(lib):
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
         "evt_gated_mlp": [POINTER(MlpDesc), P],
-        "evt_split_weights": [P, P, c_int64, P],
+        "evt_split_weights": [P, P, c_int64, c_int64, P],
         "evt_qk": [POINTER(QkDesc), P],
         "evt_softmax_gate": [POINTER(SoftmaxDesc), P],
         "evt_v_gate": [P, c_int64, P, P, I, I, I, I, P, P, P, I, I, I, P, I, I, P, P],
@@ -274,12 +276,18 @@ DENSE_FUSED = os.environ.get("EVT_DENSE_FUSED", "1") != "0"   # K8 (evt_attentio
 
 
 def split_weight(W):
-    """Fresh bf16 hi/lo planes (2, out, in) of a weight matrix via evt_split_weights, or None when the
-    split path does not apply.  Callers cache the result (CountedLinear.split_planes)."""
-    if GEMM_MODE != "split" or (W.shape[-1] % 8) != 0:
+    """Fresh bf16 hi/lo planes of a (out, in) weight matrix via evt_split_weights, or None when the split path does
+    not apply.  Layout "hl32" (include/evt_abi.h): (out, ceil(in / 32), 2, 32) -- per row and group of 32 input
+    features, 32 hi values then 32 lo values (one 128-byte line).  Callers cache the result (CountedLinear.split_planes)."""
+    if GEMM_MODE != "split" or W.ndim != 2 or (W.shape[-1] % 8) != 0:
         return None
-    planes = torch.empty((2,) + tuple(W.shape), dtype=torch.bfloat16, device=W.device)
-    _check(load().evt_split_weights(_p(W.detach()), _p(planes), W.numel(), _stream()))
+    rows, cols = W.shape
+    Wc = W.detach()
+    if not Wc.is_contiguous():
+        Wc = Wc.contiguous()
+    planes = torch.empty((rows, (cols + 31) // 32, 2, 32), dtype=torch.bfloat16, device=W.device)
+    assert planes.numel() * 2 == load().evt_split_weights_bytes(rows, cols)
+    _check(load().evt_split_weights(_p(Wc), _p(planes), rows, cols, _stream()))
     return planes
 
 

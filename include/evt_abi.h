@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 2   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query */
+#define EVT_ABI_VERSION 3   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+                                 3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -150,13 +151,17 @@ EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
  * kernel. */
 EVT_API int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout, int32_t has_count);
 
-/* Split an fp32 weight matrix (n elements, n % 4 == 0) into two bf16 planes written back to back to
- * `out` (2*n bf16): hi = rne_bf16(w), lo = rne_bf16(w - hi).  With W_split set, K3/K7 compute
- * a.w = a_hi.w_hi + a_hi.w_lo + a_lo.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
- * (activations are split on the fly); the dropped a_lo.w_lo term is <= 2^-16 per product, i.e. fp32
- * activations still agree with the reference to ~1e-5 relative (tolerance 1e-3), at ~5x the
- * fp32-input MFMA rate.  W_split == NULL keeps the exact fp32 MFMA kernel. */
-EVT_API int evt_split_weights(const float* w, void* out, int64_t n, void* stream);
+/* Split an fp32 weight matrix (rows, cols) row-major into bf16 hi/lo planes, hi = rne_bf16(w), lo = rne_bf16(w - hi),
+ * in the "hl32" layout the GEMM kernels stream: every row is ceil(cols / 32) groups of 128 bytes
+ * [32 x bf16 hi | 32 x bf16 lo] of 32 consecutive columns (zero past `cols`), so one 32-wide k-tile of a row is one
+ * aligned 128-byte line holding both planes.  `out` must hold evt_split_weights_bytes(rows, cols) bytes.
+ * With W_split set, K3/K7 compute a.w = a_hi.w_hi + a_hi.w_lo + a_lo.w_hi on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (activations are split on the fly, in registers); the dropped a_lo.w_lo term is <= 2^-16 per product,
+ * i.e. fp32 activations still agree with the reference to ~1e-5 relative (tolerance 1e-3), at ~5x the fp32-input
+ * MFMA rate.  W_split == NULL keeps the exact fp32 MFMA kernel.  (The reference keeps fp32 weights only:
+ * counting.py:127-162.) */
+EVT_API int evt_split_weights(const float* w, void* out, int64_t rows, int64_t cols, void* stream);
+EVT_API int64_t evt_split_weights_bytes(int64_t rows, int64_t cols);
 
 /* K7  Gated MLP: hidden = GELU(A[rows].W1^T + b1) -> out[rows] = hidden.W2^T + b2, as two MFMA
  * launches sharing one compact `hidden` scratch (B*kcap, Dh) provided by the caller.

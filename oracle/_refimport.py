@@ -55,6 +55,18 @@ def _install_stubs():
                 "torchvision.io": tio,
             }
         )
+    if "detectron2" not in sys.modules:
+        # models/vitdet.py imports `LazyConfig`, `instantiate` and `ImageList` at module level (vitdet.py:2-3); only the
+        # detection heads (out of scope) use them.  Empty stand-ins let the file import so that its
+        # LinearEmbedding / ViTDetPreprocessing / SimplePyramid classes can be run for golden vectors.
+        d2 = types.ModuleType("detectron2")
+        d2c = types.ModuleType("detectron2.config")
+        d2s = types.ModuleType("detectron2.structures")
+        d2c.LazyConfig = type("LazyConfig", (), {})
+        d2c.instantiate = lambda *a, **k: None
+        d2s.ImageList = type("ImageList", (), {})
+        d2.config, d2.structures = d2c, d2s
+        sys.modules.update({"detectron2": d2, "detectron2.config": d2c, "detectron2.structures": d2s})
     try:
         import matplotlib.pyplot  # noqa: F401
     except Exception:

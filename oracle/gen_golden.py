@@ -7,7 +7,7 @@ box).  For every case it (1) builds the reference module, loads the seeded param
 does, (2) runs it, (3) runs `oracle/eventful_oracle.py` on the same inputs and asserts the two
 agree BIT-FOR-BIT (same ATen CPU kernels), and (4) stores inputs-by-seed + expected outputs.
 
-Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vivit_k64|vitdet672|vitdet1024|counts]
+Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vivit_k64|vitdet672|vitdet1024|counts|models]
 """
 import argparse
 import hashlib
@@ -420,13 +420,92 @@ def gen_counts():
     np.savez_compressed(os.path.join(OUT, "counts.npz"), **pack)
 
 
+# ------------------------------------------------------------------------------------------------
+# (iv) model wrappers around the backbone: end-to-end ViViT classification, ViTDet pre/post backbone
+# ------------------------------------------------------------------------------------------------
+def seeded_module_params(module, seed, std=0.02):
+    """Version-stable seeded values for every parameter of a module, drawn in SORTED key order (independent of the
+    registration order): normal(0, std); 1-d `.weight`s (LayerNorm scales) 1 + N(0, 0.05^2).  Same function in
+    tests/helpers.py."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, p in sorted(module.state_dict().items()):
+        v = (rs.standard_normal(tuple(p.shape)) * std).astype(np.float32)
+        if "layer_norm.weight" in name or (name.endswith(".weight") and p.ndim == 1):
+            v = (1.0 + rs.standard_normal(tuple(p.shape)) * 0.05).astype(np.float32)
+        sd[name] = torch.from_numpy(v)
+    return sd
+
+
+def gen_models():
+    import yaml
+    from models.vivit import FactorizedViViT
+    from models.vitdet import LinearEmbedding, SimplePyramid, ViTDetPreprocessing
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+
+    # ---- FactorizedViViT end to end (vivit.py:98-150): uint8 clip -> class probabilities -----------------
+    cfg = yaml.safe_load(open("/root/reference/configs/models/vivit_b_kinetics400.yml"))["model"]
+    cfg.update(spatial_views=1, temporal_views=2)
+    cfg["spatial_config"]["block_class"] = "EventfulBlock"
+    k, seed = 128, 501
+    model = FactorizedViViT(**cfg).eval()
+    model.load_state_dict(seeded_module_params(model, seed), strict=True)
+    ref_set_policies(model, lambda: rpolicies.TokenNormTopK(k))
+    rs = np.random.RandomState(seed + 1)
+    base = rs.randint(0, 256, size=(1, 1, 3, 224, 224)).astype(np.uint8)
+    frames = [base[:, 0]]
+    for t in range(1, 80):   # a video that changes in a few 16x16 patches per frame
+        f = frames[-1].copy()
+        for _ in range(40):
+            y, x = rs.randint(0, 14) * 16, rs.randint(0, 14) * 16
+            f[:, :, y:y + 16, x:x + 16] = rs.randint(0, 256, size=(1, 3, 16, 16))
+        frames.append(f)
+    clip = torch.from_numpy(np.stack(frames, axis=1))          # (1, 80, 3, 224, 224) uint8
+    logits = {}
+    model.classifier.register_forward_hook(lambda m, i, o: logits.__setitem__("v", o.detach().clone()))
+    feats = {}
+    model.temporal_model.register_forward_pre_hook(lambda m, i: feats.__setitem__("v", i[0].detach().clone()))
+    t0 = time.time()
+    with torch.inference_mode():
+        probs = model(clip)
+    print(f"models: FactorizedViViT 2 views x 16 steps {time.time() - t0:.1f}s, top prob {float(probs.max()):.5f}")
+    pack["vivit__seed"] = np.int64(seed)
+    pack["vivit__k"] = np.int64(k)
+    pack["vivit__clip_sha"] = np.bytes_(sha(clip))
+    pack["vivit__probs"] = probs.numpy()
+    pack["vivit__logits"] = logits["v"].numpy()
+    pack["vivit__spatial_features"] = feats["v"].numpy()
+
+    # ---- ViTDet pre-backbone and pyramid (vitdet.py:17-125,223-251) ------------------------------------------
+    seed = 601
+    pre = ViTDetPreprocessing((3, 224, 256), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
+    emb = LinearEmbedding(3, 768, (16, 16)).eval()
+    emb.load_state_dict(seeded_module_params(emb, seed), strict=True)
+    pyr = SimplePyramid([4.0, 2.0, 1.0, 0.5], 768, 256).eval()
+    pyr.load_state_dict(seeded_module_params(pyr, seed + 1, std=0.05), strict=True)
+    rs = np.random.RandomState(seed + 2)
+    frame = torch.from_numpy(rs.randint(0, 256, size=(1, 3, 200, 250)).astype(np.uint8))
+    tokens = torch.from_numpy(rs.standard_normal((1, 768, 14, 16)).astype(np.float32))
+    with torch.inference_mode():
+        img = pre(frame.float() / 255.0)
+        tok = emb(img)
+        maps = pyr(tokens)
+    pack["vitdet__seed"] = np.int64(seed)
+    pack["vitdet__image_slice"] = img[:, :, ::7, ::9].numpy()
+    pack["vitdet__tokens"] = tok[:, :, ::8].numpy()
+    for i, m in enumerate(maps):
+        pack[f"vitdet__p{i + 2}"] = m[:, ::8].numpy()
+        print(f"models: pyramid p{i + 2} {tuple(m.shape)} |max| {float(m.abs().max()):.3f}")
+    np.savez_compressed(os.path.join(OUT, "models.npz"), **pack)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
-            "vitdet1024": gen_vitdet1024, "counts": gen_counts}
+            "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models}
     for name, fn in todo.items():
         if args.only in (None, name):
             fn()

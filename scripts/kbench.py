@@ -55,7 +55,7 @@ def main():
     b3, b4, b1 = torch.zeros(3 * D, device=dev), torch.zeros(4 * D, device=dev), torch.zeros(D, device=dev)
     qkv = torch.randn(B, N, 3 * D, device=dev, generator=g)
     buf = torch.empty(B, N, D, device=dev)
-    hidden = torch.empty(B * k, 4 * D, device=dev)
+    hidden = torch.randn(B * k, 4 * D, device=dev, generator=g)
     product = torch.randn(B, H, N, N, device=dev, generator=g)
     ap_ = torch.rand(B, H, N, N, device=dev, generator=g).to(sdt)
     vp = torch.randn(B, N, D, device=dev, generator=g).to(sdt)
@@ -82,6 +82,10 @@ def main():
                        ("TF", 2.0 * M * D * 3 * D)),
         "linear_proj": (lambda: n.gated_linear(x, D, idx, N, Wp, b1, buf, D, idx, N, None, p, B, k, D, D, W_split=Sp),
                         ("TF", 2.0 * M * D * D)),
+        "linear_mlp1_gelu": (lambda: n.gated_linear(x, D, idx, N, W1, b4, hidden, 4 * D, None, k, None, p, B, k, D, 4 * D, act=n.ACT_GELU,
+                                                    W_split=S1), ("TF", 2.0 * M * D * 4 * D)),
+        "linear_mlp2": (lambda: n.gated_linear(hidden, 4 * D, None, k, W2, b1, buf, D, idx, N, None, None, B, k, 4 * D, D, W_split=S2),
+                        ("TF", 2.0 * M * D * 4 * D)),
         "mlp": (lambda: n.gated_mlp(x, D, idx, N, W1, b4, W2, b1, hidden, buf, D, None, p, B, k, D, 4 * D, W1_split=S1, W2_split=S2),
                 ("TF", 4.0 * M * D * 4 * D)),
         "linear_dense_qkv": (lambda: n.gated_linear(x, D, None, B * N, Wqkv, b3, qkv, 3 * D, None, B * N, None, None,

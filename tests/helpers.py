@@ -173,3 +173,38 @@ def product_vivit(sd, cast, device="cuda"):
     res = bb.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     return bb.eval().to(device)
+
+
+def seeded_module_params(module, seed, std=0.02):
+    """Same generator as oracle/gen_golden.py::seeded_module_params (sorted key order => independent of the
+    registration order; numpy RandomState => version-stable)."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, p in sorted(module.state_dict().items()):
+        v = (rs.standard_normal(tuple(p.shape)) * std).astype(np.float32)
+        if "layer_norm.weight" in name or (name.endswith(".weight") and p.ndim == 1):
+            v = (1.0 + rs.standard_normal(tuple(p.shape)) * 0.05).astype(np.float32)
+        sd[name] = torch.from_numpy(v)
+    return sd
+
+
+def synthetic_video(seed, frames=80):
+    """(1, frames, 3, 224, 224) uint8 video of gen_golden.gen_models: 40 random 16x16 patches change per frame."""
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, 256, size=(1, 1, 3, 224, 224)).astype(np.uint8)
+    out = [base[:, 0]]
+    for t in range(1, frames):
+        f = out[-1].copy()
+        for _ in range(40):
+            y, x = rs.randint(0, 14) * 16, rs.randint(0, 14) * 16
+            f[:, :, y:y + 16, x:x + 16] = rs.randint(0, 256, size=(1, 3, 16, 16))
+        out.append(f)
+    return torch.from_numpy(np.stack(out, axis=1))
+
+
+VIVIT_B_CONFIG = dict(   # configs/models/vivit_b_kinetics400.yml of the reference, with 1 spatial x 2 temporal views
+    classes=400, input_shape=[32, 3, 224, 224], normalize_mean=0.45, normalize_std=0.225, spatial_views=1,
+    temporal_stride=2, temporal_views=2, tubelet_shape=[2, 16, 16],
+    spatial_config=dict(depth=12, position_encoding_size=[14, 14], block_config=dict(dim=768, heads=12, mlp_ratio=4),
+                        block_class="EventfulBlock"),
+    temporal_config=dict(depth=4, position_encoding_size=[16], block_config=dict(dim=768, heads=12, mlp_ratio=4)))

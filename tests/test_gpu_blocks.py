@@ -133,8 +133,8 @@ def _grab_index_sets(bb, k, sink):
     return [blk.register_forward_hook(grab) for blk in bb.blocks]
 
 
-@pytest.mark.parametrize("fixture,k,mode,cast,tol", [("vivit_b.npz", 128, "fp32", None, 1e-3), ("vivit_b.npz", 128, "bf16", "bfloat16", 5e-2),
-                                                     ("vivit_b_k64.npz", 64, "fp32", None, 1e-3), ("vivit_b_k64.npz", 64, "bf16", "bfloat16", 5e-2)])
+@pytest.mark.parametrize("fixture,k,mode,cast,tol", [("vivit_b.npz", 128, "fp32", None, 1e-3), ("vivit_b.npz", 128, "bf16", "bfloat16", 1e-1),
+                                                     ("vivit_b_k64.npz", 64, "fp32", None, 1e-3), ("vivit_b_k64.npz", 64, "bf16", "bfloat16", 1e-1)])
 def test_vivit_b_full_size(golden_dir, fixture, k, mode, cast, tol):
     """ViViT-B spatial model, 197 tokens, 12 EventfulBlocks, B=1, FREE-RUNNING against the reference's golden
     class-token features and gate index sets: BASELINE config 2 (k=128, 6 frames) and config 4's shape (k=64,

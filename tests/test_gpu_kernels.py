@@ -136,19 +136,25 @@ def gemm_mode(request):
     n.GEMM_MODE = old
 
 
-def test_split_weights_planes():
+@pytest.mark.parametrize("rows,cols", [(96, 64), (50, 72), (7, 200), (33, 768)])
+def test_split_weights_planes(rows, cols):
+    """evt_split_weights: hi = rne_bf16(w), lo = rne_bf16(w - hi) in the hl32 layout (rows, ceil(cols/32), 2, 32),
+    zero-filled past `cols`."""
     n = native()
     g = torch.Generator().manual_seed(1)
-    W = (torch.randn(96, 64, generator=g) * torch.logspace(-6, 3, 64)).to(DEV)
+    W = (torch.randn(rows, cols, generator=g) * torch.logspace(-6, 3, cols)).to(DEV)
     old, n.GEMM_MODE = n.GEMM_MODE, "split"
     try:
         planes = n.split_weight(W)
     finally:
         n.GEMM_MODE = old
-    hi = W.to(torch.bfloat16)
-    lo = (W - hi.float()).to(torch.bfloat16)
-    assert torch.equal(planes[0], hi) and torch.equal(planes[1], lo)
-    rel = ((planes[0].float() + planes[1].float() - W).abs() / W.abs().clamp_min(1e-30)).max()
+    groups = (cols + 31) // 32
+    assert planes.shape == (rows, groups, 2, 32)
+    Wp = torch.nn.functional.pad(W, (0, groups * 32 - cols)).view(rows, groups, 32)
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.float()).to(torch.bfloat16)
+    assert torch.equal(planes[:, :, 0], hi) and torch.equal(planes[:, :, 1], lo)
+    rel = ((planes[:, :, 0].float() + planes[:, :, 1].float() - Wp).abs() / Wp.abs().clamp_min(1e-30)).max()
     assert float(rel) < 2.0 ** -15
 
 

@@ -1,0 +1,72 @@
+"""GPU: the model wrappers around the gated-token backbone against golden vectors produced by
+the REAL reference classes (oracle/gen_golden.py::gen_models): `FactorizedViViT` end to end (uint8 clip -> class
+probabilities) and ViTDet's pre-backbone + `SimplePyramid`."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_vivit_clip_classification_end_to_end(golden_dir):
+    """models/vivit.py of this package vs the reference's FactorizedViViT: tubelet embedding (patch GEMM), spatial
+    `EventfulBlock` model stepped over 16 time steps with top-k 128 gating (two temporal views on the batch axis),
+    temporal model (4 dense Blocks on 17 tokens), classifier, view mean, softmax.  fp32, free-running."""
+    from eventful_transformer import policies
+    from models.vivit import FactorizedViViT
+    g = H.load_npz(os.path.join(golden_dir, "models.npz"))
+    seed, k = int(g["vivit__seed"]), int(g["vivit__k"])
+    model = FactorizedViViT(**H.VIVIT_B_CONFIG)
+    res = model.load_state_dict(H.seeded_module_params(model, seed), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.eval().to(DEV)
+    H.set_policies(model, policies.TokenNormTopK, k=k)
+    clip = H.synthetic_video(seed + 1)
+    assert hashlib.sha256(clip.numpy().tobytes()).hexdigest() == bytes(g["vivit__clip_sha"]).decode()
+    feats, logits = {}, {}
+    model.temporal_model.register_forward_pre_hook(lambda m, i: feats.__setitem__("v", i[0].detach().clone()))
+    model.classifier.register_forward_hook(lambda m, i, o: logits.__setitem__("v", o.detach().clone()))
+    with torch.inference_mode():
+        probs = model(clip.to(DEV))
+    e_feat = float((feats["v"].cpu() - torch.from_numpy(g["vivit__spatial_features"])).abs().max())
+    e_logit = float((logits["v"].cpu() - torch.from_numpy(g["vivit__logits"])).abs().max())
+    e_prob = float((probs.cpu() - torch.from_numpy(g["vivit__probs"])).abs().max())
+    print(f"\n[ViViT end to end] spatial features {e_feat:.2e}, logits {e_logit:.2e}, probabilities {e_prob:.2e}")
+    assert probs.shape == (1, 400) and abs(float(probs.sum()) - 1.0) < 1e-5
+    assert e_feat <= 2e-3 and e_logit <= 1e-3 and e_prob <= 1e-5, (e_feat, e_logit, e_prob)
+
+
+def test_vitdet_pre_backbone_and_pyramid(golden_dir):
+    """models/vitdet.py of this package vs the reference's ViTDetPreprocessing + LinearEmbedding (patch GEMM) and
+    SimplePyramid (transposed convs as four scatter-GEMMs, 1x1 / 3x3 convs as GEMMs, LayerNorm row passes)."""
+    from models.vitdet import LinearEmbedding, SimplePyramid, ViTDetPreprocessing
+    g = H.load_npz(os.path.join(golden_dir, "models.npz"))
+    seed = int(g["vitdet__seed"])
+    pre = ViTDetPreprocessing((3, 224, 256), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375])
+    emb = LinearEmbedding(3, 768, (16, 16))
+    emb.load_state_dict(H.seeded_module_params(emb, seed), strict=True)
+    pyr = SimplePyramid([4.0, 2.0, 1.0, 0.5], 768, 256)
+    pyr.load_state_dict(H.seeded_module_params(pyr, seed + 1, std=0.05), strict=True)
+    emb, pyr = emb.eval().to(DEV), pyr.eval().to(DEV)
+    rs = np.random.RandomState(seed + 2)
+    frame = torch.from_numpy(rs.randint(0, 256, size=(1, 3, 200, 250)).astype(np.uint8))
+    tokens = torch.from_numpy(rs.standard_normal((1, 768, 14, 16)).astype(np.float32))
+    with torch.inference_mode():
+        img = pre(frame.to(DEV).float() / 255.0)
+        tok = emb(img.contiguous())
+        maps = pyr(tokens.to(DEV))
+    assert img.shape == (1, 3, 224, 256)
+    assert float((img[:, :, ::7, ::9].cpu() - torch.from_numpy(g["vitdet__image_slice"])).abs().max()) <= 1e-5
+    e_tok = float((tok[:, :, ::8].cpu() - torch.from_numpy(g["vitdet__tokens"])).abs().max())
+    assert tok.shape == (1, 14 * 16, 768) and e_tok <= 1e-3, e_tok
+    assert len(maps) == 5
+    for i, m in enumerate(maps):
+        want = torch.from_numpy(g[f"vitdet__p{i + 2}"])
+        err = float((m[:, ::8].cpu() - want).abs().max())
+        assert m[:, ::8].shape == want.shape and err <= 1e-3, (i, err)
