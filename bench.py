@@ -291,45 +291,99 @@ def _time_clips(run, frames, budget_s, max_clips=50):
             return n, el
 
 
-def cpu_baseline_vivit(sd, cast, k, frames, kind="EventfulBlock", budget_s=12.0):
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container
+    can see 256 cores and be throttled to the time of a few)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def _cpu_sample(sd, cast, k, frames, model_kind, threads, budget_s):
+    """Whole single clips (B=1, T frames, dense first frame included) through the oracle for ~budget_s."""
+    torch.set_num_threads(threads)
+    clip = synthetic_clips(1, frames, k, 1234, torch.device("cpu"))
+    model, _ = vivit_oracle_model(sd, cast if model_kind != "Block" else None, k if model_kind != "Block" else 0, model_kind)
+
+    def run():
+        model.reset()
+        for t in range(frames):
+            model.forward(clip[t])
+    with torch.inference_mode():
+        n, el = _time_clips(run, frames, budget_s)
+    return n, el
+
+
+def cpu_worker(args):
+    """`bench.py --cpu-worker`: one 8-thread oracle process of the all-cores CPU sample (never touches the GPU)."""
+    kind, block_class, frames, k, cast, _ = WORKLOADS[args.workload]
+    frames = args.frames if args.frames is not None else frames
+    k = args.k if args.k is not None else k
+    n, el = _cpu_sample(seeded_state_dict(), cast, k, frames, block_class, args.cpu_threads, args.cpu_budget)
+    print(json.dumps({"clips": n, "seconds": el}), flush=True)
+
+
+def cpu_baseline_vivit(sd, cast, k, frames, workload, kind="EventfulBlock", budget_s=12.0):
     """CPU column: the oracle (a torch-CPU port of the reference's op sequence, pinned bit-exact to the reference
     by tests/golden) on this box's host cores.  Bounded sample: whole single clips (B=1, T frames, first dense
-    frame included).  Reported at 8 threads (the reference's own CPU setting, configs/time/*/_cpu.yml) and, when
-    the box has more, at all cores; plus the dense config-1 figure (ViViT-B with `Block`, gating off)."""
-    cores = os.cpu_count() or 1
-    clip = synthetic_clips(1, frames, k, 1234, torch.device("cpu"))
-
-    def sample(model_kind, threads, budget):
-        torch.set_num_threads(threads)
-        model, _ = vivit_oracle_model(sd, cast if model_kind != "Block" else None, k if model_kind != "Block" else 0, model_kind)
-
-        def run():
-            model.reset()
-            for t in range(frames):
-                model.forward(clip[t])
-        with torch.inference_mode():
-            n, el = _time_clips(run, frames, budget)
-        return round(n * frames / el, 3), f"{n} clips x {frames} frames in {el:.1f}s"
-
+    frame included).  `value` is ONE clip stream at 8 threads (the reference's own CPU setting,
+    configs/time/*/_cpu.yml).  `all_cores`: the host filled with cores/8 such 8-thread processes, one clip stream each
+    (one B=1 stream cannot use more: 256 intra-op threads on 197 x 768 operands are slower than 8).  Plus the
+    dense config-1 figure (ViViT-B with `Block`, gating off) at 8 threads."""
+    cores = usable_cores()
     t8 = min(8, cores)
-    v8, s8 = sample(kind, t8, budget_s)
-    out = {"value": v8, "unit": "frames/s", "cores": t8, "kind": "port",
-           "sample": f"{s8}, B=1, ViViT-B spatial {kind} k={k} cast={cast}, torch-CPU oracle, {t8} threads"}
-    if cores > t8:
-        va, sa = sample(kind, cores, budget_s * 0.6)
-        out["all_cores"] = {"value": va, "cores": cores, "sample": sa}
+    n8, el8 = _cpu_sample(sd, cast, k, frames, kind, t8, budget_s)
+    out = {"value": round(n8 * frames / el8, 3), "unit": "frames/s", "cores": t8, "kind": "port",
+           "sample": f"{n8} clips x {frames} frames in {el8:.1f}s, B=1, ViViT-B spatial {kind} k={k} cast={cast}, "
+                     f"torch-CPU oracle, {t8} threads"}
+    workers = cores // 8
+    if workers >= 2:
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--workload", workload, "--frames", str(frames),
+               "--k", str(k), "--cpu-threads", "8", "--cpu-budget", str(budget_s * 0.6)]
+        env = dict(os.environ, OMP_NUM_THREADS="8", MKL_NUM_THREADS="8", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+                 for _ in range(workers)]
+        rate, done = 0.0, 0
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=240)
+                r = json.loads(o.strip().splitlines()[-1])
+                rate += r["clips"] * frames / r["seconds"]
+                done += 1
+            except Exception:
+                pr.kill()
+        out["all_cores"] = {"value": round(rate, 2), "unit": "frames/s", "cores": 8 * done,
+                            "sample": f"{done} concurrent 8-thread oracle processes, one B=1 clip stream each, "
+                                      f"~{budget_s * 0.6:.0f}s each; {cores} usable cores (os.cpu_count() = {os.cpu_count()})"}
     else:
-        out["all_cores"] = {"value": v8, "cores": cores, "sample": "host has no more than 8 cores: same run"}
+        out["all_cores"] = {"value": out["value"], "cores": cores,
+                            "sample": f"fewer than 16 usable cores ({cores}; os.cpu_count() = {os.cpu_count()}): the 8-thread run"}
     if kind != "Block":
-        vd, sdn = sample("Block", t8, budget_s * 0.5)
-        out["dense_config1"] = {"value": vd, "unit": "frames/s", "cores": t8,
-                                "sample": f"{sdn}, ViViT-B spatial dense `Block` (BASELINE configs[0]), {t8} threads"}
+        nd, eld = _cpu_sample(sd, None, 0, frames, "Block", t8, budget_s * 0.5)
+        out["dense_config1"] = {"value": round(nd * frames / eld, 3), "unit": "frames/s", "cores": t8,
+                                "sample": f"{nd} clips x {frames} frames in {eld:.1f}s, ViViT-B spatial dense `Block` "
+                                          f"(BASELINE configs[0]), {t8} threads"}
     return out
 
 
 def cpu_baseline_vitdet(sd, cast, policy, grid, stream_cpu):
     """One first frame + the incremental frames of `stream_cpu` (bounded) through the oracle, 8 threads."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t8 = min(8, cores)
     torch.set_num_threads(t8)
     bb, _ = vitdet_oracle_model(sd, cast, policy, grid)
@@ -354,10 +408,33 @@ def topk_margin(e, k):
     return float(((s[..., k - 1] - s[..., k]) / s[..., k - 1]).min())
 
 
-def self_check_vivit(model, clips, sd, cast, k, margin_bar=1e-3):
-    """Runs the timed model once more on the same resident batch (identical launches), reads back clip 0's
-    class embeddings and -- through forward hooks on the blocks -- clip 0's three gate index sets per block per
-    frame, and compares them with the CPU oracle run on clip 0 free-running."""
+class _ReplayTopK:
+    """Oracle-side policy for the self-check: hands the oracle the index set the HIP run selected for this gate (so
+    both sides refresh the same tokens and their states stay comparable), and records what the oracle's own top-k
+    would have selected on its input, with the relative margin between the k-th and (k+1)-th norm."""
+
+    def __init__(self, k):
+        self.k = k
+        self.forced = None
+        self.own = None
+        self.margin = None
+        self.last_input = None
+
+    def __call__(self, e, dim=-1):
+        n = torch.linalg.vector_norm(e, ord=2, dim=dim)
+        self.own = n.topk(self.k, sorted=False)[1].sort(dim=-1)[0]
+        self.margin = topk_margin(e, self.k)
+        return self.forced
+
+
+def self_check_vivit(model, clips, sd, cast, k):
+    """After the timed region: runs the timed model once more on the same resident batch (identical launches) and
+    reads back clip 0's class embeddings and -- through forward hooks on the blocks -- clip 0's three gate index sets
+    per block per frame.  The CPU oracle then replays clip 0 with THOSE index sets forced into its gates (so a
+    near-tie decided the other way cannot fork the two states) while recording what its own top-k selects:
+      * max_abs_err: class embeddings of every frame, HIP vs oracle;
+      * index_sets_equal: the HIP set equals the oracle's own selection for every gate whose margin is >= margin_bar
+        (1e-3; 3e-3 with the bf16 A.v cast, whose rounding noise sits in the projection gate's input)."""
     from eventful_transformer import _native
 
     T, B = clips.shape[0], clips.shape[1]
@@ -375,31 +452,43 @@ def self_check_vivit(model, clips, sd, cast, k, margin_bar=1e-3):
         h.remove()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     oracle, oblocks = vivit_oracle_model(sd, cast, k, "EventfulBlock" if k > 0 else "Block")
+    gates = ("qkv_gate", "projection_gate", "mlp_gate")
+    for ob in oblocks:
+        for gname in ob.GATES:
+            ob.policy[gname] = _ReplayTopK(k)
     x0 = clips[:, :1].cpu()
+    bar = 1e-3 if cast is None else 3e-3
     worst, checked, equal_on_margin, equal_all, total = 0.0, 0, 0, 0, 0
     with torch.inference_mode():
         oracle.reset()
         for t in range(T):
+            if t > 0 and k > 0:
+                for bi, ob in enumerate(oblocks):
+                    for gi, gname in enumerate(gates):
+                        ob.policy[gname].forced = got_idx[t * DEPTH + bi][gi].view(1, k)
             ref = oracle.forward(x0[t])
             worst = max(worst, float((feats[t] - ref[0]).abs().max()))
             if t == 0 or k == 0:
                 continue
             for bi, ob in enumerate(oblocks):
-                mine = got_idx[t * DEPTH + bi]
-                for gi, (gname, tkey) in enumerate((("qkv_gate", "qkv_index"), ("projection_gate", "projection_index"),
-                                                    ("mlp_gate", "mlp_index"))):
-                    want = ob.trace[tkey].sort(dim=-1)[0][0]
-                    same = bool(torch.equal(mine[gi], want))
+                for gi, gname in enumerate(gates):
+                    pol = ob.policy[gname]
+                    same = bool(torch.equal(pol.forced, pol.own))
                     total += 1
                     equal_all += same
-                    if topk_margin(ob.policy[gname].last_input, k) >= margin_bar:
+                    if pol.margin >= bar:
                         checked += 1
                         equal_on_margin += same
-    tol = 1e-3 if cast is None else 5e-2
+    # fp32: 1e-3 (north_star).  bf16 A.v cast: a different fp32 summation order flips single bf16 roundings (2^-9
+    # relative) of A.v state elements, which persist in the state; over 12 blocks x T frames the class embedding
+    # moves by ~1e-2 (the reference's own fp32-vs-bf16 gap on this model is 6.6e-2).
+    tol = 1e-3 if cast is None else 2e-2
     return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol,
             "gates_checked": checked, "index_sets_equal": bool(checked == equal_on_margin),
             "gates_total": total, "agreement_rate_all_margins": round(equal_all / total, 4) if total else None,
-            "margin_bar": margin_bar, "mode": "free-running vs CPU oracle (gates with reference margin >= bar must agree)",
+            "margin_bar": bar,
+            "mode": "CPU oracle replays clip 0 of the timed batch with the HIP index sets forced into its gates; its own "
+                    "top-k must pick the same set wherever its margin >= bar",
             "ok": bool(worst <= tol and checked == equal_on_margin)}
 
 
@@ -464,6 +553,15 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
     return None, None
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress to stderr (stdout carries only the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,7 +584,12 @@ def main():
                     "host-bound otherwise); implies --no-kernel-events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing test only: no GPU, a stub step (tests/test_dist_cpu.py)")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -512,6 +615,7 @@ def main():
     from eventful_transformer import _native
 
     _native.load()  # fail loudly here if the HIP library is missing
+    log(f"library loaded, workload {args.workload}, world {world}")
 
     # ---- clip set and its sharding ---------------------------------------------------------------------
     if kind == "vitdet":
@@ -545,6 +649,7 @@ def main():
     if args.graphs:
         model.use_graphs()
         args.no_kernel_events = True
+    log(f"model + {len(data)} resident batch(es) of synthetic clips ready")
 
     def sync_all():
         if world > 1:
@@ -561,6 +666,8 @@ def main():
     with torch.inference_mode():
         for _ in range(args.warmup):
             step()
+        torch.cuda.synchronize()
+        log(f"{args.warmup} warm-up step(s) done")
         events = None if args.no_kernel_events else []
         _native.set_kernel_events(timed_kernel, events)
         sync_all()
@@ -570,6 +677,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         _native.set_kernel_events(timed_kernel, None)
+    log(f"timed region: {args.steps} step(s) in {elapsed:.2f}s")
 
     if world > 1:
         elapsed = max_over_ranks(elapsed, device)
@@ -633,11 +741,14 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_check and kind == "vivit":
             line["check"] = self_check_vivit(model, data[0], sd, cast, k)
+            log(f"self-check vs CPU oracle: {line['check']}")
         if not args.no_exact and kind == "vivit" and _native.GEMM_MODE == "split":
             line["exact_fp32_frames_s"] = exact_fp32_rate(model, data[0], frames)
+            log(f"exact-fp32 arithmetic: {line['exact_fp32_frames_s']} frames/s")
         if not args.no_cpu_baseline:
+            log("CPU baseline (oracle on the host cores) ...")
             if kind == "vivit":
-                line["cpu_baseline"] = cpu_baseline_vivit(sd, cast, k, frames, kind=block_class)
+                line["cpu_baseline"] = cpu_baseline_vivit(sd, cast, k, frames, args.workload, kind=block_class)
             else:
                 n_cpu = 3 if grid <= 42 else 2
                 line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu].cpu())

@@ -25,8 +25,9 @@ Per-clip state lives on the gate / buffer sub-modules under the reference's attr
 (`qkv_gate.p`, `qkv_accumulator.b`, `matmul_accumulator_1.product`, ...), so `reset()` and state
 inspection work as in the reference.  `pool_size` (K/V token pooling, blocks.py:303-326,525-540) is
 supported on global blocks: keys/values are pooled by `evt_pool_kv`, the gate's index list is mapped to
-pooled cells by `evt_pool_index`, and K4/K5/K6 run with Nq != Nk.  Not implemented:
-`ats_fraction` (adaptive token sampling) and pooling inside windowed blocks; both raise at construction.
+pooled cells by `evt_pool_index`, and K4/K5/K6 run with Nq != Nk.  `ats_fraction` (adaptive token sampling,
+blocks.py:150-181) runs off the fast path (`_ats_attention`) and, like the reference, only when batch == heads.
+Not implemented: pooling inside windowed blocks and ATS combined with pooling / windows (raise).
 """
 from math import prod, sqrt
 
@@ -72,11 +73,10 @@ class Block(ExtendedModule):
                  relative_embedding_size=None, matmul_2_cast=None, pool_size=None, window_size=None):
         super().__init__()
         if ats_fraction is not None:
-            # The reference reduces its ATS scores over the BATCH axis (`scores.sum(dim=-3)` on a (B, H, N) tensor,
-            # blocks.py:163, commented "sum scores over heads"): it only executes when batch == heads, and then gives
-            # clip b the selection of head b computed from all clips.  There is no behaviour to be identical to.
-            raise NotImplementedError("ats_fraction: the reference's adaptive token sampling reduces over the batch axis "
-                                      "(blocks.py:163) and only runs when batch == heads; not reproduced in the MI355X path")
+            assert not (ats_fraction < 0.0 or ats_fraction > 1.0)
+            if pool_size is not None or window_size is not None:
+                raise NotImplementedError("ats_fraction together with pool_size / window_size is not built in the MI355X "
+                                          "path (the reference's ATS configs use neither)")
         if pool_size is not None and window_size is not None:
             raise NotImplementedError("pool_size together with window_size is not built in the MI355X path "
                                       "(the reference's configs pool only the global blocks)")
@@ -85,7 +85,7 @@ class Block(ExtendedModule):
         self.dim = dim
         self.heads = heads
         self.input_size = tuple(input_size)
-        self.ats_fraction = None
+        self.ats_fraction = ats_fraction
         self.last_ats_indices = None
         self.matmul_2_cast = matmul_2_cast
         self.pool_size = None if pool_size is None else numeric_tuple(pool_size, length=2)
@@ -181,6 +181,76 @@ class Block(ExtendedModule):
         ln = self.input_layer_norm if which == 1 else self.mlp_layer_norm
         return ln.weight, ln.bias
 
+    # -- adaptive token sampling (blocks.py:150-181, 378-391, 196-203) --------------------------------
+    # Off the fast path: the q.k^T / softmax / A.v contractions still run on K4 / K5 / K6, the token scoring and index
+    # bookkeeping (a few thousand scalars) are ATen ops on the HIP device, and the selection stays on the device
+    # (the reference moves it to the CPU for `_stabilize_ats_indices`).  The reference sums its scores over the
+    # BATCH axis (`scores.sum(dim=-3)` on a (B, H, N) tensor, blocks.py:163), so -- like the reference -- this only
+    # runs when batch == heads: clip b then keeps the tokens ranked by head b's scores summed over all clips.
+    def _ats_select(self, a, v):
+        """a (B,H,N,N) probabilities, v (B,H,N,dh) (both already in the dtype the reference scores in) -> (H, n) int64."""
+        B, H, N = a.shape[0], a.shape[1], a.shape[2]
+        if B != H:
+            raise RuntimeError(f"ats_fraction: the reference's adaptive token sampling sums its scores over the batch axis "
+                               f"(blocks.py:163) and only runs when batch == heads; got batch {B}, heads {H}")
+        raw = a[..., 0] * torch.linalg.vector_norm(v, dim=-1)
+        scores = raw / raw[..., 1:].sum(dim=-1, keepdim=True)
+        scores[..., 0] = float("inf")
+        scores = scores.sum(dim=-3)
+        n_select = int(self.ats_fraction * (N - 1)) + 1
+        index = scores.topk(n_select, sorted=False)[1].sort(dim=-1)[0]
+        last = self.last_ats_indices
+        if last is not None:  # keep every surviving token at last frame's position (blocks.py:378-391)
+            gone = ~(last.unsqueeze(-1) == index.unsqueeze(-2)).any(dim=-1)
+            fresh = ~(index.unsqueeze(-1) == last.unsqueeze(-2)).any(dim=-1)
+            index = last.masked_scatter(gone, index[fresh])   # per row #gone == #fresh, both in ascending order
+        self.last_ats_indices = index
+        return index
+
+    @staticmethod
+    def _ats_rows(x, index):
+        """x (B, N, F) -> rows index[b] of clip b: (B, n, F) (`_gather_ats_skip`, blocks.py:196-203)."""
+        return x.gather(dim=1, index=index.unsqueeze(-1).expand(-1, -1, x.shape[-1])).contiguous()
+
+    def _heads_v(self, qkv, B, N):
+        """Value heads (B,H,N,dh) as a view of the packed (B,N,3D) buffer (blocks.py:248-255)."""
+        D, H = self.dim, self.heads
+        return qkv.view(B, N, 3, H, D // H)[:, :, 2].permute(0, 2, 1, 3)
+
+    def _ats_attention(self, product, qkv, B, N, eventful):
+        """Attention tail with ATS from the (B,H,N,N) score state `product`: softmax (K5) -> scores -> selection ->
+        A.v.  Returns (attention output (B, n, D) fp32, indices (H, n)).
+        eventful=False (Block / EventfulTokenwiseBlock / EventfulMatmul1Block): ATS scores in fp32, before the
+        matmul_2 cast; the selected rows of a.v are rows of the full product (K6 over all rows, then a gather).
+        eventful=True (EventfulBlock): cast first, then ATS, then the v / A delta gates and the delta accumulator on
+        the gathered rows, with the stand-alone gate / accumulator modules (blocks.py:558-575)."""
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        ry, rx, gh, gw, qw = self._rel_tables()
+        a32 = self._ws("ats_probs", (B, H, N, N), torch.float32, qkv)
+        _native.softmax_gate(product, a32, B, H, N, N, D, _native.EVT_F32, qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
+        v = self._heads_v(qkv, B, N)
+        if not eventful:
+            index = self._ats_select(a32, v)
+            a = a32 if sdt == torch.float32 else a32.to(sdt)
+            v_s = self._ws("attn_values", (B, N, D), sdt, qkv)
+            self._v_full(qkv, None, B, N, N, v_s, _native.store_code(sdt))
+            full = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+            _native.av(a, v_s, N, B, H, N, N, D, _native.store_code(sdt), out_f32=full)
+            self.matmul.count_product(B * H * index.shape[-1] * dh, N)
+            return self._ats_rows(full, index), index
+        a = a32 if sdt == torch.float32 else a32.to(sdt)
+        v = v.to(sdt) if sdt != torch.float32 else v.clone()
+        index = self._ats_select(a, v)
+        a = a.gather(dim=2, index=index.view(B, 1, -1, 1).expand(-1, H, -1, N))
+        idx_v = None if self._ats_idx_k is None else self._ats_idx_k
+        v_n, v_d, index_v = self.v_gate(v, forced_index=idx_v)
+        a_n, a_d, _ = self.matmul_gate(a, forced_index=index_v)
+        x = self.matmul_accumulator_2(a_n, v_n, a_d, v_d)
+        x = x.permute(0, 2, 1, 3).reshape(B, index.shape[-1], D)
+        return x.float().contiguous(), index
+
     # -- dense attention (also the windowed attention of ViTDet's EventfulTokenwiseBlocks) -----------
     def _attention_dense(self, qkv, B, N, out):
         """qkv (B,N,3D) -> out (B,N,D) fp32.  Block._forward_attention (blocks.py:205-240)."""
@@ -196,6 +266,13 @@ class Block(ExtendedModule):
             gpc, n = tok_map.shape
             G, pad = B * gpc, self.qkv.bias
             assert prod(self.input_size) == N, "windowed attention needs tokens == prod(input_size)"
+        if self.ats_fraction is not None:
+            prod_s = self._ws("attn_scores", (B, H, N, N), torch.float32, qkv)
+            _native.qk_packed(qkv, B, N, D, H, self.scale, prod_s)
+            self.matmul.count_product(B * H * N * N, dh)
+            if self.relative_position is not None:
+                self.relative_position.count_fused(B, H)
+            return self._ats_attention(prod_s, qkv, B, N, eventful=False)
         if self.pool_size is None and _native.attention_dense_fits(n, D, H) and _native.DENSE_FUSED:
             # K8: the whole group in one launch, no score / probability tensors in HBM
             _native.attention_dense(qkv, G, H, n, D, self.scale, store, out_f32=out, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
@@ -256,7 +333,10 @@ class Block(ExtendedModule):
                              rows, D, 3 * D, W_split=self.qkv.split_planes())
         self.qkv.count_rows(rows)
         attn = self._ws("attn_out", (B, N, D), torch.float32, x)
-        self._attention_dense(qkv, B, N, attn)
+        ats = self._attention_dense(qkv, B, N, attn)
+        if ats is not None:   # adaptive token sampling: the block continues on the selected tokens only
+            attn, index = ats
+            return self._dense_tail(attn, self._ats_rows(x, index), B, attn.shape[1])
         return self._dense_tail(attn, x, B, N)
 
 
@@ -404,16 +484,18 @@ class EventfulTokenwiseBlock(Block):
         return out
 
     def _forward_attention(self, qkv, idx, count, cap, B, N):
+        """-> (attention output, ATS indices or None)"""
         attn = self._ws("attn_out", (B, N, self.dim), torch.float32, qkv)
-        self._attention_dense(qkv, B, N, attn)
-        return attn
+        ats = self._attention_dense(qkv, B, N, attn)
+        return ats if ats is not None else (attn, None)
 
     def forward(self, x):
         x = self._check_input(x)
         B, N, _ = x.shape
         qkv, idx, count, cap = self._forward_pre_attention(x)
-        attn = self._forward_attention(qkv, idx, count, cap, B, N)
-        return self._forward_post_attention(attn, x)
+        attn, ats_index = self._forward_attention(qkv, idx, count, cap, B, N)
+        skip = x if ats_index is None else self._ats_rows(x, ats_index)   # blocks.py:426,493
+        return self._forward_post_attention(attn, skip)
 
 
 class EventfulMatmul1Block(EventfulTokenwiseBlock):
@@ -478,11 +560,14 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         D, H = self.dim, self.heads
         sdt = self._store_dtype()
         store = _native.store_code(sdt)
+        if self.ats_fraction is not None:
+            product = self._scores(qkv, idx, count, cap, B, N)[0]
+            return self._ats_attention(product, qkv, B, N, eventful=False)
         if idx is None:
             attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
             if self._first_frame_fused(qkv, B, N, attn):
                 self.matmul.count_product(B * H * N * (D // H), N)
-                return attn
+                return attn, None
         product, kv, Nk, _, _, _ = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         a_s = self._ws("attn_probs", (B, H, N, Nk), sdt, qkv)
@@ -492,7 +577,7 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
         _native.av(a_s, v_s, Nk, B, H, N, Nk, D, store, out_f32=attn)
         self.matmul.count_product(B * H * N * (D // H), Nk)
-        return attn
+        return attn, None
 
 
 class EventfulBlock(EventfulMatmul1Block):
@@ -511,6 +596,13 @@ class EventfulBlock(EventfulMatmul1Block):
         store = _native.store_code(sdt)
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
         vg, ag, acc = self.v_gate, self.matmul_gate, self.matmul_accumulator_2
+        if self.ats_fraction is not None:
+            if count is not None:
+                raise NotImplementedError("ats_fraction with a variable-count policy: the gated A.v path needs one index "
+                                          "count for the whole batch (and ATS needs batch == heads > 1)")
+            product = self._scores(qkv, idx, count, cap, B, N)[0]
+            self._ats_idx_k = None if idx is None else idx.long()
+            return self._ats_attention(product, qkv, B, N, eventful=True)
         if acc.first and idx is None and self.matmul_accumulator_1.first:
             a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
             pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
@@ -522,7 +614,7 @@ class EventfulBlock(EventfulMatmul1Block):
                 acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
                 self._v_full(qkv, None, B, N, N, vg._state, store)
                 acc.matmul.count_product(B * H * N * dh, N)
-                return attn
+                return attn, None
         product, kv, Nk, idx_k, count_k, cap_k = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         rel = dict(qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
@@ -540,7 +632,7 @@ class EventfulBlock(EventfulMatmul1Block):
             self._v_full(qkv, kv, B, N, Nk, vg._state, store)
             _native.av(ag.p, vg._state, Nk, B, H, N, Nk, D, store, pv=acc._state, out_f32=attn)
             acc.matmul.count_product(B * H * N * dh, Nk)
-            return attn
+            return attn, None
         if dh in (64, 128):
             # K6a with k-contiguous outputs + fused K5/K6: a~ / da~ stay in LDS
             v_delta = self._ws("v_delta_t", (B, D, cap_k), sdt, qkv)
@@ -566,7 +658,7 @@ class EventfulBlock(EventfulMatmul1Block):
             if acc.count_mode:
                 acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
             acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
-        return attn
+        return attn, None
 
     def reset_self(self):
         super().reset_self()

@@ -226,11 +226,13 @@ class BlockOracle:
 
     kind: "Block" | "EventfulTokenwiseBlock" | "EventfulMatmul1Block" | "EventfulBlock"
     params: dict with the reference's state_dict key names (blocks.py:94-116).
-    Pooling (`pool_size`) and ATS (`ats_fraction`) are not restated (SURVEY.md §8f "next").
+    `ats_fraction` restates the reference's adaptive token sampling as written (blocks.py:150-181,378-391): its
+    scores are summed over the BATCH axis (blocks.py:163), so it only runs when batch == heads.
     """
 
     def __init__(self, kind, params, dim, heads, input_size, window_size=None,
-                 relative_embedding_size=None, matmul_2_cast=None, gate_before_ln=False, stgt=False, pool_size=None):
+                 relative_embedding_size=None, matmul_2_cast=None, gate_before_ln=False, stgt=False, pool_size=None,
+                 ats_fraction=None):
         self.kind = kind
         self.p = params
         self.dim, self.heads = dim, heads
@@ -252,6 +254,8 @@ class BlockOracle:
         self.rel_y = self.rel_x = None
         if kind in ("EventfulMatmul1Block", "EventfulBlock"):
             assert self.window_size is None  # blocks.py:485
+        self.ats_fraction = ats_fraction
+        self.last_ats = None
         self.policy = {}  # gate name -> policy callable (utils/misc.py:140-143: one per gate)
         self.reset()
 
@@ -267,6 +271,7 @@ class BlockOracle:
                  "matmul_accumulator_2")
         self.s = {n: Slot() for n in names}
         self.rel_y = self.rel_x = None  # utils.py:191-195
+        self.last_ats = None            # blocks.py:139-140
         self.trace = {}
 
     # -- pieces ------------------------------------------------------------------------------
@@ -366,6 +371,42 @@ class BlockOracle:
             return a, v, a.dtype
         return a.to(self.cast), v.to(self.cast), a.dtype
 
+    # -- adaptive token sampling (blocks.py:150-181, 378-391, 196-203) ---------------------------
+    def _ats(self, a, v):
+        """a (B,H,N,N) probabilities, v (B,H,N,dh) -> (a rows gathered (B,H,n,N), indices (H,n)) or (a, None)."""
+        if self.ats_fraction is None:
+            return a, None
+        class_scores = a[..., 0]
+        raw = class_scores * vector_norm(v[...], dim=-1)
+        scores = raw / raw[..., 1:].sum(dim=-1, keepdim=True)
+        scores[..., 0] = float("inf")           # the class token always stays
+        scores = scores.sum(dim=-3)             # blocks.py:163 ("sum scores over heads": reduces the BATCH axis)
+        n_select = int(self.ats_fraction * (scores.shape[-1] - 1)) + 1
+        self.trace["ats_scores"] = scores
+        index = scores.topk(n_select, sorted=False)[1]
+        index = self._stabilize_ats(index)
+        self.last_ats = index
+        self.trace["ats_index"] = index
+        return a.gather(dim=-2, index=rows_index(index, a.shape)), index
+
+    def _stabilize_ats(self, index):
+        # blocks.py:378-391: ascending, then keep every token that survives at the position it had last frame
+        index = index.sort(dim=-1)[0]
+        if self.last_ats is None:
+            return index
+        new, old = index.flatten(end_dim=-2), self.last_ats.flatten(end_dim=-2)
+        out = old.clone()
+        for i in range(new.shape[0]):
+            gone = torch.isin(old[i], new[i], invert=True)
+            fresh = torch.isin(new[i], old[i], invert=True)
+            out[i, gone] = new[i, fresh]
+        return out.view(index.shape)
+
+    @staticmethod
+    def _ats_skip(skip, index):
+        # blocks.py:196-203
+        return skip if index is None else skip.gather(dim=-2, index=rows_index(index, skip.shape))
+
     # -- attention variants --------------------------------------------------------------------
     def _attention_dense(self, qkv):
         # Block._forward_attention (blocks.py:205-240)
@@ -374,6 +415,7 @@ class BlockOracle:
         x = (q / self.scale) @ k.transpose(-2, -1)
         x = self._rel(x, q, inplace=True)
         x = x.softmax(dim=-1)
+        x, self._ats_index = self._ats(x, v)
         x, v, old = self._cast2(x, v)
         x = self._from_windows(self._merge(x @ v))
         return x.to(old) if self.cast is not None else x
@@ -391,6 +433,7 @@ class BlockOracle:
     def _attention_matmul1(self, qkv, index):
         # EventfulMatmul1Block._forward_attention (blocks.py:497-504)
         a, v, _ = self._scores_gated(qkv, index)
+        a, self._ats_index = self._ats(a, v)
         a, v, old = self._cast2(a, v)
         x = self._merge(a @ v)
         return x.to(old) if self.cast is not None else x
@@ -399,6 +442,7 @@ class BlockOracle:
         # EventfulBlock._forward_attention (blocks.py:558-575)
         a, v, index_k = self._scores_gated(qkv, index)
         a, v, old = self._cast2(a, v)
+        a, self._ats_index = self._ats(a, v)      # after the cast here (blocks.py:561-562)
         if self.cast is None:
             v = v.clone()
         v_new, v_delta, index_v = token_delta_gate(self.s["v_gate"], v, None, forced=index_k)
@@ -415,7 +459,8 @@ class BlockOracle:
             # Block.forward (blocks.py:117-137)
             skip = x
             x = self._lin(self._ln(x, "input_layer_norm"), "qkv")
-            x = self._lin(self._attention_dense(x), "projection") + skip
+            x = self._attention_dense(x)
+            x = self._lin(x, "projection") + self._ats_skip(skip, self._ats_index)
             return self._mlp(self._ln(x, "mlp_layer_norm")) + x
 
         # EventfulTokenwiseBlock._forward_pre_attention (blocks.py:452-463)
@@ -438,6 +483,7 @@ class BlockOracle:
         else:
             x = self._attention_eventful(x, index)
         tr["attn_out"] = x
+        skip = self._ats_skip(skip, self._ats_index)   # blocks.py:426,493
 
         # EventfulTokenwiseBlock._forward_post_attention (blocks.py:430-450)
         x, index = self._gate("projection_gate", x)

@@ -7,7 +7,7 @@ box).  For every case it (1) builds the reference module, loads the seeded param
 does, (2) runs it, (3) runs `oracle/eventful_oracle.py` on the same inputs and asserts the two
 agree BIT-FOR-BIT (same ATen CPU kernels), and (4) stores inputs-by-seed + expected outputs.
 
-Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vivit_k64|vitdet672|vitdet1024|counts|models]
+Usage:  python oracle/gen_golden.py [--only gates|blocks|vivit|vivit_k64|vitdet672|vitdet1024|counts|models|ats]
 """
 import argparse
 import hashlib
@@ -499,13 +499,74 @@ def gen_models():
     np.savez_compressed(os.path.join(OUT, "models.npz"), **pack)
 
 
+# ------------------------------------------------------------------------------------------------
+# (v) adaptive token sampling (blocks.py:150-181): batch == heads, the only shape the reference runs
+# ------------------------------------------------------------------------------------------------
+def ats_cases():
+    cs = {}
+    for kind in ("Block", "EventfulTokenwiseBlock", "EventfulMatmul1Block", "EventfulBlock"):
+        cs[f"{kind}_ats"] = (kind, {})
+    cs["EventfulBlock_ats_bf16"] = ("EventfulBlock", dict(matmul_2_cast="bfloat16"))
+    cs["EventfulMatmul1Block_ats_bf16"] = ("EventfulMatmul1Block", dict(matmul_2_cast="bfloat16"))
+    return cs
+
+
+def gen_ats():
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    steps, isz, frac, k = 4, (6, 6), 0.7, 10
+    batch = SMALL["heads"]          # blocks.py:163 sums the scores over the batch axis: batch must equal heads
+    tokens = isz[0] * isz[1] + 1
+    names = []
+    for ci, (name, (kind, kw)) in enumerate(ats_cases().items()):
+        seed = 7000
+        while True:
+            seed += 1
+            params = O.make_block_params(SMALL["dim"], SMALL["mlp_ratio"], seed=seed + ci, std=0.08)
+            xs = O.make_token_stream(batch, tokens, SMALL["dim"], steps, k, seed=seed, small=0.02)
+            ref = build_ref_block(kind, params, isz, ats_fraction=frac, **kw)
+            ora = O.BlockOracle(kind, params, SMALL["dim"], SMALL["heads"], isz, ats_fraction=frac, **kw)
+            if kind != "Block":
+                ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
+                ora.set_policy(lambda: O.TopK(k))
+            outs, ats_idx, margins = [], [], []
+            with torch.inference_mode():
+                for t in range(steps):
+                    y_ref = ref(xs[t].clone())
+                    y_ora = ora.forward(xs[t].clone())
+                    assert torch.equal(y_ref, y_ora), (name, t, float((y_ref - y_ora).abs().max()))
+                    assert torch.equal(ref.last_ats_indices, ora.trace["ats_index"])
+                    outs.append(y_ref.clone())
+                    ats_idx.append(ora.trace["ats_index"].clone())
+                    sc = ora.trace["ats_scores"].double()
+                    n_sel = ats_idx[-1].shape[-1]
+                    srt = sc.sort(dim=-1, descending=True)[0]
+                    margins.append(float(((srt[..., n_sel - 1] - srt[..., n_sel]) / srt[..., n_sel - 1]).min()))
+                    if kind != "Block" and t > 0:
+                        for g in ("qkv_gate", "projection_gate", "mlp_gate"):
+                            pol = getattr(ref, g).policy
+                            margins.append(topk_margin(pol.last_input, k))
+            if min(margins) >= 1e-3:
+                break
+        names.append(name)
+        pack[f"{name}__seed"] = np.int64(seed)
+        pack[f"{name}__param_seed"] = np.int64(seed + ci)
+        pack[f"{name}__x"] = xs.numpy()
+        pack[f"{name}__y"] = torch.stack(outs).numpy()
+        pack[f"{name}__ats_index"] = torch.stack(ats_idx).numpy().astype(np.int32)
+        print(f"ats {name}: seed={seed} min margin {min(margins):.2e} out {tuple(outs[-1].shape)}")
+    pack["names"] = np.array(names)
+    pack["fraction"] = np.float64(frac)
+    pack["k"] = np.int64(k)
+    np.savez_compressed(os.path.join(OUT, "ats.npz"), **pack)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
-            "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models}
+            "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models, "ats": gen_ats}
     for name, fn in todo.items():
         if args.only in (None, name):
             fn()

@@ -93,8 +93,10 @@ def test_state_dict_keys_and_constructor_contract():
         blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, window_size=(3, 3))  # blocks.py:485
     with pytest.raises(NotImplementedError):
         blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, window_size=(3, 3))
-    with pytest.raises(NotImplementedError):
-        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5)
+    ats = blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5)
+    assert ats.ats_fraction == 0.5 and ats.last_ats_indices is None
+    with pytest.raises(NotImplementedError):   # ATS + pooling: not built (the reference's ATS configs use neither)
+        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5, pool_size=2)
     pooled = blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, relative_embedding_size=(6, 6))
     assert pooled.pool_size == (2, 2) and pooled.relative_position.pool_size == (2, 2)
     bb = ViTBackbone(block_config=dict(dim=64, heads=4, mlp_ratio=4, relative_embedding_size=(8, 8), window_size=(3, 3)),

@@ -130,3 +130,29 @@ def test_vitdet_1024_threshold(golden_dir):
             if t > 0:
                 counts = [blk.trace[k].shape[-1] for blk in ob.blocks for k in ("qkv_index", "projection_index", "mlp_index")]
                 assert counts == g["counts"][t - 1].reshape(-1).tolist()
+
+
+def _ats_cases():
+    cs = {}
+    for kind in ("Block", "EventfulTokenwiseBlock", "EventfulMatmul1Block", "EventfulBlock"):
+        cs[f"{kind}_ats"] = (kind, {})
+    cs["EventfulBlock_ats_bf16"] = ("EventfulBlock", dict(matmul_2_cast="bfloat16"))
+    cs["EventfulMatmul1Block_ats_bf16"] = ("EventfulMatmul1Block", dict(matmul_2_cast="bfloat16"))
+    return cs
+
+
+@pytest.mark.parametrize("name", list(_ats_cases().keys()))
+def test_adaptive_token_sampling_vs_golden(golden_dir, name):
+    """ATS (blocks.py:150-181,378-391) as the reference runs it -- batch == heads, scores summed over the batch axis --
+    for all four block classes: outputs and the stabilised index sets of the real reference."""
+    g = H.load_npz(os.path.join(golden_dir, "ats.npz"))
+    kind, kw = _ats_cases()[name]
+    params = O.make_block_params(64, 4, seed=int(g[f"{name}__param_seed"]), std=0.08)
+    ora = O.BlockOracle(kind, params, 64, 4, (6, 6), ats_fraction=float(g["fraction"]), **kw)
+    if kind != "Block":
+        ora.set_policy(lambda: O.TopK(int(g["k"])))
+    xs, ys = torch.from_numpy(g[f"{name}__x"]), torch.from_numpy(g[f"{name}__y"])
+    for t in range(xs.shape[0]):
+        y = ora.forward(xs[t].clone())
+        assert torch.allclose(y, ys[t], atol=ATOL, rtol=0), (name, t, float((y - ys[t]).abs().max()))
+        assert np.array_equal(ora.trace["ats_index"].numpy(), g[f"{name}__ats_index"][t])
