@@ -20,6 +20,12 @@
 // MFMA operands are staged with 16-byte copies and read from LDS as 16-byte k-contiguous fragments.
 // For N <= 256 the exponentials of the workgroup's 32 rows live in an LDS tile, so the gather of the
 // selected columns is an LDS lookup; larger N re-reads the (L2-hot) state row and recomputes k exps.
+//
+// QK mode (product == nullptr; N == Nk <= 256, head dim 64): the score rows are not read from the q.k^T state at
+// all but computed in the kernel from the CURRENT token buffer -- (q / scale) k^T on the fp32-input MFMA, K streamed
+// through LDS in 64-key chunks into the same LDS tile.  At the ViViT operating point (k / N = 0.65) the state's row +
+// column panel update (K4) touches 88 % of the state and costs more than this full recompute, and the state would
+// only be written (K4) to be read once here: K4 and 2 x 477 MB of state traffic per launch at B = 256 go away.
 #include "evt_common.h"
 
 namespace {
@@ -81,11 +87,17 @@ struct FusedArgs {
   void* a_state; const int32_t* idx; const int32_t* count;
   const void* v_delta_t; const void* v_old_t; void* pv; float* out_f32;
   int B, H, N, Nk, D, dh, kcap, gh, gw, qw;   // N rows x Nk columns; gh x gw: KEY grid; qw: query grid width
+  float scale;                                // QK mode: q / scale (blocks.py:514)
 };
+
+constexpr int QKC = 64;       // QK mode: keys per staged chunk
+constexpr int QKP = 64 + 4;   // QK mode: fp32 LDS pitch of the q / K tiles (head dim 64)
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 // TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
 // in registers (one HBM pass, all 8*NREG loads in flight together); NREG == 0: any N, two streamed passes.
-template <typename T, int TPW, int NREG>
+// QK: the score tile is computed here (needs NREG > 0, TPW == 1) instead of being read from the state.
+template <typename T, int TPW, int NREG, int QK = 0>
 __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a) {
   constexpr int P = Tile<T>::PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -196,12 +208,102 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     }
     __syncthreads();
   }
+  if (QK && NREG > 0) {
+    // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  q tile aliases
+    // the An/Ad tiles, the K chunk the V tiles (both idle until the chunk loop); wave w owns keys 16w..16w+15 of
+    // every 64-key chunk (v_mfma_f32_16x16x4_f32, q fragments in registers), as in evt_attn_dense.hip.
+    float* Qs = reinterpret_cast<float*>(An);            // [FR][QKP]   (2*FR*P*sizeof(T) >= FR*QKP*4)
+    float* Ks = reinterpret_cast<float*>(Vd);            // [QKC][QKP]  (2*dh*P*sizeof(T) >= QKC*QKP*4)
+    const int64_t rs = 3 * (int64_t)a.D;
+    const float* clip = a.qkv + (int64_t)b * a.N * rs;
+    constexpr int IT = QKC * 16 / 256;                   // float4 per thread per K chunk
+    float4 kr[IT];
+    auto load_k = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15, j = c0 + r;
+        const float4 x = *reinterpret_cast<const float4*>(clip + (int64_t)(j < a.N ? j : a.N - 1) * rs + a.D + h * 64 + c4 * 4);
+        kr[it] = (j < a.N) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto store_k = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15;
+        *reinterpret_cast<float4*>(Ks + r * QKP + c4 * 4) = kr[it];
+      }
+    };
+    {
+      float4 q[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15, i = i0 + r;
+        const float4 x = *reinterpret_cast<const float4*>(clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64 + c4 * 4);
+        q[it] = (i < a.N) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      load_k(0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15;
+        *reinterpret_cast<float4*>(Qs + r * QKP + c4 * 4) = q[it];
+      }
+      store_k();
+    }
+    __syncthreads();
+    if (QKC < a.N) load_k(QKC);
+    const int l15 = lane & 15, kg = lane >> 4;
+    float4 qf[2][4];
+    {
+      const float inv = 1.0f / a.scale;
+      const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float4 q = *reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QKP + kg * 16 + 4 * m);
+          if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
+          else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
+          qf[hr][m] = q;
+        }
+    }
+    for (int c0 = 0; c0 < a.N; c0 += QKC) {
+      if (c0 > 0) {
+        store_k();
+        __syncthreads();
+        if (c0 + QKC < a.N) load_k(c0 + QKC);
+      }
+      const int n0 = c0 + wave * 16;
+      if (n0 < a.N) {  // wave-uniform
+        f32x4_acc sacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const float* kb = Ks + (wave * 16 + l15) * QKP + kg * 16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) {
+            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, sacc[hr], 0, 0, 0);
+            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, sacc[hr], 0, 0, 0);
+            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, sacc[hr], 0, 0, 0);
+            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, sacc[hr], 0, 0, 0);
+          }
+        }
+        const int j = n0 + l15;
+        if (j < a.N) {
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) et[(hr * 16 + 4 * kg + r) * EP + j] = sacc[hr][r];
+        }
+      }
+      __syncthreads();
+    }
+  }
   if (NREG > 0) {
     float xv[8][NREG > 0 ? NREG : 1];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
-      const float* prow = prod + (int64_t)(i < a.N ? i : 0) * a.Nk;
+      const float* prow = QK ? (et + r * EP) : (prod + (int64_t)(i < a.N ? i : 0) * a.Nk);
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
         // branch-free: a clamped address keeps all 8*NREG loads of the wave in flight together (a predicated load
@@ -210,6 +312,10 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
         const float x = prow[j < a.Nk ? j : a.Nk - 1];
         xv[rr][u] = (j < a.Nk) ? x : -INFINITY;
       }
+    }
+    if (QK) {   // every lane holds its scores before the row's exps overwrite them in the same tile
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int c = 0; c < PF; ++c)
@@ -451,12 +557,12 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   }
 }
 
-template <typename T, int TPW, int NREG>
+template <typename T, int TPW, int NREG, int QK = 0>
 void launch_fused_inst(const FusedArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_av_gated_kernel<T, TPW, NREG>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_av_gated_kernel<T, TPW, NREG, QK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((softmax_av_gated_kernel<T, TPW, NREG>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((softmax_av_gated_kernel<T, TPW, NREG, QK>), grid, dim3(256), lds, s, a);
 }
 
 template <typename T>
@@ -469,7 +575,11 @@ int launch_fused(const FusedArgs& a, void* stream) {
   const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
   if (grid.y == 0) return EVT_OK;
   hipStream_t s = evt_stream(stream);
-  if (a.dh == 64) {
+  static_assert(2 * FR * P * sizeof(T) >= FR * QKP * sizeof(float) && 2 * 64 * P * sizeof(T) >= QKC * QKP * sizeof(float),
+                "QK mode: the q tile / K chunk must fit in the A / V tiles they alias");
+  if (a.product == nullptr) {   // QK mode (validated by the entry point: dh == 64, N == Nk <= 256, kcap > 0)
+    launch_fused_inst<T, 1, 4, 1>(a, grid, lds, s);
+  } else if (a.dh == 64) {
     if (nreg <= 4 && a.kcap > 0) launch_fused_inst<T, 1, 4>(a, grid, lds, s);
     else launch_fused_inst<T, 1, 0>(a, grid, lds, s);
   } else {
@@ -483,8 +593,14 @@ int launch_fused(const FusedArgs& a, void* stream) {
 
 extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) {
   EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null descriptor");
-  EVT_REQUIRE(d->product && d->a_state && d->idx && d->v_delta_t && d->v_old_t && d->pv && d->out_f32,
+  EVT_REQUIRE(d->a_state && d->idx && d->v_delta_t && d->v_old_t && d->pv && d->out_f32,
               EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null pointer");
+  if (d->product == nullptr) {  // QK mode: scores from the token buffer
+    EVT_REQUIRE(d->qkv != nullptr && d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: product == NULL needs qkv and scale");
+    EVT_REQUIRE(d->dh == 64 && d->Nk == d->N && d->N <= 256 && d->kcap > 0, EVT_ERR_BAD_SHAPE,
+                "evt_softmax_av_gated: in-kernel q.k^T needs head dim 64, N == Nk <= 256, kcap > 0 (dh=%d N=%d Nk=%d kcap=%d)",
+                d->dh, d->N, d->Nk, d->kcap);
+  }
   EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->kcap >= 0 && d->D == d->H * d->dh, EVT_ERR_BAD_ARG,
               "evt_softmax_av_gated: bad sizes");
   EVT_REQUIRE(d->dh == 64 || d->dh == 128, EVT_ERR_BAD_SHAPE,
@@ -499,7 +615,7 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
   }
   FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
               d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
-              d->rel_y ? d->qw : 1};
+              d->rel_y ? d->qw : 1, d->scale};
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }

@@ -89,7 +89,7 @@ class SoftmaxAvDesc(Structure):
         ("gh", c_int32), ("gw", c_int32), ("a_state", c_void_p), ("idx", c_void_p), ("count", c_void_p),
         ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
         ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
-        ("store", c_int32), ("Nk", c_int32), ("qw", c_int32),
+        ("store", c_int32), ("Nk", c_int32), ("qw", c_int32), ("scale", c_float),
     ]
 
 
@@ -273,6 +273,7 @@ def gemm_kernel_name():
 GEMM_MODE = os.environ.get("EVT_GEMM", "split")
 QK_SPLIT = os.environ.get("EVT_QK_SPLIT", "1" if GEMM_MODE == "split" else "0") != "0"   # K4 on the bf16x3 split MFMA
 DENSE_FUSED = os.environ.get("EVT_DENSE_FUSED", "1") != "0"   # K8 (evt_attention_dense) vs the K4+K5+K6 chain
+FUSED_QK = os.environ.get("EVT_FUSED_QK", "1") != "0"         # gated frames: q.k^T inside K5+K6 (no K4, no state traffic)
 
 
 def split_weight(W):
@@ -384,15 +385,23 @@ def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
 
 
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
-                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None):
+                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0):
+    """K5+K6.  product None: the score rows are computed in the kernel from `qkv` ((q / scale) k^T; head dim 64,
+    N == Nk <= 256) instead of being read from the q.k^T state."""
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
-                      N if Nk is None else Nk, gw if qw is None else qw)
+                      N if Nk is None else Nk, gw if qw is None else qw, float(scale))
     # algorithmic bytes: q.k^T state read once, gate-reference columns read + rewritten, v delta / old reads,
     # A.v state read-modify-write, fp32 output
-    es, nk = product.element_size() if store == EVT_F32 else 2, (N if Nk is None else Nk)
-    work = B * (4.0 * H * N * nk + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D + 4.0 * N * D)
+    es, nk = (4 if store == EVT_F32 else 2), (N if Nk is None else Nk)
+    state_read = 4.0 * H * N * nk if product is not None else 8.0 * N * D   # QK mode reads q and k instead of the state
+    work = B * (state_read + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D + 4.0 * N * D)
     _timed("attn", work, lambda: _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream())))
+
+
+def fused_qk_fits(N, Nk, D, H, kcap):
+    """K5+K6 can compute the score rows itself (product=None): head dim 64, un-pooled, at most 256 tokens."""
+    return FUSED_QK and D == 64 * H and N == Nk and 0 < N <= 256 and kcap > 0
 
 
 def attention_dense_fits(N, D, H):

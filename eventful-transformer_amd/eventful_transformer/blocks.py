@@ -49,6 +49,9 @@ from eventful_transformer.policies import _NormPolicy
 from eventful_transformer.utils import DropPath, RelativePositionEmbedding
 
 LN_EPS = 1e-6
+# q.k^T state update: above this fraction of changed state entries the whole product is recomputed instead of the
+# row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
+QK_FULL_RATIO = 0.7
 
 
 def _window_map(input_size, window_size, device):
@@ -528,6 +531,14 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
             acc.product = torch.empty((B, H, N, Nk), dtype=torch.float32, device=qkv.device)
             _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, kv=kv, Nk=Nk)
             acc.matmul.count_product(B * H * N * Nk, D // H)
+        elif count is None and count_k is None and (cap * Nk + N * cap_k - cap * cap_k) > QK_FULL_RATIO * N * Nk:
+            # Most of the state changes (k/N = 0.65 at the ViViT operating point: the row + column panels are 88 % of
+            # the N x N state): recomputing ALL of q.k^T from the updated buffer gives the same state (I1) and is
+            # cheaper than the two panels with their scattered column writes (288 vs 374 us at B = 256).
+            _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, kv=kv, Nk=Nk)
+            if acc.matmul.count_mode:   # the reference's count is that of the delta update (modules.py:232-247)
+                acc.matmul.count_product(H * Nk * B * cap, D // H)
+                acc.matmul.count_product(H * N * B * cap_k, D // H)
         else:
             _native.qk_packed(qkv, B, N, D, H, self.scale, acc.product, idx=idx, count=count, kcap=cap, kv=kv, Nk=Nk,
                               idx_k=idx_k, count_k=count_k, kcap_k=cap_k, idx_rest=self._rest)
@@ -615,7 +626,23 @@ class EventfulBlock(EventfulMatmul1Block):
                 self._v_full(qkv, None, B, N, N, vg._state, store)
                 acc.matmul.count_product(B * H * N * dh, N)
                 return attn, None
-        product, kv, Nk, idx_k, count_k, cap_k = self._scores(qkv, idx, count, cap, B, N)
+        acc1 = self.matmul_accumulator_1
+        in_kernel_qk = (not acc.first and not acc1.first and self.pool_size is None and
+                        _native.fused_qk_fits(N, N, D, H, cap))
+        if in_kernel_qk:
+            # Gated frame, <= 256 tokens, head dim 64: the fused kernel computes (q / scale) k^T itself from the updated
+            # token buffer; K4 and the write + read of the (B,H,N,N) score state are skipped.  The state attribute is
+            # refreshed lazily if anybody reads it (MatmulBuffer.defer).
+            product, kv, Nk, idx_k, count_k, cap_k = None, None, N, idx, count, cap
+            buf, state, scale = self.qkv_accumulator.b, acc1._product, self.scale
+            acc1.defer(lambda: _native.qk_packed(buf, B, N, D, H, scale, state))
+            if acc1.matmul.count_mode:
+                n_sel = self._n_rows(B, cap, count)
+                acc1.matmul.count_product(2 * H * N * n_sel, dh)
+            if self.relative_position is not None:
+                self.relative_position.count_fused(B, H)
+        else:
+            product, kv, Nk, idx_k, count_k, cap_k = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         rel = dict(qkv=qkv, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
         # value source for K6a: packed buffer, or the value half of the pooled buffer
@@ -640,7 +667,7 @@ class EventfulBlock(EventfulMatmul1Block):
             _native.v_gate(vsrc, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True,
                            transposed=True, **vkw)
             _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state, attn, B, H, N, D,
-                                     store, Nk=Nk, **rel)
+                                     store, Nk=Nk, scale=self.scale, **rel)
         else:
             a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)
             a_delta = self._ws("a_delta", (B, H, N, cap_k), sdt, qkv)

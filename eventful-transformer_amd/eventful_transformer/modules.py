@@ -222,8 +222,28 @@ class MatmulBuffer(ExtendedModule):
     def __init__(self):
         super().__init__()
         self.first = True
-        self.product = None
+        self._product = None
+        self._refresh = None
         self.matmul = CountedMatmul()
+
+    # `product` is the reference's state attribute.  On gated frames EventfulBlock may compute the scores inside the
+    # fused attention kernel without touching this tensor; it then registers a refresh (one K4 launch over the
+    # current token buffer) that runs when -- and only if -- somebody reads the state.
+    @property
+    def product(self):
+        if self._refresh is not None:
+            fn, self._refresh = self._refresh, None
+            fn()
+        return self._product
+
+    @product.setter
+    def product(self, value):
+        self._product = value
+        self._refresh = None
+
+    def defer(self, refresh):
+        """Mark the state stale; `refresh()` recomputes it in place on the next read."""
+        self._refresh = refresh
 
     def forward(self, q, k, index_q, index_k):
         """q: (B,H,Nq,dh) (already divided by the scale); k: (B,H,dh,Nk) as in the reference."""

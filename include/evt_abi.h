@@ -300,8 +300,10 @@ EVT_API int evt_av(const evt_av_desc* d, void* stream);
  * fp32 on v_mfma_f32_32x32x2_f32.
  * ------------------------------------------------------------------------------------------ */
 typedef struct evt_softmax_av_desc {
-  const float* product;                   /* (B,H,N,Nk)                                          */
-  const float* qkv;                       /* (B,N,3D); only read for rel-pos                     */
+  const float* product;                   /* (B,H,N,Nk) q.k^T state; NULL: the scores are computed  */
+                                          /* in the kernel as (q/scale).k^T from `qkv` (head dim 64, */
+                                          /* N == Nk <= 256, kcap > 0) -- no state read, no evt_qk   */
+  const float* qkv;                       /* (B,N,3D); read for rel-pos and when product == NULL     */
   const float* rel_y; const float* rel_x; int32_t gh, gw;
   void* a_state;                          /* (B,H,N,Nk) store type: matmul_gate.p                */
   const int32_t* idx; const int32_t* count; int32_t kcap;
@@ -311,6 +313,7 @@ typedef struct evt_softmax_av_desc {
   int32_t B, H, N, D, dh;
   int32_t store;
   int32_t Nk, qw;                         /* key count (== N unless pooled), query grid width    */
+  float scale;                            /* product == NULL: q / scale (blocks.py:514)          */
 } evt_softmax_av_desc;
 
 EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);

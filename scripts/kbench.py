@@ -110,6 +110,8 @@ def main():
                      ("GB/s", B * k * D * (4 + 4 * es))),
         "softmax_av_fused": (lambda: n.softmax_av_gated(product, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store),
                              ("GB/s", B * H * N * (4 * N + 2 * es * k) + B * N * D * (4 + 2 * es))),
+        "softmax_av_fused_qk": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0),
+                                ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 2 * es))),
         "softmax_gated": (lambda: n.softmax_gate(product, ap_, B, H, N, N, D, store, a_new=a_new, a_delta=a_del,
                                                  idx=idx, kcap=k, gated=True),
                           ("GB/s", B * H * N * (4 * N + 4 * es * k))),

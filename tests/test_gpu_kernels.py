@@ -491,6 +491,65 @@ def test_fused_softmax_av_gated_matches_oracle(cast, N, k, rel):
         assert torch.equal(out.cpu(), pv.float().cpu())
 
 
+@pytest.mark.parametrize("cast,N,k,rel", [(None, 70, 12, False), ("bfloat16", 197, 128, False), ("float16", 36, 20, True),
+                                          (None, 256, 100, False), ("bfloat16", 42, 17, True), (None, 197, 197, False)])
+def test_fused_attention_in_kernel_qk(cast, N, k, rel):
+    """evt_softmax_av_gated with product == NULL: the score rows are (q / scale) k^T computed INSIDE the kernel from the
+    token buffer (no q.k^T state, no K4) -- against the oracle's softmax / delta gates / accumulator on the same
+    buffer, 3 gated frames incl. a device-side count < kcap, rel-pos, partial row blocks and N = 256."""
+    n = native()
+    B, H, dh, scale = 2, 2, 64, 8.0
+    D = H * dh
+    gh, gw = (6, N // 6) if rel else (0, 0)
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(N * 17 + k)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    ap = torch.empty(B, H, N, N, dtype=sdt, device=DEV)
+    vp = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    ry = torch.randn(gh, gh, dh, generator=g) * 0.2 if rel else None
+    rx = torch.randn(gw, gw, dh, generator=g) * 0.2 if rel else None
+    tol = 3e-5 if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+    for t in range(4):
+        buf = torch.randn(B, N, 3 * D, generator=g) * 1.5
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        q, kk, v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        scores = (q / scale) @ kk.transpose(-2, -1)
+        logits = O.add_relative(scores.clone(), q, ry, rx, (gh, gw), inplace=False) if rel else scores
+        a = logits.softmax(dim=-1)
+        if cast is not None:
+            a, v = a.to(sdt), v.to(sdt)
+        else:
+            v = v.clone()
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        bd, idxd = buf.to(DEV), idx.int().to(DEV)
+        relkw = dict(rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=gh, gw=gw) if rel else {}
+        if t == 0:
+            n.attention_dense(bd, B, H, N, D, scale, store, out_f32=out, a_state=ap, pv=pv, qw=gw, **relkw)
+            n.v_gate(bd, None, None, B, N, D, 0, vp, None, None, store, False)
+        else:
+            cap = k if (t != 2 or k == N) else k + 5
+            idx_cap = torch.full((B, cap), 0, dtype=torch.int32, device=DEV)
+            idx_cap[:, :k] = idxd
+            count = None if cap == k else torch.full((B,), k, dtype=torch.int32, device=DEV)
+            v_del = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            v_old = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            n.v_gate(bd, idx_cap, count, B, N, D, cap, vp, v_del, v_old, store, True, transposed=True)
+            n.softmax_av_gated(None, ap, idx_cap, count, cap, v_del, v_old, pv, out, B, H, N, D, store, qkv=bd, scale=scale,
+                               **relkw)
+        assert torch.allclose(ap.float().cpu(), ag.t.float(), atol=tol * 0.1 + 3e-6), (cast, t)
+        err = float((out.cpu() - ref).abs().max())
+        assert err <= tol, (cast, N, k, t, err)
+        assert torch.equal(out.cpu(), pv.float().cpu())
+    with pytest.raises(RuntimeError, match="in-kernel"):
+        n.softmax_av_gated(None, torch.empty(1, 2, 300, 300, device=DEV), idxd[:1], None, k, v_del, v_old,
+                           torch.empty(1, 300, D, device=DEV), torch.empty(1, 300, D, device=DEV), 1, H, 300, D, 0, qkv=bd, scale=scale)
+
+
 @pytest.mark.parametrize("cast,N,rel", [(None, 197, False), ("bfloat16", 197, False), (None, 196, True), ("float16", 100, True),
                                         (None, 256, True), (None, 33, False)])
 def test_attention_dense_fused_vs_fp64(cast, N, rel):
