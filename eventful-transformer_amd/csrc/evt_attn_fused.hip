@@ -26,11 +26,10 @@
 // through LDS in 64-key chunks into the same LDS tile.  At the ViViT operating point (k / N = 0.65) the state's row +
 // column panel update (K4) touches 88 % of the state and costs more than this full recompute, and the state would
 // only be written (K4) to be read once here: K4 and 2 x 477 MB of state traffic per launch at B = 256 go away.
-#include "evt_common.h"
+#include "evt_linear.h"   // split4 (fp32 -> bf16 hi / lo)
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int FR = 32;    // rows per workgroup
@@ -88,6 +87,7 @@ struct FusedArgs {
   const void* v_delta_t; const void* v_old_t; void* pv; float* out_f32;
   int B, H, N, Nk, D, dh, kcap, gh, gw, qw;   // N rows x Nk columns; gh x gw: KEY grid; qw: query grid width
   float scale;                                // QK mode: q / scale (blocks.py:514)
+  int qk_split;                               // QK mode: 1 = bf16 hi/lo split products, 0 = exact fp32 products
 };
 
 constexpr int QKC = 64;       // QK mode: keys per staged chunk
@@ -96,7 +96,9 @@ typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 // TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
 // in registers (one HBM pass, all 8*NREG loads in flight together); NREG == 0: any N, two streamed passes.
-// QK: the score tile is computed here (needs NREG > 0, TPW == 1) instead of being read from the state.
+// QK: the score tile is computed here (needs NREG > 0, TPW == 1) instead of being read from the state:
+// 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = split precision (q, k as bf16 hi + lo, three
+// v_mfma_f32_16x16x32_bf16 per product, ~1e-5 relative -- the arithmetic K4 uses by default; 5x less matrix-pipe time).
 template <typename T, int TPW, int NREG, int QK = 0>
 __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a) {
   constexpr int P = Tile<T>::PITCH;
@@ -252,19 +254,36 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     __syncthreads();
     if (QKC < a.N) load_k(QKC);
     const int l15 = lane & 15, kg = lane >> 4;
+    const float inv = 1.0f / a.scale;
+    const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+    auto scaled = [&](float4 q) __attribute__((always_inline)) {   // q / self.scale; a power-of-two scale: exact multiply
+      if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
+      else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
+      return q;
+    };
+    auto split8 = [&](const float4 u, const float4 v, bf16x8_t* hi, bf16x8_t* lo) __attribute__((always_inline)) {
+      bf16x4_t h0, l0, h1, l1;
+      split4(u, &h0, &l0);
+      split4(v, &h1, &l1);
+      *hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // fragments of the scaled q rows, kept in registers for all chunks.  QK == 1: 16x16x4 fp32 tiles, lane = (row l15
+    // of a 16-row half, 16 channels kg*16..); QK == 2: 16x16x32 bf16 tiles, lane = (row l15, 8 channels 32m + 8kg..).
     float4 qf[2][4];
-    {
-      const float inv = 1.0f / a.scale;
-      const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+    bf16x8_t qh[2][2], ql[2][2];
 #pragma unroll
-      for (int hr = 0; hr < 2; ++hr)
+    for (int hr = 0; hr < 2; ++hr) {
+      if (QK == 1) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float4 q = *reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QKP + kg * 16 + 4 * m);
-          if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
-          else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
-          qf[hr][m] = q;
+        for (int m = 0; m < 4; ++m) qf[hr][m] = scaled(*reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QKP + kg * 16 + 4 * m));
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float* qp = Qs + (hr * 16 + l15) * QKP + 32 * m + 8 * kg;
+          split8(scaled(*reinterpret_cast<const float4*>(qp)), scaled(*reinterpret_cast<const float4*>(qp + 4)), &qh[hr][m], &ql[hr][m]);
         }
+      }
     }
     for (int c0 = 0; c0 < a.N; c0 += QKC) {
       if (c0 > 0) {
@@ -275,16 +294,31 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       const int n0 = c0 + wave * 16;
       if (n0 < a.N) {  // wave-uniform
         f32x4_acc sacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const float* kb = Ks + (wave * 16 + l15) * QKP + kg * 16;
+        if (QK == 1) {
+          const float* kb = Ks + (wave * 16 + l15) * QKP + kg * 16;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
+          for (int m = 0; m < 4; ++m) {
+            const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
 #pragma unroll
-          for (int hr = 0; hr < 2; ++hr) {
-            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, sacc[hr], 0, 0, 0);
-            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, sacc[hr], 0, 0, 0);
-            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, sacc[hr], 0, 0, 0);
-            sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, sacc[hr], 0, 0, 0);
+            for (int hr = 0; hr < 2; ++hr) {
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, sacc[hr], 0, 0, 0);
+            }
+          }
+        } else {
+          const float* kb = Ks + (wave * 16 + l15) * QKP + 8 * kg;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            bf16x8_t kh, kl;
+            split8(*reinterpret_cast<const float4*>(kb + 32 * m), *reinterpret_cast<const float4*>(kb + 32 * m + 4), &kh, &kl);
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr) {
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[hr][m], kh, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kl, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kh, sacc[hr], 0, 0, 0);
+            }
           }
         }
         const int j = n0 + l15;
@@ -578,7 +612,8 @@ int launch_fused(const FusedArgs& a, void* stream) {
   static_assert(2 * FR * P * sizeof(T) >= FR * QKP * sizeof(float) && 2 * 64 * P * sizeof(T) >= QKC * QKP * sizeof(float),
                 "QK mode: the q tile / K chunk must fit in the A / V tiles they alias");
   if (a.product == nullptr) {   // QK mode (validated by the entry point: dh == 64, N == Nk <= 256, kcap > 0)
-    launch_fused_inst<T, 1, 4, 1>(a, grid, lds, s);
+    if (a.qk_split) launch_fused_inst<T, 1, 4, 2>(a, grid, lds, s);
+    else launch_fused_inst<T, 1, 4, 1>(a, grid, lds, s);
   } else if (a.dh == 64) {
     if (nreg <= 4 && a.kcap > 0) launch_fused_inst<T, 1, 4>(a, grid, lds, s);
     else launch_fused_inst<T, 1, 0>(a, grid, lds, s);
@@ -615,7 +650,7 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
   }
   FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
               d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
-              d->rel_y ? d->qw : 1, d->scale};
+              d->rel_y ? d->qw : 1, d->scale, d->qk_split};
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }

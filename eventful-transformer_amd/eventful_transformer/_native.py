@@ -89,7 +89,7 @@ class SoftmaxAvDesc(Structure):
         ("gh", c_int32), ("gw", c_int32), ("a_state", c_void_p), ("idx", c_void_p), ("count", c_void_p),
         ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
         ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
-        ("store", c_int32), ("Nk", c_int32), ("qw", c_int32), ("scale", c_float),
+        ("store", c_int32), ("Nk", c_int32), ("qw", c_int32), ("scale", c_float), ("qk_split", c_int32),
     ]
 
 
@@ -385,12 +385,13 @@ def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
 
 
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
-                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0):
+                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0, qk_split=None):
     """K5+K6.  product None: the score rows are computed in the kernel from `qkv` ((q / scale) k^T; head dim 64,
     N == Nk <= 256) instead of being read from the q.k^T state."""
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
-                      N if Nk is None else Nk, gw if qw is None else qw, float(scale))
+                      N if Nk is None else Nk, gw if qw is None else qw, float(scale),
+                      int(QK_SPLIT if qk_split is None else qk_split))
     # algorithmic bytes: q.k^T state read once, gate-reference columns read + rewritten, v delta / old reads,
     # A.v state read-modify-write, fp32 output
     es, nk = (4 if store == EVT_F32 else 2), (N if Nk is None else Nk)

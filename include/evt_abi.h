@@ -314,6 +314,8 @@ typedef struct evt_softmax_av_desc {
   int32_t store;
   int32_t Nk, qw;                         /* key count (== N unless pooled), query grid width    */
   float scale;                            /* product == NULL: q / scale (blocks.py:514)          */
+  int32_t qk_split;                       /* product == NULL: 1 = q, k as bf16 hi + lo (3 bf16 MFMAs */
+                                          /* per product, like evt_qk split), 0 = exact fp32 MFMA    */
 } evt_softmax_av_desc;
 
 EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
