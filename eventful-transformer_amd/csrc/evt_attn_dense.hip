@@ -95,8 +95,16 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int gh_ = blockIdx.y, g = gh_ / a.H, h = gh_ - g * a.H;
-  const int i0 = blockIdx.x * AR;
+  // XCD-aware placement (dispatch is round-robin over the 8 XCDs in linear workgroup order, x fastest): all row tiles of
+  // one (group, head) run on the same XCD, so its K and V rows are fetched into ONE private L2.
+  int gh_ = blockIdx.y, tile_x = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int p = blockIdx.x + gridDim.x * blockIdx.y, x = p & 7, s = p >> 3, hl = s / (int)gridDim.x;
+    tile_x = s - hl * (int)gridDim.x;
+    gh_ = hl * 8 + x;
+  }
+  const int g = gh_ / a.H, h = gh_ - g * a.H;
+  const int i0 = tile_x * AR;
   const int64_t rs = 3 * (int64_t)a.D;
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;

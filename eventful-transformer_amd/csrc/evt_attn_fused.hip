@@ -22,8 +22,8 @@
 // selected columns is an LDS lookup; larger N re-reads the (L2-hot) state row and recomputes k exps.
 //
 // QK mode (product == nullptr; N == Nk <= 256, head dim 64): the score rows are not read from the q.k^T state at
-// all but computed in the kernel from the CURRENT token buffer -- (q / scale) k^T on the fp32-input MFMA, K streamed
-// through LDS in 64-key chunks into the same LDS tile.  At the ViViT operating point (k / N = 0.65) the state's row +
+// all but computed in the kernel from the CURRENT token buffer -- (q / scale) k^T on the matrix cores, q and k read
+// from the buffer straight into MFMA fragments, into the same LDS tile.  At the ViViT operating point (k / N = 0.65) the state's row +
 // column panel update (K4) touches 88 % of the state and costs more than this full recompute, and the state would
 // only be written (K4) to be read once here: K4 and 2 x 477 MB of state traffic per launch at B = 256 go away.
 #include "evt_linear.h"   // split4 (fp32 -> bf16 hi / lo)
@@ -90,8 +90,7 @@ struct FusedArgs {
   int qk_split;                               // QK mode: 1 = bf16 hi/lo split products, 0 = exact fp32 products
 };
 
-constexpr int QKC = 64;       // QK mode: keys per staged chunk
-constexpr int QKP = 64 + 4;   // QK mode: fp32 LDS pitch of the q / K tiles (head dim 64)
+constexpr int QKC = 64;       // QK mode: keys per chunk (16 per wave)
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 // TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
@@ -116,8 +115,17 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int i0 = blockIdx.x * FR;
+  // XCD-aware placement: workgroups are dispatched round-robin over the 8 XCDs in linear order (x fastest), which
+  // would spread the row tiles of one (clip, head) over 8 private L2s.  Remapped so that all row tiles of a head run on
+  // ONE XCD: its dv~ / v_old tiles -- and, in QK mode, its K rows -- are fetched into one L2 instead of up to eight.
+  int bh = blockIdx.y, tile_x = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int p = blockIdx.x + gridDim.x * blockIdx.y, x = p & 7, s = p >> 3, hl = s / (int)gridDim.x;
+    tile_x = s - hl * (int)gridDim.x;
+    bh = hl * 8 + x;
+  }
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int i0 = tile_x * FR;
   const int cnt = a.count ? a.count[b] : a.kcap;
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;
@@ -210,49 +218,30 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
     }
     __syncthreads();
   }
+  // Requests for everything the chunk loop and the epilogue need that does not depend on the scores: old a~ values of
+  // the first PF chunks, the first dv~ / v_old chunk, the A.v state rows.  Issued behind the state-row loads of phase 1
+  // or, in QK mode, ahead of the q.k^T phase, so that one workgroup waits for ~2 dependent round trips, not one per phase.
+  auto prefetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < PF; ++c)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int i = i0 + wave * 8 + rr;
+        oldpf[c][rr] = Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + (jpf[c] >= 0 ? jpf[c] : 0));   // branch-free
+      }
+    if (vvec) load_v(0);
+    load_pv();
+  };
   if (QK && NREG > 0) {
-    // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  q tile aliases
-    // the An/Ad tiles, the K chunk the V tiles (both idle until the chunk loop); wave w owns keys 16w..16w+15 of
-    // every 64-key chunk (v_mfma_f32_16x16x4_f32, q fragments in registers), as in evt_attn_dense.hip.
-    float* Qs = reinterpret_cast<float*>(An);            // [FR][QKP]   (2*FR*P*sizeof(T) >= FR*QKP*4)
-    float* Ks = reinterpret_cast<float*>(Vd);            // [QKC][QKP]  (2*dh*P*sizeof(T) >= QKC*QKP*4)
+    prefetch();
+    asm volatile("" ::: "memory");
+    // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  Wave w owns keys
+    // 16w .. 16w+15 of every 64-key chunk.  Both operands go STRAIGHT from the token buffer into MFMA fragments: lane
+    // (l15, kg) reads, of q row l15 / key l15, the channels its fragment holds (16 lanes x 4 kg cover whole 128-byte
+    // lines of 16 rows), so there is no LDS staging and no barrier until the tile is complete; the next chunk's
+    // fragments are requested before the current chunk's MFMAs.
     const int64_t rs = 3 * (int64_t)a.D;
     const float* clip = a.qkv + (int64_t)b * a.N * rs;
-    constexpr int IT = QKC * 16 / 256;                   // float4 per thread per K chunk
-    float4 kr[IT];
-    auto load_k = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15, j = c0 + r;
-        const float4 x = *reinterpret_cast<const float4*>(clip + (int64_t)(j < a.N ? j : a.N - 1) * rs + a.D + h * 64 + c4 * 4);
-        kr[it] = (j < a.N) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    auto store_k = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15;
-        *reinterpret_cast<float4*>(Ks + r * QKP + c4 * 4) = kr[it];
-      }
-    };
-    {
-      float4 q[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15, i = i0 + r;
-        const float4 x = *reinterpret_cast<const float4*>(clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64 + c4 * 4);
-        q[it] = (i < a.N) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      load_k(0);
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int e = tid + 256 * it, r = e >> 4, c4 = e & 15;
-        *reinterpret_cast<float4*>(Qs + r * QKP + c4 * 4) = q[it];
-      }
-      store_k();
-    }
-    __syncthreads();
-    if (QKC < a.N) load_k(QKC);
     const int l15 = lane & 15, kg = lane >> 4;
     const float inv = 1.0f / a.scale;
     const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
@@ -268,51 +257,58 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       *hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
       *lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    // fragments of the scaled q rows, kept in registers for all chunks.  QK == 1: 16x16x4 fp32 tiles, lane = (row l15
-    // of a 16-row half, 16 channels kg*16..); QK == 2: 16x16x32 bf16 tiles, lane = (row l15, 8 channels 32m + 8kg..).
+    // channel of float4 piece p (0..3) of this lane.  QK == 1 (16x16x4 fp32 tiles, k permuted: the sum over channels
+    // does not care which channel meets which MFMA step as long as q and k agree): 16 contiguous channels 16kg + 4p.
+    // QK == 2 (16x16x32 bf16 tiles): k-block m = p >> 1 holds channels 32m + 8kg .. +8, pieces 2m, 2m + 1.
+    auto chan = [&](int p_) __attribute__((always_inline)) { return QK == 1 ? 16 * kg + 4 * p_ : 32 * (p_ >> 1) + 8 * kg + 4 * (p_ & 1); };
     float4 qf[2][4];
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr) {
+      const int i = i0 + hr * 16 + l15;
+      const float* qp = clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64;
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qp + chan(p_));
+    }
+    auto load_kf = [&](int c0, float4* kf) __attribute__((always_inline)) {
+      const int j = c0 + wave * 16 + l15;
+      const float* kp = clip + (int64_t)(j < a.N ? j : a.N - 1) * rs + a.D + h * 64;
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
+    };
+    float4 kf[4];
+    load_kf(0, kf);
     bf16x8_t qh[2][2], ql[2][2];
 #pragma unroll
     for (int hr = 0; hr < 2; ++hr) {
-      if (QK == 1) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) qf[hr][m] = scaled(*reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QKP + kg * 16 + 4 * m));
-      } else {
+      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = scaled(qf[hr][p_]);
+      if (QK == 2) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const float* qp = Qs + (hr * 16 + l15) * QKP + 32 * m + 8 * kg;
-          split8(scaled(*reinterpret_cast<const float4*>(qp)), scaled(*reinterpret_cast<const float4*>(qp + 4)), &qh[hr][m], &ql[hr][m]);
-        }
+        for (int m = 0; m < 2; ++m) split8(qf[hr][2 * m], qf[hr][2 * m + 1], &qh[hr][m], &ql[hr][m]);
       }
     }
     for (int c0 = 0; c0 < a.N; c0 += QKC) {
-      if (c0 > 0) {
-        store_k();
-        __syncthreads();
-        if (c0 + QKC < a.N) load_k(c0 + QKC);
-      }
+      float4 kn[4];
+      const bool more = c0 + QKC < a.N;
+      if (more) load_kf(c0 + QKC, kn);
       const int n0 = c0 + wave * 16;
       if (n0 < a.N) {  // wave-uniform
         f32x4_acc sacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (QK == 1) {
-          const float* kb = Ks + (wave * 16 + l15) * QKP + kg * 16;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
+          for (int p_ = 0; p_ < 4; ++p_)
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr) {
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].x, kf[p_].x, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].y, kf[p_].y, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].z, kf[p_].z, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].w, kf[p_].w, sacc[hr], 0, 0, 0);
             }
-          }
         } else {
-          const float* kb = Ks + (wave * 16 + l15) * QKP + 8 * kg;
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             bf16x8_t kh, kl;
-            split8(*reinterpret_cast<const float4*>(kb + 32 * m), *reinterpret_cast<const float4*>(kb + 32 * m + 4), &kh, &kl);
+            split8(kf[2 * m], kf[2 * m + 1], &kh, &kl);
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr) {
               sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[hr][m], kh, sacc[hr], 0, 0, 0);
@@ -329,8 +325,12 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
             for (int r = 0; r < 4; ++r) et[(hr * 16 + 4 * kg + r) * EP + j] = sacc[hr][r];
         }
       }
-      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) kf[p_] = kn[p_];
+      }
     }
+    __syncthreads();
   }
   if (NREG > 0) {
     float xv[8][NREG > 0 ? NREG : 1];
@@ -351,15 +351,7 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int c = 0; c < PF; ++c)
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int i = i0 + wave * 8 + rr;
-        oldpf[c][rr] = Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + (jpf[c] >= 0 ? jpf[c] : 0));   // branch-free
-      }
-    if (vvec) load_v(0);
-    load_pv();
+    if (!QK) prefetch();
     asm volatile("" ::: "memory");   // scheduling fence: the requests above are issued before the statistics below
     if (rel) {
 #pragma unroll
@@ -609,8 +601,6 @@ int launch_fused(const FusedArgs& a, void* stream) {
   const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
   if (grid.y == 0) return EVT_OK;
   hipStream_t s = evt_stream(stream);
-  static_assert(2 * FR * P * sizeof(T) >= FR * QKP * sizeof(float) && 2 * 64 * P * sizeof(T) >= QKC * QKP * sizeof(float),
-                "QK mode: the q tile / K chunk must fit in the A / V tiles they alias");
   if (a.product == nullptr) {   // QK mode (validated by the entry point: dh == 64, N == Nk <= 256, kcap > 0)
     if (a.qk_split) launch_fused_inst<T, 1, 4, 2>(a, grid, lds, s);
     else launch_fused_inst<T, 1, 4, 1>(a, grid, lds, s);

@@ -1,17 +1,21 @@
 #!/bin/bash
-# Run ON the GPU box (via gpurun): bench line + rocprofv3 kernel stats + the two PMC passes for the default
-# bench workload.  Writes everything under gpurun_out/final/ (copied into profiles/r01/ afterwards).
+# Run ON the GPU box (via gpurun): bench line + rocprofv3 kernel stats + separate PMC passes (HBM traffic, MFMA busy)
+# for the default bench workload at one resident batch.  Writes under gpurun_out/prof/ (copied into profiles/rNN/).
+#   gpurun -- 'bash scripts/collect_profiles.sh 256'
 set -u
 B=${1:-256}
-OUT=gpurun_out/final
+OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --clips $B --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_B$B.json
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --clips $B --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f --output-format csv -- python3 bench.py --clips $B --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w --output-format csv -- python3 bench.py --clips $B --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/write.log 2>&1
+SHORT="--clips $B --total-clips $B --no-cpu-baseline --no-check --no-exact --no-kernel-events"
+python bench.py --steps 5 --warmup 2 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py $SHORT --steps 2 --warmup 1 > $OUT/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d" " -f1)
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$n -o p --output-format csv -- python3 bench.py $SHORT --steps 1 --warmup 1 > $OUT/pmc_$n.log 2>&1
+done
 python scripts/pmc_summary.py $OUT $B
-# the raw per-dispatch counter CSVs are large; keep only the aggregates
-rm -f $OUT/fetch/*_kernel_trace.csv $OUT/write/*_kernel_trace.csv $OUT/fetch/f_counter_collection.csv $OUT/write/w_counter_collection.csv $OUT/stats/s_kernel_trace.csv
+# the raw per-dispatch CSVs are large; keep only the aggregates
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "p_counter_collection.csv" -delete
 ls -la $OUT $OUT/stats
-cat $OUT/bench_B$B.json
+cat $OUT/bench_default.json

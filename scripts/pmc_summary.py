@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel (run by scripts/collect_profiles.sh)."""
-import collections, csv, json, sys
+"""Aggregate the rocprofv3 --pmc passes of scripts/collect_profiles.sh per kernel: HBM traffic (FETCH_SIZE / WRITE_SIZE with
+the gfx950 correction of MI355X_MICROARCH.md) and matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES)."""
+import collections, csv, glob, hashlib, json, os, sys
 
 out, B = sys.argv[1], int(sys.argv[2])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["gated_linear_split_kernel<0", "gated_linear_split_kernel<1", "gated_linear_kernel<0", "gated_linear_kernel<1",
-         "softmax_av_gated_kernel", "qk_kernel", "row_pass_kernel", "v_gate_t_kernel", "v_gate_kernel", "select_kernel",
+         "softmax_av_gated_kernel", "qk_kernel", "qk_split_kernel", "row_pass_kernel", "v_gate_t_kernel", "v_gate_kernel", "select_kernel",
          "av_kernel", "softmax_gate_kernel", "split_weights_kernel", "attn_dense_kernel", "splitk_finish_kernel"]
 
 
@@ -14,35 +16,56 @@ def key(n):
             return k
 
 
-def agg(path, counter):
-    tot = collections.defaultdict(lambda: [0, 0.0, 0])
-    for r in csv.DictReader(open(path)):
-        k = key(r["Kernel_Name"])
-        if r["Counter_Name"] == counter and k:
-            t = tot[k]
-            t[0] += 1
-            t[1] += float(r["Counter_Value"])
-            t[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    return tot
+def agg(tag):
+    """{counter: {kernel: [launches, sum value, sum ns]}} of one pass"""
+    res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0]))
+    for path in glob.glob(f"{out}/pmc_{tag}/**/p_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            k = key(r["Kernel_Name"])
+            if k:
+                t = res[r["Counter_Name"]][k]
+                t[0] += 1
+                t[1] += float(r["Counter_Value"])
+                t[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return res
 
 
-f = agg(f"{out}/fetch/f_counter_collection.csv", "FETCH_SIZE")
-w = agg(f"{out}/write/w_counter_collection.csv", "WRITE_SIZE")
+f = agg("FETCH_SIZE")["FETCH_SIZE"]
+w = agg("WRITE_SIZE")["WRITE_SIZE"]
+sq = agg("SQ_VALU_MFMA_BUSY_CYCLES")
+gr = agg("GRBM_GUI_ACTIVE")["GRBM_GUI_ACTIVE"]
 rows = []
 for n in NAMES:
     if n in f and n in w:
         c, v, t = f[n]
         wc, wv, _ = w[n]
-        rows.append(dict(kernel=n.replace("<0", "<ACT_NONE>").replace("<1", "<ACT_GELU>"), launches=c,
-                         fetch_size_kb_raw=round(v / c, 1), write_size_kb=round(wv / wc, 1),
-                         hbm_bytes_per_launch=int((2 * v / c + wv / wc) * 1024), avg_us_profiled=round(t / c / 1e3, 1)))
+        row = dict(kernel=n.replace("<0", "<ACT_NONE>").replace("<1", "<ACT_GELU>"), launches=c,
+                   fetch_size_kb_raw=round(v / c, 1), write_size_kb=round(wv / wc, 1),
+                   hbm_bytes_per_launch=int((2 * v / c + wv / wc) * 1024), avg_us_profiled=round(t / c / 1e3, 1))
+        mb = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get(n)
+        if mb and mb[1] > 0:
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs; GRBM_GUI_ACTIVE = cycles the launch was active
+            row["mfma_busy_cycles"] = round(mb[1] / mb[0])
+            ga = gr.get(n)
+            if ga and ga[1] > 0:
+                row["gui_active_cycles"] = round(ga[1] / ga[0])
+                row["mfma_util_pmc"] = round((mb[1] / mb[0]) / (ga[1] / ga[0] * 1024), 4)
+            row["mfma_bf16_mops"] = round(sq.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", {}).get(n, [1, 0, 0])[1] / max(1, mb[0]))
+        rows.append(row)
 g = [r for r in rows if r["kernel"].startswith("gated_linear")]
 gem = int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in g) / max(1, sum(r["launches"] for r in g)))
+h = hashlib.sha256()
+for src in sorted(glob.glob(os.path.join(ROOT, "eventful-transformer_amd", "csrc", "evt_linear*.hip"))):
+    h.update(open(src, "rb").read())
 json.dump(dict(
-    command=f"rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --clips {B} --steps 1 --warmup 1 --no-cpu-baseline "
-            "--no-kernel-events  (second, separate pass with --pmc WRITE_SIZE)",
+    command=f"rocprofv3 --pmc <counter> --kernel-trace -- python3 bench.py --clips {B} --total-clips {B} --steps 1 --warmup 1 "
+            "--no-cpu-baseline --no-check --no-exact --no-kernel-events  (one separate pass per counter group: FETCH_SIZE; WRITE_SIZE; "
+            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16; GRBM_GUI_ACTIVE)",
     correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                "coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected; Infinity-Cache hits are counted",
-    workload=dict(clips=B, frames=16, k=128, cast="bfloat16", gemm="split"),
+    mfma_util="mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), averaged per launch",
+    workload=dict(clips=B, frames=16, k=128, cast="bfloat16", gemm="split"), gemm_source_sha16=h.hexdigest()[:16],
     gated_linear_hbm_bytes_per_launch=gem, kernels=rows), open(f"{out}/pmc_traffic_B{B}.json", "w"), indent=1)
 print("GEMM HBM bytes/launch:", gem)
+for r in rows:
+    print(r)
