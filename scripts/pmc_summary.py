@@ -44,12 +44,16 @@ for n in NAMES:
                    hbm_bytes_per_launch=int((2 * v / c + wv / wc) * 1024), avg_us_profiled=round(t / c / 1e3, 1))
         mb = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get(n)
         if mb and mb[1] > 0:
-            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs; GRBM_GUI_ACTIVE = cycles the launch was active
+            # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs (32 per 32x32x16 bf16 MFMA); GRBM_GUI_ACTIVE is
+            # reported summed over the 8 XCDs: / 8 = shader cycles the launch was active (checks out against the profiled
+            # duration at ~2.0 GHz, the clock this chip sustains under the MFMA load)
             row["mfma_busy_cycles"] = round(mb[1] / mb[0])
             ga = gr.get(n)
             if ga and ga[1] > 0:
-                row["gui_active_cycles"] = round(ga[1] / ga[0])
-                row["mfma_util_pmc"] = round((mb[1] / mb[0]) / (ga[1] / ga[0] * 1024), 4)
+                cyc = ga[1] / ga[0] / 8
+                row["active_cycles"] = round(cyc)
+                row["clock_ghz_profiled"] = round(cyc / (ga[2] / ga[0]), 3)
+                row["mfma_util_pmc"] = round((mb[1] / mb[0]) / (cyc * 1024), 4)
             row["mfma_bf16_mops"] = round(sq.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", {}).get(n, [1, 0, 0])[1] / max(1, mb[0]))
         rows.append(row)
 g = [r for r in rows if r["kernel"].startswith("gated_linear")]
@@ -63,7 +67,8 @@ json.dump(dict(
             "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16; GRBM_GUI_ACTIVE)",
     correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                "coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected; Infinity-Cache hits are counted",
-    mfma_util="mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), averaged per launch",
+    mfma_util="mfma_util_pmc = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), averaged per launch: the "
+              "fraction of the launch's shader cycles in which a SIMD's matrix pipe is busy, at the clock the chip actually ran",
     workload=dict(clips=B, frames=16, k=128, cast="bfloat16", gemm="split"), gemm_source_sha16=h.hexdigest()[:16],
     gated_linear_hbm_bytes_per_launch=gem, kernels=rows), open(f"{out}/pmc_traffic_B{B}.json", "w"), indent=1)
 print("GEMM HBM bytes/launch:", gem)
