@@ -240,13 +240,32 @@ __device__ __forceinline__ int splitk_dynamic(const int32_t* count, int B, int t
 // Tile configuration: TBM x TBN output tile, TBK k-tile, WM x WN waves each owning a 64x64 sub-tile
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
-template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
+// WDMA (128x128x32 tile only): the weight tile is not staged through registers but streamed global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 16 rows x 64 B of one plane per wave instruction, lane-linear destination, the chunk swizzle
+// applied to the SOURCE chunk each lane fetches) into one of TWO weight buffers, one k-tile ahead; a counted
+// s_waitcnt leaves the next tile's loads in flight across the (raw) barriers.  Removes the weight ds_write_b128 (52 of
+// the ~164 LDS-pipe cycles a wave spends per k-tile) and 16 staging registers.
+template <int ACT, int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM_MIN_BLOCKS : 1)) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
   constexpr int NT = WM * WN * 64;
-  constexpr int TSP = TBK + 8;  // bf16 LDS pitch: 80 / 144 bytes, 16 consecutive rows tile all 64 banks
+  static_assert(!WDMA || (TBK == 32 && TBN == 128 && NT == 256), "LDS-DMA weight path: 128-wide tiles, 4 waves");
+  // bf16 LDS tile layout.  TBK == 32: unpadded 64-byte rows with the 16-byte chunk c of row r stored at chunk
+  // c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 lane group touches cover all 16 slots of a 256-byte bank row, and the
+  // two rows a 16-lane ds_write_b64 group / 8-lane ds_write_b128 group writes occupy disjoint halves of the 32 write
+  // banks.  (The padded 80-byte pitch used before was conflict-free for the reads only: rocprof counted a third of the
+  // LDS cycles of this kernel as bank conflicts, all from the staging stores.)  Other TBK: padded pitch, no swizzle.
+  constexpr bool SWZ = (TBK == 32);
+  constexpr int TSP = SWZ ? TBK : TBK + 8;
+  auto lds_off = [](int row, int k) {   // element offset of (row, k); k a multiple of 4
+    return SWZ ? row * TSP + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7) : row * TSP + k;
+  };
   static_assert(TBM == WM * 64 && TBN == WN * 64, "each wave owns 64x64");
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (TBM + TBN) * TSP];
-  __shared__ int64_t orow_off[TBM];  // output row offset (elements) of each tile row, -1 = masked row
+  constexpr int BBUF = 2 * TBN * TSP;   // one weight buffer: hi plane, lo plane
+  // ONE dynamic LDS object for everything (operand tiles, then the row-offset table): with a second __shared__ object
+  // in the kernel hipcc waits vmcnt(0) -- i.e. for the LDS-DMA just issued -- before the fragment reads of every k-tile.
+  extern __shared__ __attribute__((aligned(16))) unsigned char evt_gemm_smem[];
+  __bf16* lds = reinterpret_cast<__bf16*>(evt_gemm_smem);
+  int64_t* orow_off = reinterpret_cast<int64_t*>(lds + 2 * TBM * TSP + (WDMA ? 2 : 1) * BBUF);  // output row offset (elements) of each tile row, -1 = masked row
   __bf16* Ahi = lds;
   __bf16* Alo = lds + TBM * TSP;
   __bf16* Bhi = lds + 2 * TBM * TSP;
@@ -332,11 +351,43 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
     const int n = n0 + wr0 + WROWS * j;
     w_off[j] = (int64_t)(n < g.Nout ? n : g.Nout - 1) * wpitch;
   }
+  // LDS-DMA weight path: wave w moves row blocks 2w, 2w + 1 (16 rows x 64 B each) of the hi and of the lo plane.
+  // lane -> (row lane >> 2 of the block, physical chunk lane & 3); it fetches the logical chunk that belongs there.
+  const uint16_t* dma_src[2];
+  if (WDMA) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 16 * (2 * wave + j) + (lane >> 2);
+      dma_src[j] = g.Wsplit + (int64_t)(n < g.Nout ? n : g.Nout - 1) * wpitch + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+    }
+  }
+  auto issue_w = [&](int t, int buf) {   // k-tile t (a whole hl32 group: always readable, zero past K) -> weight buffer buf
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    typedef const __attribute__((address_space(1))) void gbl_void_t;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __bf16* dst = Bhi + buf * BBUF + (2 * wave + j) * 16 * TSP;
+      const uint16_t* src = dma_src[j] + (int64_t)t * 64;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + 32), (lds_void_t*)(dst + TBN * TSP), 16, 0, 0);
+    }
+  };
   float4 ra[AJ];
   uint4 rwh[WJ], rwl[WJ];
   auto fetch = [&](int k0) {
     const int kc = k0 + ac4 * 4;
     const int kw = hl32_hi(k0 + wc8);
+    if (WDMA) {   // activations only
+      if (k0 + TBK <= g.K) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j)
+          ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
     if (k0 + TBK <= g.K) {
       // Whole k-tile inside K (always, when K % TBK == 0): unconditional loads, no per-load branch.  Masked rows
       // (a_ptr = A) and weight rows past Nout (clamped) contribute to accumulators that the epilogue never stores.
@@ -364,13 +415,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
     for (int j = 0; j < AJ; ++j) {
       bf16x4_t h, l;
       split4(ra[j], &h, &l);
-      *reinterpret_cast<bf16x4_t*>(Ahi + (ar0 + AROWS * j) * TSP + ac4 * 4) = h;
-      *reinterpret_cast<bf16x4_t*>(Alo + (ar0 + AROWS * j) * TSP + ac4 * 4) = l;
+      *reinterpret_cast<bf16x4_t*>(Ahi + lds_off(ar0 + AROWS * j, ac4 * 4)) = h;
+      *reinterpret_cast<bf16x4_t*>(Alo + lds_off(ar0 + AROWS * j, ac4 * 4)) = l;
     }
+    if (!WDMA) {
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      *reinterpret_cast<uint4*>(Bhi + (wr0 + WROWS * j) * TSP + wc8) = rwh[j];
-      *reinterpret_cast<uint4*>(Blo + (wr0 + WROWS * j) * TSP + wc8) = rwl[j];
+      for (int j = 0; j < WJ; ++j) {
+        *reinterpret_cast<uint4*>(Bhi + lds_off(wr0 + WROWS * j, wc8)) = rwh[j];
+        *reinterpret_cast<uint4*>(Blo + lds_off(wr0 + WROWS * j, wc8)) = rwl[j];
+      }
     }
   };
 
@@ -396,25 +449,38 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   const int nk_all = (g.K + TBK - 1) / TBK, kps = (nk_all + ksplit - 1) / ksplit;
   const int t0 = split * kps, nk = min(nk_all, t0 + kps);
   const int lr = lane & 31, lh = lane >> 5;
+  if (WDMA) issue_w(t0, 0);
   fetch(t0 * TBK);
   for (int t = t0; t < nk; ++t) {
     stage();
-    if (do_upd && (t % tiles_n) == bn) {
+    const bool upd_now = do_upd && (t % tiles_n) == bn;
+    if (upd_now) {
       const int kc = t * TBK + ac4 * 4;
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
         if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
     }
     if (t + 1 < nk) fetch((t + 1) * TBK);   // before the barrier: the requests do not wait for the slowest wave's staging
-    __syncthreads();
+    const int wbuf = WDMA ? ((t - t0) & 1) * BBUF : 0;
+    if (WDMA) {
+      // k-tile t + 1 goes into the other weight buffer: its last readers (k-tile t - 1) passed the barrier that ended
+      // the previous iteration.  Then wait for THIS tile's weights only: the AJ activation loads and the 4 LDS-DMA
+      // instructions just issued stay in flight across both barriers (raw s_barrier: __syncthreads() would drain them).
+      if (t + 1 < nk) issue_w(t + 1, ((t - t0) & 1) ^ 1);
+      if (t + 1 < nk && !upd_now) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AJ + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // last tile, or stores of the p refresh in the queue
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < TBK; ks += 16) {
       bf16x8_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ao = (wm * 64 + i * 32 + lr) * TSP + ks + 8 * lh;
-        const int bo = (wn * 64 + i * 32 + lr) * TSP + ks + 8 * lh;
+        const int ao = lds_off(wm * 64 + i * 32 + lr, ks + 8 * lh);
+        const int bo = lds_off(wn * 64 + i * 32 + lr, ks + 8 * lh) + wbuf;
         ah[i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
         al[i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
         bh[i] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
@@ -430,7 +496,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
         }
     }
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+    if (WDMA) __builtin_amdgcn_s_barrier();   // every wave's fragment reads are complete (their MFMAs consumed them)
+    else __syncthreads();
   }
 
   int ncol[2];
@@ -514,18 +581,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int
   *reinterpret_cast<float4*>(g.out + orow * g.ldo + c) = v;
 }
 
-template <int TBM, int TBN, int TBK, int WM, int WN>
+template <int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
 void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn = 0) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
   const dim3 grid(tiles_m * tiles_n * ksplit), block(WM * WN * 64);
+  constexpr int TSP_ = (TBK == 32) ? TBK : TBK + 8;
+  constexpr size_t lds_bytes = (size_t)(2 * TBM * TSP_ + (WDMA ? 2 : 1) * 2 * TBN * TSP_) * 2 + (size_t)TBM * 8;
+  if (lds_bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN, WDMA>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN, WDMA>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  }
   static const int want_map = getenv("EVT_GEMM_MAP") ? atoi(getenv("EVT_GEMM_MAP")) : 0;
   const int tile_map = (want_map == 1 && (tiles_n % 2) == 0 && (tiles_m % 4) == 0) ? 1 : 0;
   if (a.act == EVT_ACT_GELU_ERF)
-    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN, WDMA>), grid, block, lds_bytes, s, a,
                        tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   else
-    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, 0, s, a,
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN, WDMA>), grid, block, lds_bytes, s, a,
                        tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   if (ksplit > 1) {
     const int64_t work = (int64_t)M * (a.Nout / 4);
@@ -555,7 +630,12 @@ void launch_split(const LinArgs& a, hipStream_t s) {
     case 4: launch_split_cfg<128, 256, 32, 2, 4>(a, s); break;
     case 5: launch_split_cfg<256, 256, 32, 4, 4>(a, s); break;
     case 6: launch_split_cfg<64, 64, 32, 1, 1>(a, s); break;
-    default: launch_split_cfg<128, 128, 32, 2, 2>(a, s); break;
+    default: {
+      static const int wdma = getenv("EVT_GEMM_WDMA") ? atoi(getenv("EVT_GEMM_WDMA")) : 0;
+      if (wdma) launch_split_cfg<128, 128, 32, 2, 2, true>(a, s);
+      else launch_split_cfg<128, 128, 32, 2, 2>(a, s);
+      break;
+    }
   }
 }
 

@@ -1,7 +1,8 @@
 // evt_select.hip -- K1: token selection from delta norms (top-k / threshold policies).
 //
 // One 256-thread workgroup per clip.  The clip's norms are staged once in LDS as order-preserving
-// uint keys; the k-th largest key is found by a 4-pass 8-bit radix select (LDS histograms); the
+// uint keys; the k-th largest key is found by a 4-pass 8-bit radix select (LDS histograms, 16 private copies per bin
+// so that the norms of a clip -- which share their exponent byte -- do not serialise on one LDS atomic); the
 // selected tokens are then emitted in ASCENDING index order by wavefront-ballot compaction:
 // per 256-token round each wave ranks its lanes with a 64-bit ballot + popcount of the lower
 // lanes, and the 4 per-wave counts are combined through LDS.  Ties at the k-th key are resolved
@@ -12,6 +13,7 @@ namespace {
 
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_MAX_N = 16384;
+constexpr int SEL_COPIES = 16;   // private histogram copies: at most 4 lanes of a wave share an LDS atomic address
 
 // Non-negative floats order like their bit patterns.  NaN norms (bits > +inf) sort first, which
 // matches ATen's topk treating NaN as the largest value.
@@ -23,24 +25,37 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
                                                              int32_t* __restrict__ count, int32_t* __restrict__ rest) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* keys = smem;               // N
-  uint32_t* hist = smem + N;           // 256
-  uint32_t* wsum = hist + 256;         // 8: [0..3] eq counts per wave, [4..7] selected counts per wave
+  uint32_t* hist = smem + N;           // 256 bin totals
+  uint32_t* hpriv = hist + 256;        // SEL_COPIES x 256: copy (lane & 15) of every bin
+  uint32_t* wsum = hpriv + SEL_COPIES * 256;  // 8: [0..3] eq counts per wave, [4..7] selected counts per wave
   uint32_t* bc = wsum + 8;             // 4 broadcast words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const float* nrm = norms + (int64_t)b * N;
   for (int i = tid; i < N; i += SEL_THREADS) keys[i] = norm_key(nrm[i]);
+  __syncthreads();   // the compaction reads contiguous chunks: keys staged by other threads
 
   uint32_t kth = 0;     // key of the k-th largest element
   uint32_t need_eq = 0; // how many elements equal to kth are selected
   if (mode == 0) {
     uint32_t prefix = 0, mask = 0, remaining = (uint32_t)k;
+#pragma unroll
+    for (int c = 0; c < SEL_COPIES; ++c) hpriv[c * 256 + tid] = 0;
+    __syncthreads();
+    // three barriers per pass: the private copies are re-zeroed by the thread that sums them, and the two broadcast
+    // words alternate between two slots, so a pass needs no barrier before the next one starts
     for (int shift = 24; shift >= 0; shift -= 8) {
-      hist[tid] = 0;
-      __syncthreads();
+      uint32_t* bcp = bc + ((shift >> 3) & 1) * 2;
       for (int i = tid; i < N; i += SEL_THREADS) {
         const uint32_t key = keys[i];
-        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        if ((key & mask) == prefix) atomicAdd(&hpriv[(lane & (SEL_COPIES - 1)) * 256 + ((key >> shift) & 255u)], 1u);
+      }
+      __syncthreads();
+      {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int c = 0; c < SEL_COPIES; ++c) { tot += hpriv[c * 256 + tid]; hpriv[c * 256 + tid] = 0; }
+        hist[tid] = tot;
       }
       __syncthreads();
       if (wave == 0) {
@@ -64,64 +79,72 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
             if (acc + hb[j] >= remaining) { bin = lane * 4 + j; break; }
             acc += hb[j];
           }
-          bc[0] = (uint32_t)bin;
-          bc[1] = remaining - acc;  // rank inside the chosen bin (1-based)
+          bcp[0] = (uint32_t)bin;
+          bcp[1] = remaining - acc;  // rank inside the chosen bin (1-based)
         }
       }
       __syncthreads();
-      prefix |= bc[0] << shift;
+      prefix |= bcp[0] << shift;
       mask |= 255u << shift;
-      remaining = bc[1];
-      __syncthreads();
+      remaining = bcp[1];
     }
     kth = prefix;
     need_eq = remaining;
   }
 
-  // Ordered compaction.
-  uint32_t eq_run = 0, out_run = 0;  // running totals, identical in every thread
+  // Ordered compaction in ONE pass: thread t owns the contiguous tokens [t*C, (t+1)*C).  It counts its keys above and
+  // equal to the k-th key, an exclusive scan over the 256 threads (wave scan + four wave totals through LDS: one
+  // barrier) gives the counts before its chunk, and it then emits its selected tokens in order:
+  //   #selected before token i = #greater before i + min(#equal before i, need_eq)      (ties: lowest index first).
+  // (The round-per-256-tokens version this replaces cost three barriers per round: 21 of them at N = 1764.)
+  const int C = (N + SEL_THREADS - 1) / SEL_THREADS;
+  const int i_lo = tid * C, i_hi = min(N, i_lo + C);
+  const float thr_f = thr;
+  auto classify = [&](uint32_t key, bool& gt, bool& eq) {
+    if (mode == 0) { gt = key > kth; eq = key == kth; }
+    else { gt = __uint_as_float(key) > thr_f; eq = false; }   // norm.gt(threshold), policies.py:28
+  };
+  uint32_t my_gt = 0, my_eq = 0;
+  for (int i = i_lo; i < i_hi; ++i) {
+    bool gt, eq;
+    classify(keys[i], gt, eq);
+    my_gt += gt;
+    my_eq += eq;
+  }
+  // exclusive scan of (eq << 16 | gt) over the workgroup (N <= 16384 < 65536: the halves cannot carry into each other)
+  const uint32_t mine = (my_eq << 16) | my_gt;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  uint32_t gt_run = before & 0xffffu, eq_run = before >> 16;
   int32_t* out = idx + (int64_t)b * kcap;
-  for (int base = 0; base < N; base += SEL_THREADS) {
-    const int i = base + tid;
-    bool is_eq = false, is_sel = false;
-    uint32_t key = 0;
-    if (i < N) {
-      key = keys[i];
-      if (mode == 0) {
-        is_eq = (key == kth);
-        is_sel = (key > kth);
-      } else {
-        is_sel = __uint_as_float(key) > thr;  // norm.gt(threshold), policies.py:28
-      }
-    }
-    const unsigned long long lower = (1ull << lane) - 1ull;
-    uint32_t eq_rank = 0;
-    if (mode == 0) {
-      const unsigned long long beq = __ballot(is_eq);
-      if (lane == 0) wsum[wave] = (uint32_t)__popcll(beq);
-      __syncthreads();
-      eq_rank = eq_run + (uint32_t)__popcll(beq & lower);
-      for (int w = 0; w < wave; ++w) eq_rank += wsum[w];
-      if (is_eq && eq_rank < need_eq) is_sel = true;
-      eq_run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-    const unsigned long long bsel = __ballot(is_sel);
-    if (lane == 0) wsum[4 + wave] = (uint32_t)__popcll(bsel);
-    __syncthreads();
-    uint32_t pos = out_run + (uint32_t)__popcll(bsel & lower);
-    for (int w = 0; w < wave; ++w) pos += wsum[4 + w];
+  for (int i = i_lo; i < i_hi; ++i) {
+    bool gt, eq;
+    classify(keys[i], gt, eq);
+    const uint32_t pos = gt_run + (eq_run < need_eq ? eq_run : need_eq);   // selected tokens before i
+    const bool is_sel = gt || (eq && eq_run < need_eq);
     if (is_sel && pos < (uint32_t)kcap) out[pos] = i;
     // complement list, ascending too: #unselected before token i = i - #selected before i
-    if (rest != nullptr && i < N && !is_sel) rest[(int64_t)b * N + (i - (int)pos)] = i;
-    out_run += wsum[4] + wsum[5] + wsum[6] + wsum[7];
-    __syncthreads();
+    if (rest != nullptr && !is_sel) rest[(int64_t)b * N + (i - (int)pos)] = i;
+    gt_run += gt;
+    eq_run += eq;
   }
+  const uint32_t tot_eq = total >> 16;
+  const uint32_t out_run = (total & 0xffffu) + (tot_eq < need_eq ? tot_eq : need_eq);
   if (count != nullptr && tid == 0) count[b] = (int32_t)out_run;
 }
 
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
                   int32_t* rest, void* stream) {
-  const size_t lds = (size_t)(N + 256 + 8 + 4) * sizeof(uint32_t);
+  const size_t lds = (size_t)(N + 256 + SEL_COPIES * 256 + 8 + 4) * sizeof(uint32_t);
   if (lds > 64 * 1024)  // N near SEL_MAX_N: above the 64 KB default dynamic-LDS limit
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), lds, evt_stream(stream), norms, N, k, thr, mode, kcap,
