@@ -1,5 +1,7 @@
 """ViT backbone (API of the reference's backbones.py): position encoding, then a stack of blocks
 chosen BY CLASS NAME from `eventful_transformer.blocks` (backbones.py:46-59)."""
+import os
+
 import torch.nn as nn
 
 from eventful_transformer import blocks
@@ -29,5 +31,22 @@ class ViTBackbone(ExtendedModule):
 
     def forward(self, x):
         x = self.position_encoding(x)
-        x = self.blocks(x)
-        return x
+        # Between consecutive eventful blocks the residual stream travels as an unevaluated sum (blocks.PendingSum): the
+        # next block's first row pass performs the add together with its LayerNorm + delta norm.  Same arithmetic, one
+        # launch and one HBM round trip of the stream less per block boundary.  Blocks are still invoked through
+        # __call__ (forward hooks keep working); callers of the backbone only ever see tensors.
+        mods = list(self.blocks)
+        for i, blk in enumerate(mods):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if CHAIN_BLOCKS and _chains(blk) and nxt is not None and _chains(nxt):
+                blk._defer_output = True
+            x = blk(x)
+        return x.materialize() if isinstance(x, blocks.PendingSum) else x
+
+
+CHAIN_BLOCKS = os.environ.get("EVT_CHAIN_BLOCKS", "1") != "0"
+
+
+def _chains(blk):
+    """Blocks that can pass / take a pending residual sum: the eventful classes without adaptive token sampling."""
+    return isinstance(blk, blocks.EventfulTokenwiseBlock) and blk.ats_fraction is None

@@ -54,6 +54,31 @@ LN_EPS = 1e-6
 QK_FULL_RATIO = 0.7
 
 
+class PendingSum:
+    """Block output handed to the next block as an UNEVALUATED residual sum `src + res` (backbone-internal).
+
+    The last step of a block is `x_out = mlp_buffer + x_mid` and the first step of the next block reads x_out once to
+    normalise it; `ViTBackbone` lets consecutive eventful blocks pass (mlp_buffer, x_mid) instead, and the next block's
+    first row pass does the add, the LayerNorm and the delta norm in one sweep (writing x_out on the way, as its skip
+    connection): one HBM read of x_out and one kernel launch per block boundary less.  Never visible to callers of
+    the backbone; blocks called directly always take and return tensors."""
+
+    __slots__ = ("src", "res")
+
+    def __init__(self, src, res):
+        self.src, self.res = src, res
+
+    @property
+    def shape(self):
+        return self.src.shape
+
+    def materialize(self):
+        out = torch.empty_like(self.src)
+        B, N, D = self.src.shape
+        _native.row_pass(self.src, B * N, D, res=self.res, sum_out=out)
+        return out
+
+
 def _window_map(input_size, window_size, device):
     """(windows, window_len) int32: clip-row index of each window token, -1 for padding.
 
@@ -390,7 +415,7 @@ class EventfulTokenwiseBlock(Block):
         """Gated row total for MAC accounting (one readback, counting mode only)."""
         return B * cap if count is None else int(count.sum().item())
 
-    def _group(self, gate, buffer, src, res, ln, linear_fn, out_features, tag, sum_out=None):
+    def _group(self, gate, buffer, src, res, ln, linear_fn, out_features, tag, sum_out=None, count_res=True):
         """Generic gate group.  src (+res) -> [LN] -> gate -> linear_fn on gated rows -> buffer rows.
 
         Returns (buffer state, idx, count, cap); idx is None on the first frame of a clip."""
@@ -398,7 +423,7 @@ class EventfulTokenwiseBlock(Block):
         rows = B * N
         stgt = isinstance(gate, SimpleSTGTGate)
         ln_w, ln_b = (None, None) if ln is None else self._ln(ln)
-        if res is not None:
+        if res is not None and count_res:
             self._count_add(rows * D)
         if gate.first:
             gate.first = False
@@ -468,22 +493,26 @@ class EventfulTokenwiseBlock(Block):
             self.mlp_2.count_rows(n)
 
     # ---------------------------------------------------------------------------------------------
-    def _forward_pre_attention(self, x):
-        """LN1 -> qkv gate -> QKV -> qkv buffer (blocks.py:452-463 + :491)."""
-        return self._group(self.qkv_gate, self.qkv_accumulator, x, None, 1, self._linear_fn(self.qkv), 3 * self.dim,
-                           "qkv")
+    def _forward_pre_attention(self, x, res=None, sum_out=None):
+        """LN1 -> qkv gate -> QKV -> qkv buffer (blocks.py:452-463 + :491).  With `res` the block input is the pending
+        sum x + res of the previous block, written to `sum_out` by the same row pass (the add was counted there)."""
+        return self._group(self.qkv_gate, self.qkv_accumulator, x, res, 1, self._linear_fn(self.qkv), 3 * self.dim,
+                           "qkv", sum_out=sum_out, count_res=False)
 
-    def _forward_post_attention(self, attn, skip):
-        """projection group, +skip, LN2, mlp group, +skip (blocks.py:430-450)."""
+    def _forward_post_attention(self, attn, skip, defer=False):
+        """projection group, +skip, LN2, mlp group, +skip (blocks.py:430-450).  defer: leave the last add to the
+        next block's first row pass (returns a PendingSum)."""
         B, N, D = attn.shape
         proj, _, _, _ = self._group(self.projection_gate, self.projection_accumulator, attn, None, None,
                                     self._linear_fn(self.projection), D, "projection")
         x2 = self._ws("x_mid", (B, N, D), torch.float32, attn)
         mlp, _, _, _ = self._group(self.mlp_gate, self.mlp_accumulator, proj, skip, 2, self._mlp_fn, D, "mlp",
                                    sum_out=x2)
+        self._count_add(B * N * D)
+        if defer:
+            return PendingSum(mlp, x2)
         out = torch.empty((B, N, D), dtype=torch.float32, device=attn.device)
         _native.row_pass(mlp, B * N, D, res=x2, sum_out=out)
-        self._count_add(B * N * D)
         return out
 
     def _forward_attention(self, qkv, idx, count, cap, B, N):
@@ -493,12 +522,19 @@ class EventfulTokenwiseBlock(Block):
         return ats if ats is not None else (attn, None)
 
     def forward(self, x):
-        x = self._check_input(x)
-        B, N, _ = x.shape
-        qkv, idx, count, cap = self._forward_pre_attention(x)
+        defer, self._defer_output = getattr(self, "_defer_output", False), False   # set by ViTBackbone, one call only
+        if isinstance(x, PendingSum):
+            B, N, D = x.shape
+            xin = self._ws("x_in", (B, N, D), torch.float32, x.src)
+            qkv, idx, count, cap = self._forward_pre_attention(x.src, res=x.res, sum_out=xin)
+            x = xin
+        else:
+            x = self._check_input(x)
+            B, N, _ = x.shape
+            qkv, idx, count, cap = self._forward_pre_attention(x)
         attn, ats_index = self._forward_attention(qkv, idx, count, cap, B, N)
         skip = x if ats_index is None else self._ats_rows(x, ats_index)   # blocks.py:426,493
-        return self._forward_post_attention(attn, skip)
+        return self._forward_post_attention(attn, skip, defer=defer and ats_index is None)
 
 
 class EventfulMatmul1Block(EventfulTokenwiseBlock):
@@ -549,6 +585,18 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
             self.relative_position.count_fused(B, H)
         return acc.product, kv, Nk, idx_k, count_k, cap_k
 
+    def _defer_scores(self, B, N):
+        """Marks `matmul_accumulator_1.product` stale: it is recomputed (one K4 launch over the current token buffer,
+        allocating the tensor if need be) when -- and only if -- somebody reads the attribute."""
+        acc, owner, D, H, scale = self.matmul_accumulator_1, self.qkv_accumulator, self.dim, self.heads, self.scale
+
+        def refresh():
+            buf = owner.b
+            if acc._product is None or acc._product.shape != (B, H, N, N):
+                acc._product = torch.empty((B, H, N, N), dtype=torch.float32, device=buf.device)
+            _native.qk_packed(buf, B, N, D, H, scale, acc._product)
+        acc.defer(refresh)
+
     def _first_frame_fused(self, qkv, B, N, attn, a_state=None, pv=None):
         """First frame of a clip through K8: q.k^T state, probabilities, A.v state and the block's attention output
         from ONE launch (MatmulBuffer.forward_first, modules.py:224-230, + blocks.py:518-522 + modules.py:277-283).
@@ -558,10 +606,16 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         if not (acc.first and self.pool_size is None and _native.DENSE_FUSED and _native.attention_dense_fits(N, D, H)):
             return False
         acc.first = False
-        acc.product = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
+        if a_state is not None and _native.FUSED_QK:
+            # EventfulBlock whose gated frames compute the scores inside the fused kernel: nobody reads the q.k^T state,
+            # so it is neither written here (477 MB per block at B = 256) nor even allocated until somebody asks for it
+            product = None
+            self._defer_scores(B, N)
+        else:
+            product = acc.product = torch.empty((B, H, N, N), dtype=torch.float32, device=qkv.device)
         ry, rx, gh, gw, qw = self._rel_tables()
         _native.attention_dense(qkv, B, H, N, D, self.scale, _native.store_code(self._store_dtype()), out_f32=attn,
-                                rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw, product=acc.product, a_state=a_state, pv=pv)
+                                rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw, product=product, a_state=a_state, pv=pv)
         acc.matmul.count_product(B * H * N * N, D // H)
         if self.relative_position is not None:
             self.relative_position.count_fused(B, H)
@@ -634,8 +688,7 @@ class EventfulBlock(EventfulMatmul1Block):
             # token buffer; K4 and the write + read of the (B,H,N,N) score state are skipped.  The state attribute is
             # refreshed lazily if anybody reads it (MatmulBuffer.defer).
             product, kv, Nk, idx_k, count_k, cap_k = None, None, N, idx, count, cap
-            buf, state, scale = self.qkv_accumulator.b, acc1._product, self.scale
-            acc1.defer(lambda: _native.qk_packed(buf, B, N, D, H, scale, state))
+            self._defer_scores(B, N)
             if acc1.matmul.count_mode:
                 n_sel = self._n_rows(B, cap, count)
                 acc1.matmul.count_product(2 * H * N * n_sel, dh)

@@ -533,3 +533,29 @@ def test_adaptive_token_sampling_needs_batch_equal_heads():
     blk = H.product_block("Block", params, 64, 4, (6, 6), ats_fraction=0.5)
     with pytest.raises(RuntimeError, match="batch == heads"):
         blk(torch.randn(2, 37, 64, device=DEV))
+
+
+def test_lazy_qk_state_is_exact_when_read():
+    """ViViT-shaped EventfulBlock (head dim 64, <= 256 tokens): on gated frames the scores are computed inside the fused
+    attention kernel and `matmul_accumulator_1.product` is only refreshed when read -- it must then be the exact q.k^T of the
+    CURRENT token buffer (I1), and EVT_FUSED_QK=0 (K4 + stored state) must give the same block outputs to rounding."""
+    from eventful_transformer import _native, policies
+    sd = H.backbone_params(1, 768, 4, 5, 197)
+    xs = O.make_token_stream(2, 197, 768, 3, 128, seed=9, small=0.01)
+    outs = {}
+    for fused in (True, False):
+        old, _native.FUSED_QK = _native.FUSED_QK, fused
+        try:
+            blk = H.product_block("EventfulBlock", H.block_params_of(sd, 0), 768, 12, (14, 14), matmul_2_cast="bfloat16")
+            H.set_policies(blk, policies.TokenNormTopK, k=128)
+            with torch.inference_mode():
+                outs[fused] = [blk(xs[t].to(DEV)).cpu() for t in range(3)]
+                state = blk.matmul_accumulator_1.product            # read: triggers the refresh when stale
+                q, k, _ = blk.qkv_accumulator.b.cpu().view(2, 197, 3, 12, 64).permute(2, 0, 3, 1, 4)
+                want = (q / 8.0) @ k.transpose(-2, -1)
+                assert state.shape == (2, 12, 197, 197)
+                assert torch.allclose(state.cpu(), want, atol=2e-4), float((state.cpu() - want).abs().max())
+        finally:
+            _native.FUSED_QK = old
+    for a, b_ in zip(outs[True], outs[False]):
+        assert float((a - b_).abs().max()) <= 1e-3
