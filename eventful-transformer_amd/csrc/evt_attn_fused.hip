@@ -88,6 +88,7 @@ struct FusedArgs {
   int B, H, N, Nk, D, dh, kcap, gh, gw, qw;   // N rows x Nk columns; gh x gw: KEY grid; qw: query grid width
   float scale;                                // QK mode: q / scale (blocks.py:514)
   int qk_split;                               // QK mode: 1 = bf16 hi/lo split products, 0 = exact fp32 products
+  const float* norm_ref; float* norm_parts;   // optional: (B,N,D) reference of the next gate -> (B,N,H) partial ||out - ref||^2
 };
 
 constexpr int QKC = 64;       // QK mode: keys per chunk (16 per wave)
@@ -171,6 +172,8 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   constexpr int PIT = FR * (64 * TPW / 8) / 256;      // 8-channel state pieces per thread (epilogue)
   union Pv8 { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; };
   Pv8 pvr[PIT];
+  union Ref8 { float4 v[2]; float f[8]; };
+  Ref8 nrr[PIT];   // the next gate's reference values of the same 8 channels (norm_ref), for the fused delta norm
   auto load_pv = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
@@ -178,6 +181,10 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       const int64_t o = ((int64_t)b * a.N + (i < a.N ? i : a.N - 1)) * a.D + h * a.dh + c8;   // clamped: branch-free
 #pragma unroll
       for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) pvr[it].u[q] = reinterpret_cast<const uint4*>(pv + o)[q];
+      if (a.norm_ref != nullptr) {   // wave-uniform
+        nrr[it].v[0] = reinterpret_cast<const float4*>(a.norm_ref + o)[0];
+        nrr[it].v[1] = reinterpret_cast<const float4*>(a.norm_ref + o)[1];
+      }
     }
   };
 
@@ -565,8 +572,8 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
   for (int it = 0; it < PIT; ++it) {
     const int e = tid + 256 * it, row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8;
     const int i = i0 + row;
-    if (i >= a.N) continue;
-    const int64_t o = ((int64_t)b * a.N + i) * a.D + h * a.dh + c8;
+    const bool ok = i < a.N;
+    const int64_t o = ((int64_t)b * a.N + (ok ? i : a.N - 1)) * a.D + h * a.dh + c8;
     Pv8 st8 = pvr[it];
     union { float4 v[2]; float f[8]; } o8;
 #pragma unroll
@@ -576,10 +583,21 @@ __global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a
       Store<T>::store(&st8.t[q], v);
       o8.f[q] = v;
     }
+    if (ok) {
 #pragma unroll
-    for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + o)[q] = st8.u[q];
-    reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
-    reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + o)[q] = st8.u[q];
+      reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
+      reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+    }
+    if (a.norm_parts != nullptr) {   // wave-uniform
+      // ||out - ref||^2 over this head's channels: the dh/8 threads of a row are consecutive lanes; their sums are
+      // combined in a fixed butterfly order (deterministic), the first lane of the group writes the head's partial
+      float ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float d = o8.f[q] - nrr[it].f[q]; ss = fmaf(d, d, ss); }
+      for (int m = 1; m < a.dh / 8; m <<= 1) ss += __shfl_xor(ss, m, 64);
+      if (ok && (tid & (a.dh / 8 - 1)) == 0) a.norm_parts[((int64_t)b * a.N + i) * a.H + h] = ss;
+    }
   }
 }
 
@@ -640,7 +658,8 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
   }
   FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
               d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
-              d->rel_y ? d->qw : 1, d->scale, d->qk_split};
+              d->rel_y ? d->qw : 1, d->scale, d->qk_split, d->norm_ref, d->norm_parts};
+  EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_av_gated: norm_ref / norm_parts come together");
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }

@@ -20,9 +20,11 @@ constexpr int SEL_COPIES = 16;   // private histogram copies: at most 4 lanes of
 __device__ __forceinline__ uint32_t norm_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
 // mode 0: top-k (k given); mode 1: threshold (norm > thr).
+// parts > 0: `norms` holds `parts` partial sums of SQUARES per token (written per attention head by the fused attention
+// kernel's epilogue); the norm is sqrt of their sum, added in index order (deterministic).
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ norms, int N, int k, float thr,
                                                              int mode, int kcap, int32_t* __restrict__ idx,
-                                                             int32_t* __restrict__ count, int32_t* __restrict__ rest) {
+                                                             int32_t* __restrict__ count, int32_t* __restrict__ rest, int parts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* keys = smem;               // N
   uint32_t* hist = smem + N;           // 256 bin totals
@@ -31,8 +33,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
   uint32_t* bc = wsum + 8;             // 4 broadcast words
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
-  const float* nrm = norms + (int64_t)b * N;
-  for (int i = tid; i < N; i += SEL_THREADS) keys[i] = norm_key(nrm[i]);
+  if (parts > 0) {
+    const float* sq = norms + (int64_t)b * N * parts;
+    for (int i = tid; i < N; i += SEL_THREADS) {
+      float s = 0.f;
+      for (int p = 0; p < parts; ++p) s += sq[(int64_t)i * parts + p];
+      keys[i] = norm_key(sqrtf(s));
+    }
+  } else {
+    const float* nrm = norms + (int64_t)b * N;
+    for (int i = tid; i < N; i += SEL_THREADS) keys[i] = norm_key(nrm[i]);
+  }
   __syncthreads();   // the compaction reads contiguous chunks: keys staged by other threads
 
   uint32_t kth = 0;     // key of the k-th largest element
@@ -143,12 +154,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 }
 
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
-                  int32_t* rest, void* stream) {
+                  int32_t* rest, void* stream, int parts = 0) {
   const size_t lds = (size_t)(N + 256 + SEL_COPIES * 256 + 8 + 4) * sizeof(uint32_t);
   if (lds > 64 * 1024)  // N near SEL_MAX_N: above the 64 KB default dynamic-LDS limit
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), lds, evt_stream(stream), norms, N, k, thr, mode, kcap,
-                     idx, count, rest);
+                     idx, count, rest, parts);
   return evt_check_launch("evt_select");
 }
 
@@ -174,4 +185,26 @@ extern "C" int evt_select_threshold(const float* norms, int B, int N, float thre
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold: NaN threshold");
   if (B == 0) return EVT_OK;
   return launch_select(norms, B, N, 0, threshold, 1, kcap, idx, count, rest, stream);
+}
+
+extern "C" int evt_select_topk_sq(const float* sq_parts, int parts, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream) {
+  EVT_REQUIRE(sq_parts != nullptr && idx != nullptr && parts > 0, EVT_ERR_BAD_ARG, "evt_select_topk_sq: null pointer / parts");
+  EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk_sq: B=%d N=%d", B, N);
+  EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k=%d out of range for N=%d (topk would raise)", k, N);
+  EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk_sq: N=%d exceeds %d", N, SEL_MAX_N);
+  if (B == 0) return EVT_OK;
+  EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k == 0 with a complement list");
+  if (k == 0) return EVT_OK;
+  return launch_select(sq_parts, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream, parts);
+}
+
+extern "C" int evt_select_threshold_sq(const float* sq_parts, int parts, int B, int N, float threshold, int kcap, int32_t* idx,
+                                       int32_t* count, int32_t* rest, void* stream) {
+  EVT_REQUIRE(sq_parts != nullptr && idx != nullptr && count != nullptr && parts > 0, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: null pointer / parts");
+  EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: B=%d N=%d", B, N);
+  EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: kcap=%d must be >= N=%d", kcap, N);
+  EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold_sq: N=%d exceeds %d", N, SEL_MAX_N);
+  EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: NaN threshold");
+  if (B == 0) return EVT_OK;
+  return launch_select(sq_parts, B, N, 0, threshold, 1, kcap, idx, count, rest, stream, parts);
 }

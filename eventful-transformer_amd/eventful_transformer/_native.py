@@ -23,7 +23,7 @@ _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EV
 ABI_VERSION = 3   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
-    "evt_select_threshold", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
+    "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense",
 )
@@ -90,6 +90,7 @@ class SoftmaxAvDesc(Structure):
         ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
         ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
         ("store", c_int32), ("Nk", c_int32), ("qw", c_int32), ("scale", c_float), ("qk_split", c_int32),
+        ("norm_ref", c_void_p), ("norm_parts", c_void_p),
     ]
 
 
@@ -118,6 +119,8 @@ def _bind(lib):
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
         "evt_select_threshold": [P, I, I, F, I, P, P, P, P],
+        "evt_select_topk_sq": [P, I, I, I, I, P, P, P],
+        "evt_select_threshold_sq": [P, I, I, I, F, I, P, P, P, P],
         "evt_gate_gather_update": [P, P, P, P, I, I, I, I, P, P, I, P],
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
@@ -223,12 +226,19 @@ def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=Non
                                _p(norms), rows, D, _stream()))
 
 
-def select_topk(norms, B, N, k, idx, rest=None):
-    _check(load().evt_select_topk(_p(norms), B, N, k, _p(idx), _p(rest), _stream()))
+def select_topk(norms, B, N, k, idx, rest=None, parts=0):
+    """parts > 0: `norms` is (B, N, parts) partial sums of squares (evt_softmax_av_gated norm_parts)."""
+    if parts:
+        _check(load().evt_select_topk_sq(_p(norms), parts, B, N, k, _p(idx), _p(rest), _stream()))
+    else:
+        _check(load().evt_select_topk(_p(norms), B, N, k, _p(idx), _p(rest), _stream()))
 
 
-def select_threshold(norms, B, N, threshold, kcap, idx, count, rest=None):
-    _check(load().evt_select_threshold(_p(norms), B, N, float(threshold), kcap, _p(idx), _p(count), _p(rest), _stream()))
+def select_threshold(norms, B, N, threshold, kcap, idx, count, rest=None, parts=0):
+    if parts:
+        _check(load().evt_select_threshold_sq(_p(norms), parts, B, N, float(threshold), kcap, _p(idx), _p(count), _p(rest), _stream()))
+    else:
+        _check(load().evt_select_threshold(_p(norms), B, N, float(threshold), kcap, _p(idx), _p(count), _p(rest), _stream()))
 
 
 def gate_gather_update(c, p, idx, count, B, N, D, kcap, c_tilde=None, e_tilde=None, update_p=True):
@@ -385,13 +395,14 @@ def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
 
 
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
-                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0, qk_split=None):
+                     qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0, qk_split=None,
+                     norm_ref=None, norm_parts=None):
     """K5+K6.  product None: the score rows are computed in the kernel from `qkv` ((q / scale) k^T; head dim 64,
     N == Nk <= 256) instead of being read from the q.k^T state."""
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
                       N if Nk is None else Nk, gw if qw is None else qw, float(scale),
-                      int(QK_SPLIT if qk_split is None else qk_split))
+                      int(QK_SPLIT if qk_split is None else qk_split), _p(norm_ref), _p(norm_parts))
     # algorithmic bytes: q.k^T state read once, gate-reference columns read + rewritten, v delta / old reads,
     # A.v state read-modify-write, fp32 output
     es, nk = (4 if store == EVT_F32 else 2), (N if Nk is None else Nk)

@@ -29,6 +29,7 @@ pooled cells by `evt_pool_index`, and K4/K5/K6 run with Nq != Nk.  `ats_fraction
 blocks.py:150-181) runs off the fast path (`_ats_attention`) and, like the reference, only when batch == heads.
 Not implemented: pooling inside windowed blocks and ATS combined with pooling / windows (raise).
 """
+import os
 from math import prod, sqrt
 
 import torch
@@ -52,6 +53,7 @@ LN_EPS = 1e-6
 # q.k^T state update: above this fraction of changed state entries the whole product is recomputed instead of the
 # row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
 QK_FULL_RATIO = 0.7
+FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
 
 
 class PendingSum:
@@ -388,8 +390,9 @@ class EventfulTokenwiseBlock(Block):
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
     # ---------------------------------------------------------------------------------------------
-    def _select(self, gate, c, norms, B, N, tag):
-        """Runs the gate's policy on the norms already produced by the row pass."""
+    def _select(self, gate, c, norms, B, N, tag, parts=0):
+        """Runs the gate's policy on the norms already produced by the row pass (parts > 0: on the per-head partial
+        sums of squares produced by the fused attention epilogue)."""
         policy = gate.policy
         if isinstance(policy, _NormPolicy):
             cap = policy.capacity(N)
@@ -398,7 +401,7 @@ class EventfulTokenwiseBlock(Block):
             # the qkv gate of blocks with a q.k^T state also wants the complement list (K4 skips re-written rows)
             rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
             self._rest = rest if tag == "qkv" else self._rest
-            policy.select_into(norms, B, N, idx, count, rest)
+            policy.select_into(norms, B, N, idx, count, rest, parts=parts)
             return idx, count, cap
         # Any other callable gets the delta tensor like in the reference (modules.py:149).
         index = policy(c - gate.p, dim=-1)
@@ -458,13 +461,18 @@ class EventfulTokenwiseBlock(Block):
                 _native.gate_gather_update(raw, gate.p, idx, count, B, N, D, cap, update_p=True)
             linear_fn(c, idx, count, buffer.b, None, B, cap)
         else:
+            parts = 0
             if ln is None and res is None:
                 c = src  # the gate input already exists in HBM: only the norms are new
-                _native.row_pass(src, rows, D, p=gate.p, norms=norms)
+                ready, self._norm_parts_ready = getattr(self, "_norm_parts_ready", None), None
+                if ready is not None and tag == "projection":
+                    norms, parts = ready   # ||src - p||^2 per head came out of the fused attention epilogue
+                else:
+                    _native.row_pass(src, rows, D, p=gate.p, norms=norms)
             else:
                 _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
                                  p=gate.p, norms=norms)
-            idx, count, cap = self._select(gate, c, norms, B, N, tag)
+            idx, count, cap = self._select(gate, c, norms, B, N, tag, parts=parts)
             linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap)
             if stgt:
                 _native.row_pass(c, rows, D, c_out=gate.p)
@@ -719,8 +727,15 @@ class EventfulBlock(EventfulMatmul1Block):
             v_old = self._ws("v_old_t", (B, D, cap_k), sdt, qkv)
             _native.v_gate(vsrc, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True,
                            transposed=True, **vkw)
+            # The projection gate's delta norm ||attn - p||^2 comes out of the same epilogue, per head (the select kernel
+            # adds the H partials): no separate pass over the attention output.
+            pg = self.projection_gate
+            fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
+            nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
             _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state, attn, B, H, N, D,
-                                     store, Nk=Nk, scale=self.scale, **rel)
+                                     store, Nk=Nk, scale=self.scale, norm_ref=pg.p if fuse_norm else None,
+                                     norm_parts=nparts, **rel)
+            self._norm_parts_ready = (nparts, H) if fuse_norm else None
         else:
             a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)
             a_delta = self._ws("a_delta", (B, H, N, cap_k), sdt, qkv)

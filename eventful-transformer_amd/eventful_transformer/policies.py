@@ -52,9 +52,10 @@ class _NormPolicy(ExtendedModule):
         """Exact per-clip count if it is data-independent, else None."""
         raise NotImplementedError
 
-    def select_into(self, norms, B, N, idx, count, rest=None):
+    def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         """norms (B,N) f32 -> idx (B,capacity) int32 ascending; `count` (B,) int32 if data-dependent;
-        `rest` (B,N) int32, optional: the complement list (unselected tokens, ascending)."""
+        `rest` (B,N) int32, optional: the complement list (unselected tokens, ascending).
+        parts > 0: `norms` holds (B,N,parts) partial sums of squares instead (fused attention epilogue)."""
         raise NotImplementedError
 
 
@@ -72,9 +73,9 @@ class TokenNormThreshold(_NormPolicy):
     def fixed_count(self, n_tokens):
         return None
 
-    def select_into(self, norms, B, N, idx, count, rest=None):
+    def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
-        _native.select_threshold(norms, B, N, self.threshold, idx.shape[-1], idx, count, rest)
+        _native.select_threshold(norms, B, N, self.threshold, idx.shape[-1], idx, count, rest, parts=parts)
 
     def forward(self, x, dim=-1):
         # The reference asserts batch 1 because nonzero() flattens the batch (policies.py:25).
@@ -107,9 +108,9 @@ class TokenNormTopK(_NormPolicy):
     def fixed_count(self, n_tokens):
         return self._k(n_tokens)
 
-    def select_into(self, norms, B, N, idx, count, rest=None):
+    def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
-        _native.select_topk(norms, B, N, self._k(N), idx, rest)
+        _native.select_topk(norms, B, N, self._k(N), idx, rest, parts=parts)
 
     def forward(self, x, dim=-1):
         norms, lead, N = _token_norms(x, dim)

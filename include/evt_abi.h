@@ -91,6 +91,12 @@ EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* 
 EVT_API int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream);
 EVT_API int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap,
                          int32_t* idx, int32_t* count, int32_t* rest, void* stream);
+/* The same selections from PARTIAL SUMS OF SQUARES: norm[b,i] = sqrt(sum_p sq_parts[(b*N + i)*parts + p]), the parts added
+ * in index order.  evt_softmax_av_gated can emit ||attention output - projection_gate.p||^2 per head (norm_parts), which
+ * makes the projection gate's delta-norm pass over the attention output (modules.py:149 + policies.py:63) unnecessary. */
+EVT_API int evt_select_topk_sq(const float* sq_parts, int parts, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream);
+EVT_API int evt_select_threshold_sq(const float* sq_parts, int parts, int B, int N, float threshold, int kcap,
+                                    int32_t* idx, int32_t* count, int32_t* rest, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K2  Gate gather + reference update for the selected tokens (rows):
@@ -316,6 +322,9 @@ typedef struct evt_softmax_av_desc {
   float scale;                            /* product == NULL: q / scale (blocks.py:514)          */
   int32_t qk_split;                       /* product == NULL: 1 = q, k as bf16 hi + lo (3 bf16 MFMAs */
                                           /* per product, like evt_qk split), 0 = exact fp32 MFMA    */
+  const float* norm_ref;                  /* nullable (B,N,D): the NEXT gate's reference (projection_gate.p) */
+  float* norm_parts;                      /* with norm_ref: (B,N,H) out, ||out_f32 - norm_ref||^2 over the   */
+                                          /* head's channels -> evt_select_*_sq(parts = H)                   */
 } evt_softmax_av_desc;
 
 EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);

@@ -541,8 +541,19 @@ def test_fused_attention_in_kernel_qk(cast, N, k, rel, qk_split):
             v_del = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
             v_old = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
             n.v_gate(bd, idx_cap, count, B, N, D, cap, vp, v_del, v_old, store, True, transposed=True)
+            ref_next = torch.randn(B, N, D, generator=g).to(DEV)      # stands for the projection gate's reference
+            parts = torch.full((B, N, H), float("nan"), device=DEV)
             n.softmax_av_gated(None, ap, idx_cap, count, cap, v_del, v_old, pv, out, B, H, N, D, store, qkv=bd, scale=scale,
-                               qk_split=qk_split, **relkw)
+                               qk_split=qk_split, norm_ref=ref_next, norm_parts=parts, **relkw)
+            # fused delta norm: per-head ||out - ref||^2, and the selection from those partials == selection from the norms
+            want_parts = (out - ref_next).view(B, N, H, dh).pow(2).sum(-1)
+            assert torch.allclose(parts, want_parts, rtol=1e-5, atol=1e-6), float((parts - want_parts).abs().max())
+            kk_sel = max(1, N // 3)
+            i1 = torch.empty(B, kk_sel, dtype=torch.int32, device=DEV)
+            i2 = torch.empty(B, kk_sel, dtype=torch.int32, device=DEV)
+            n.select_topk(parts.sum(-1).sqrt().contiguous(), B, N, kk_sel, i1)
+            n.select_topk(parts, B, N, kk_sel, i2, parts=H)
+            assert torch.equal(i1, i2)
         # probabilities are rounded to the store type from scores computed in a different fp32 summation order than the
         # CPU's: allow one ulp of the store type at p <= 1 (bf16 2^-8, fp16 2^-11)
         atol_p = {None: tol * 0.1 + 3e-6, "bfloat16": 4e-3, "float16": 5e-4}[cast]
