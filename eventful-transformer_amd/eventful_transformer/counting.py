@@ -94,12 +94,15 @@ class CountedLinear(ExtendedModule):
         self.weight = nn.Parameter(torch.zeros((out_features, in_features), device=device, dtype=dtype))
         self.bias = nn.Parameter(torch.zeros(out_features, device=device, dtype=dtype))
         self._split = None
+        # load_state_dict copies into `.data` without bumping the tensor version the cache below is keyed on
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.reset_self())
 
     def split_planes(self):
         """bf16 hi/lo planes of `weight` for the split-precision MFMA path (None when it does not apply).
         Cached against the weight's storage address + version and dropped on reset(), the same policy the
         reference applies to its cached rel-pos tables / position encodings ("just in case new weights get
-        loaded", utils.py:102-105,191-195)."""
+        loaded", utils.py:102-105,191-195) and on load_state_dict().  Other in-place writes through `weight.data` keep
+        pointer and version: call reset() after them."""
         w = self.weight
         key = (w.data_ptr(), w._version, _native.GEMM_MODE)
         if self._split is None or self._split[0] != key:

@@ -373,9 +373,9 @@ def test_pooled_eventful_block_head_dim_64(cast, policy):
                 assert blk.matmul_gate.p.shape == (1, 4, 64, 16) and blk.v_gate.p.shape == (1, 4, 16, 64)
 
 
-@pytest.mark.parametrize("policy,kw,windowed", [("TokenNormTopK", dict(k=20), False), ("TokenNormThreshold", dict(threshold=0.8), False),
-                                                ("TokenNormTopK", dict(k=30), True)])
-def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed):
+@pytest.mark.parametrize("policy,kw,windowed,resized", [("TokenNormTopK", dict(k=20), False, False), ("TokenNormThreshold", dict(threshold=0.8), False, False),
+                                                        ("TokenNormTopK", dict(k=30), True, False), ("TokenNormTopK", dict(k=20), False, True)])
+def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed, resized):
     """HIP-graph replay of the first / incremental frame (graphs.py) against the eager path: same kernels on the
     same buffers, so outputs must be bit-identical over several clips, including the clip boundary handled by
     replaying the first-frame graph instead of reset()."""
@@ -390,7 +390,9 @@ def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed):
         if windowed:
             cfg.update(window_size=(4, 4), relative_embedding_size=(8, 8))
             extra = dict(window_indices=(0, 2), windowed_class="EventfulTokenwiseBlock", windowed_overrides=dict(matmul_2_cast=None))
-        bb = ViTBackbone(block_config=cfg, depth=3, position_encoding_size=(8, 8), input_size=(8, 8),
+        if resized:   # rel-pos tables and the position encoding are bicubically resized: caches rebuilt after reset(),
+            cfg.update(relative_embedding_size=(6, 6))   # which must happen OUTSIDE the graph capture (graphs.py)
+        bb = ViTBackbone(block_config=cfg, depth=3, position_encoding_size=(4, 4) if resized else (8, 8), input_size=(8, 8),
                          block_class="EventfulBlock", **extra)
         for p_ in bb.parameters():
             torch.nn.init.normal_(p_, std=0.05)
