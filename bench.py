@@ -536,9 +536,9 @@ def gemm_source_hash():
 
 
 def pmc_traffic(clips, frames, k, cast, gemm_mode):
-    """HBM bytes per launch of the dominant kernel from the newest profiles/r*/pmc_traffic_B<clips>.json whose
-    workload AND GEMM source hash match this tree (FETCH_SIZE / WRITE_SIZE cannot be read in-process; a stale
-    file is reported as null, never replayed)."""
+    """HBM bytes per launch of the dominant kernel (+ its PMC matrix-pipe utilisation) from the newest
+    profiles/r*/pmc_traffic_B<clips>.json whose workload AND GEMM source hash match this tree (hardware counters
+    cannot be read in-process; a stale file is reported as null, never replayed)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_B{clips}.json")), reverse=True):
         try:
             pmc = json.load(open(path))
@@ -547,10 +547,14 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
                 continue
             if pmc.get("gemm_source_sha16") != gemm_source_hash():
                 continue
-            return pmc["gated_linear_hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            gl = [kr for kr in pmc["kernels"] if kr["kernel"].startswith("gated_linear") and "mfma_util_pmc" in kr]
+            n = sum(kr["launches"] for kr in gl)
+            util = {"mfma_util_pmc": round(sum(kr["mfma_util_pmc"] * kr["launches"] for kr in gl) / n, 4),
+                    "clock_ghz_pmc": round(sum(kr["clock_ghz_profiled"] * kr["launches"] for kr in gl) / n, 3)} if n else {}
+            return pmc["gated_linear_hbm_bytes_per_launch"], os.path.relpath(path, ROOT), util
         except Exception:
             continue
-    return None, None
+    return None, None, {}
 
 
 _T0 = time.perf_counter()
@@ -697,7 +701,7 @@ def main():
             # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
             # of `frac`; `mfma_issue_frac` = issued bf16 MFMA FLOP/s over the same peak (matrix-pipe utilisation).
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-            traffic, traffic_src = pmc_traffic(resident, frames, k, cast, _native.GEMM_MODE)
+            traffic, traffic_src, pmc_util = pmc_traffic(resident, frames, k, cast, _native.GEMM_MODE)
             roofline = {"bound": "mfma", "kernel": _native.gemm_kernel_name() + " (evt_gated_linear / evt_gated_mlp)",
                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -707,6 +711,10 @@ def main():
                         "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
                         "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                         "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+            if pmc_util:   # counter-measured (same PMC file): SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x 1024 SIMDs)
+                roofline.update(pmc_util)
+                roofline["mfma_util_note"] = ("matrix-pipe busy fraction of the launch's shader cycles at the sustained clock "
+                                              "(rocprofv3 PMC); mfma_issue_frac prices the same launches at the 2.4 GHz-spec peak")
         else:
             achieved = work / (ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "softmax_av_gated_kernel / attn_dense_kernel (global-block attention)",

@@ -99,8 +99,11 @@ typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 // QK: the score tile is computed here (needs NREG > 0, TPW == 1) instead of being read from the state:
 // 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = split precision (q, k as bf16 hi + lo, three
 // v_mfma_f32_16x16x32_bf16 per product, ~1e-5 relative -- the arithmetic K4 uses by default; 5x less matrix-pipe time).
+// bf16 / fp16 store at head dim 64 (ViViT / ViT-B with matmul_2_cast): three workgroups per CU, i.e. at most 168 registers per
+// lane incl. AGPRs -- at 170 the kernel dropped to two and the gated ViViT launch went from 480 to 610 us.  The fp32-store and
+// head-dim-128 variants need more registers than that (they would spill) and stay unconstrained.
 template <typename T, int TPW, int NREG, int QK = 0>
-__global__ __launch_bounds__(256) void softmax_av_gated_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void softmax_av_gated_kernel(const FusedArgs a) {
   constexpr int P = Tile<T>::PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* An = reinterpret_cast<T*>(smem_raw);              // [FR][P]

@@ -70,6 +70,7 @@ def main():
     vo_t = torch.empty(B, D, k, device=dev, dtype=sdt)
     vd = torch.empty(B, k, D, device=dev, dtype=sdt)
     vo = torch.empty(B, k, D, device=dev, dtype=sdt)
+    nparts = torch.empty(B, N, H, device=dev)
     a_new = torch.empty(B, H, N, k, device=dev, dtype=sdt)
     a_del = torch.empty(B, H, N, k, device=dev, dtype=sdt)
     n.v_gate(qkv, idx, None, B, N, D, k, vp, vd_t, vo_t, store, True, transposed=True)
@@ -112,6 +113,9 @@ def main():
                              ("GB/s", B * H * N * (4 * N + 2 * es * k) + B * N * D * (4 + 2 * es))),
         "softmax_av_fused_qk": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0),
                                 ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 2 * es))),
+        "softmax_av_fused_qk_norm": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0,
+                                                                norm_ref=p, norm_parts=nparts),
+                                     ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 4 + 2 * es))),
         "softmax_gated": (lambda: n.softmax_gate(product, ap_, B, H, N, N, D, store, a_new=a_new, a_delta=a_del,
                                                  idx=idx, kcap=k, gated=True),
                           ("GB/s", B * H * N * (4 * N + 4 * es * k))),
