@@ -11,6 +11,9 @@ struct LinArgs {
   float* ws; int64_t ws_bytes;
 };
 
+// evt_linear_big.hip: 256-row tiles for launches that fill the chip; false = not taken (run the 128x128 kernel)
+bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

@@ -245,6 +245,9 @@ __device__ __forceinline__ int splitk_dynamic(const int32_t* count, int B, int t
 // applied to the SOURCE chunk each lane fetches) into one of TWO weight buffers, one k-tile ahead; a counted
 // s_waitcnt leaves the next tile's loads in flight across the (raw) barriers.  Removes the weight ds_write_b128 (52 of
 // the ~164 LDS-pipe cycles a wave spends per k-tile) and 16 staging registers.
+#ifndef EVT_ABLATE   // timing experiments only (results are wrong): 1 no in-loop global loads, 2 + no staging, 3 + no fragment reads, 4 + no barriers
+#define EVT_ABLATE 0
+#endif
 template <int ACT, int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM_MIN_BLOCKS : 1)) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
   constexpr int NT = WM * WN * 64;
@@ -451,8 +454,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   const int lr = lane & 31, lh = lane >> 5;
   if (WDMA) issue_w(t0, 0);
   fetch(t0 * TBK);
+#if EVT_ABLATE >= 3 && EVT_ABLATE != 5   // timing experiment: loop-invariant fragments (read once from the staged first tile)
+  stage();
+  __syncthreads();
+  bf16x8_t abl_f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) abl_f[i] = *reinterpret_cast<const bf16x8_t*>(lds + (i * 64 + lane) * 8);
+#endif
   for (int t = t0; t < nk; ++t) {
+#if EVT_ABLATE < 2 || EVT_ABLATE == 5
     stage();
+#endif
     const bool upd_now = do_upd && (t % tiles_n) == bn;
     if (upd_now) {
       const int kc = t * TBK + ac4 * 4;
@@ -460,7 +472,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       for (int j = 0; j < AJ; ++j)
         if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
     }
+#if EVT_ABLATE < 1 || EVT_ABLATE == 5
     if (t + 1 < nk) fetch((t + 1) * TBK);   // before the barrier: the requests do not wait for the slowest wave's staging
+#endif
     const int wbuf = WDMA ? ((t - t0) & 1) * BBUF : 0;
     if (WDMA) {
       // k-tile t + 1 goes into the other weight buffer: its last readers (k-tile t - 1) passed the barrier that ended
@@ -471,12 +485,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // last tile, or stores of the p refresh in the queue
       __builtin_amdgcn_s_barrier();
     } else {
+#if EVT_ABLATE < 4 || EVT_ABLATE == 5
       __syncthreads();
+#endif
     }
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < TBK; ks += 16) {
       bf16x8_t ah[2], al[2], bh[2], bl[2];
+#if EVT_ABLATE >= 3 && EVT_ABLATE != 5
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ah[i] = abl_f[0 + i]; al[i] = abl_f[2 + i]; bh[i] = abl_f[4 + i]; bl[i] = abl_f[6 + i]; }
+#else
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ao = lds_off(wm * 64 + i * 32 + lr, ks + 8 * lh);
@@ -486,6 +506,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
         bh[i] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
         bl[i] = *reinterpret_cast<const bf16x8_t*>(Blo + bo);
       }
+#endif
+#if EVT_ABLATE == 5   // no MFMA: the fragments are only pinned
+#pragma unroll
+      for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+#else
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -494,10 +519,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+#endif
     }
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
     if (WDMA) __builtin_amdgcn_s_barrier();   // every wave's fragment reads are complete (their MFMAs consumed them)
+#if EVT_ABLATE < 4 || EVT_ABLATE == 5
     else __syncthreads();
+#endif
   }
 
   int ncol[2];
@@ -623,6 +651,7 @@ void launch_split(const LinArgs& a, hipStream_t s) {
       return;
     }
   }
+  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_big.hip)
   switch (variant) {
     case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
     case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
