@@ -9,9 +9,13 @@ struct LinArgs {
   const int32_t* count; float* p_upd;
   int B, kcap, K, Nout, act;
   float* ws; int64_t ws_bytes;
+  // evt_linear_big.hip only (set by evt_gated_mlp for its hidden scratch): A / out hold hl32 lines instead of fp32
+  int a_planes, out_planes;
 };
 
-// evt_linear_big.hip: 256-row tiles for launches that fill the chip; false = not taken (run the 128x128 kernel)
+// evt_linear_big.hip: 256-row tiles for launches that fill the chip.  evt_big_choice: the tile configuration the launch would
+// get (0 = none: run the 128x128 kernel); evt_launch_split_big launches it (false = not taken).
+int evt_big_choice(const LinArgs& a);
 bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -19,12 +23,14 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-// GELU with the exact-erf definition (nn.GELU(), blocks.py:114).  EVT_FAST_ERF: erf by the rational approximation of
-// Abramowitz & Stegun 7.1.28, erf z = 1 - (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (|error| < 3e-7 in exact arithmetic,
-// < 2e-6 as evaluated in fp32; GELU error < 1e-6): 6 FMAs, 4 squarings, one reciprocal, no branches -- about half the
-// instructions of the device library's erff.
+// GELU with the exact-erf definition (nn.GELU(), blocks.py:114): 0.5 x (1 + erf(x / sqrt 2)).  erf by the rational
+// approximation of Abramowitz & Stegun 7.1.28, erf z = 1 - (1 + a1 z + ... + a6 z^6)^-16 for z >= 0 (|error| < 3e-7 in exact
+// arithmetic, < 2e-6 as evaluated in fp32, so GELU(x) is off by at most ~1e-6 |x| -- below the 1e-5 of the split-precision
+// product that feeds it): 6 FMAs, 4 squarings, one reciprocal, no branches, about a third of the instructions of the device
+// library's erff.  The epilogue of the 256-row kernel is not hidden behind other workgroups' MFMAs: with erff the MLP-1
+// launch spent a quarter of its time there (474 -> 454 us at B = 256 with this form).  -DEVT_EXACT_ERF builds the erff form.
 __device__ __forceinline__ float gelu_erf(float x) {
-#ifdef EVT_FAST_ERF
+#ifndef EVT_EXACT_ERF
   const float z = fabsf(x) * 0.70710678118654752440f;
   float p = 0.0000430638f;
   p = fmaf(p, z, 0.0002765672f);

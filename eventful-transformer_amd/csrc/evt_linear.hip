@@ -638,9 +638,15 @@ void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn =
   }
 }
 
-void launch_split(const LinArgs& a, hipStream_t s) {
+int forced_tile_variant() {
   static const int forced = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : -1;
+  return forced;
+}
+
+void launch_split(const LinArgs& a, hipStream_t s) {
+  const int forced = forced_tile_variant();
   const int variant = forced < 0 ? 0 : forced;
+  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_big.hip)
   static const int splitk_on = getenv("EVT_GEMM_SPLITK") ? atoi(getenv("EVT_GEMM_SPLITK")) : 1;
   if (variant == 0 && splitk_on && a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {
     const int M = a.B * a.kcap;
@@ -651,7 +657,6 @@ void launch_split(const LinArgs& a, hipStream_t s) {
       return;
     }
   }
-  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_big.hip)
   switch (variant) {
     case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
     case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
@@ -744,10 +749,16 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
   EVT_REQUIRE(d->W1_split == nullptr || ((d->D & 7) == 0 && (d->Dh & 7) == 0), EVT_ERR_BAD_SHAPE, "evt_gated_mlp: split weights need D, Dh %% 8 == 0");
   LinArgs fc1{d->A, d->lda, d->idx, d->idx ? d->rows : d->kcap, d->W1, (const uint16_t*)d->W1_split, d->b1, d->hidden, (int64_t)d->Dh, nullptr,
               d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF, (float*)d->workspace, d->workspace_bytes};
-  int rc = launch_linear(fc1, stream);
-  if (rc != EVT_OK) return rc;
   LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, (const uint16_t*)d->W2_split, d->b2, d->out, d->ldo, d->idx,
               d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE, (float*)d->workspace, d->workspace_bytes};
+  // Both launches on the 256-row kernel: the hidden scratch holds hl32 lines (same bytes as fp32) -- GELU(x) is split once,
+  // in the first launch's epilogue, and the second launch stages it without conversion.
+  if (fc1.Wsplit != nullptr && forced_tile_variant() < 0 && (d->Dh & 31) == 0 && evt_big_choice(fc1) != 0 && evt_big_choice(fc2) != 0) {
+    fc1.out_planes = 1;
+    fc2.a_planes = 1;
+  }
+  int rc = launch_linear(fc1, stream);
+  if (rc != EVT_OK) return rc;
   return launch_linear(fc2, stream);
 }
 

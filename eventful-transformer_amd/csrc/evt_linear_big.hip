@@ -22,22 +22,46 @@
 
 namespace {
 
+#ifndef EVT_PINGPONG
+#define EVT_PINGPONG 1
+#endif
 #ifndef EVT_EPI_FAST
 #define EVT_EPI_FAST 1
+#endif
+#ifdef EVT_PROF   // phase timing of two waves of workgroup 0 (scripts/gemm_prof.py): s_memtime at the phase boundaries
+__device__ unsigned long long evt_prof_buf[2][8];
+#define EVT_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
+#else
+#define EVT_TICK(slot) do { } while (0)
 #endif
 #ifndef EVT_ABLATE   // timing experiments only (results are wrong)
 #define EVT_ABLATE 0
 #endif
 
-template <int ACT, int TBM, int TBN, int WM, int WN>
+// FMT bit 0 (APL): the activations are already split -- A holds hl32 lines like the weights (row pitch lda * 4 bytes, i.e. the
+// bytes of the fp32 row it replaces); staging is then a plain 16-byte copy, no conversion.  FMT bit 1 (OPL): the output is
+// written as hl32 lines instead of fp32 (same bytes).  evt_gated_mlp uses both for its hidden scratch: the first launch's
+// epilogue splits GELU(x) once per element instead of the second launch splitting it once per column tile in its k loop.
+template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel(const LinArgs g, int tiles_n, int tiles_total) {
   constexpr int NT = WM * WN * 64, TBK = 32;
+  constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0;
   constexpr int MI = TBM / WM / 32, NJ = TBN / WN / 32;   // 32x32 accumulators per wave: MI x NJ
+  // Ping-pong pacing (pre-split activations only): TWO barriers per k-tile, the multiply-first group running one barrier
+  // interval behind, so that on every SIMD one wave multiplies ALONE (all of its fragment reads requested up front) while its
+  // partner stages and fetches.  In-kernel phase timing (scripts/gemm_prof.py): with one barrier the two multiplies of a SIMD
+  // overlap, the younger wave gets the matrix pipe only in the older one's LDS waits, and its staging then runs with nothing
+  // beside it (4000 ticks per k-tile; 36 MFMAs = 1152 per wave).  With fp32 activations the staging segment (48 conversion
+  // VALU per k-tile, starved by the partner's MFMA priority: ~2200 ticks) is longer than a multiply and ping-pong loses.
+  constexpr bool PP = EVT_PINGPONG != 0 && APL && MI * NJ <= 6;   // (the 2x4 wave tile has no registers for a second fragment set)
   static_assert(TBM == WM * MI * 32 && TBN == WN * NJ * 32, "wave tiles are multiples of 32");
   static_assert(TBM <= NT && TBN <= NT, "one thread per row / column fills the output-row and bias tables");
   // 64-byte LDS rows, 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3) (see gated_linear_split_kernel)
   auto lds_off = [](int row, int k) { return row * TBK + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7); };
-  constexpr int STAGE = 2 * TBM * TBK + 2 * TBN * TBK;   // bf16 elements: A hi, A lo, W hi, W lo
+  // The weight lo plane starts 64 bytes (16 banks) past a multiple of 128: the 8 lanes of a ds_write_b128 group store the 4 hi and
+  // the 4 lo chunks of one weight row (one 128-byte hl32 line of global memory), which must not meet in the same banks.
+  constexpr int WPAD = 32, APAD = APL ? 32 : 0;   // (pre-split activations are staged the same way)
+  constexpr int STAGE = 2 * TBM * TBK + APAD + 2 * TBN * TBK + WPAD;   // bf16 elements: A hi, (pad), A lo, W hi, (pad), W lo
   extern __shared__ __attribute__((aligned(16))) unsigned char evt_gemm_big_smem[];
   __bf16* lds = reinterpret_cast<__bf16*>(evt_gemm_big_smem);
   uint32_t* orow_tab = reinterpret_cast<uint32_t*>(lds + 2 * STAGE);   // 2 x TBM: byte offset of each output row, ~0 = no such row
@@ -57,8 +81,16 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const bool stage_first = ((wave >> 2) & 1) == 0;   // waves w, w + 4, w + 8, ... share a SIMD: each SIMD gets both groups
+#ifdef EVT_NO_STAGGER   // timing experiment
+  const bool stage_first = true;
+#else
+  const bool stage_first = ((wave >> 2) & 1) == 0;
+#endif   // waves w, w + 4, w + 8, ... share a SIMD: each SIMD gets both groups
   const int M = g.B * g.kcap;
+#ifdef EVT_PROF
+  const bool prof_on = blockIdx.x == 8 && (wave == 0 || wave == 4);
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
 
   constexpr int ACH = TBK / 4, AROWS = NT / ACH, AJ = TBM / AROWS;   // float4 chunks per A row, rows per pass, passes
   // weight tile: TBN rows x one 128-byte hl32 line (4 hi chunks, 4 lo chunks of 16 bytes); chunk id = tid + NT * j
@@ -82,8 +114,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   int bn_s = 0;                // column tile of the tile being staged (p refresh hand-out)
   int nsrc[AJ], nrow = 0;      // next tile: gathered row indices in flight
   float nbias = 0.f;           //            and its bias
-  auto tile_of = [&](int seq) { return run0 + c8 + seq * cx; };
-  auto issue_indices = [&](int seq) {   // the gate's index lists (and the bias) of tile `seq` -> registers (consumed by enter_tile)
+  auto tile_of = [&](int seq) __attribute__((always_inline)) { return run0 + c8 + seq * cx; };
+  auto issue_indices = [&](int seq) __attribute__((always_inline)) {   // the gate's index lists (and the bias) of tile `seq` -> registers (consumed by enter_tile)
     const int tile_i = tile_of(seq), bm_i = tile_i / tiles_n;
     const int m0 = bm_i * TBM;
     nbias = g.bias[min((tile_i - bm_i * tiles_n) * TBN + (tid < TBN ? tid : 0), g.Nout - 1)];
@@ -95,7 +127,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     const int m = m0 + tid;
     nrow = (g.o_idx != nullptr && tid < TBM) ? g.o_idx[m < M ? m : M - 1] : 0;
   };
-  auto enter_tile = [&](int seq) {   // pointers of tile `seq`, its output-row table into half seq & 1
+  auto enter_tile = [&](int seq) __attribute__((always_inline)) {   // pointers of tile `seq`, its output-row table into half seq & 1
     const int tile = tile_of(seq), bm = tile / tiles_n, bn = tile - bm * tiles_n;
     const int m0 = bm * TBM, n0 = bn * TBN;
     bn_s = bn;
@@ -127,45 +159,72 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     // s_waitcnt vmcnt(0) in front of EVERY multiply, i.e. waited for the k-tile prefetch it had just issued)
     if (tid < TBN) bias_tab[(seq & 1) * TBN + tid] = nbias;
   };
-  float4 ra[AJ];
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // (named registers: hipcc left the array form in scratch)
-  u32x4_t rw0, rw1, rw2, rw3;
-  auto fetch = [&](int kt) {   // k-tile kt of the load-side tile -> registers (K % 32 == 0: whole tiles only)
-    const uint32_t kw = (uint32_t)kt * 128u, ka = (uint32_t)kt * (TBK * 4u);
-    rw0 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[0] + kw));
-    if (WJ > 1) rw1 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 1 ? 1 : 0] + kw));
-    if (WJ > 2) rw2 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 2 ? 2 : 0] + kw));
-    if (WJ > 3) rw3 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 3 ? 3 : 0] + kw));
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(Abase + (a_off[j] + ka));
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  // Two sets of staging registers (stream elements of even / odd parity): the loads of element x + 2 are issued as soon as
+  // element x has been written to LDS, so a load has TWO iterations to arrive.  (With one set the loop could not turn
+  // faster than one load latency + one staging per iteration: ~1.4 us, more than the iteration's MFMA time.)
+  struct Regs {   // (named weight registers: hipcc left an array of them in scratch)
+    f32x4 a[AJ];   // (native vector type: arrays of HIP's float4 / uint4 structs were left in scratch)
+    u32x4_t w0, w1, w2, w3;
   };
-  auto stage = [&](int kt, int s) {   // registers (k-tile kt of the load-side tile) -> LDS stage s; column tile bn refreshes p for kt = bn (mod tiles_n)
-    __bf16* Ahi = lds + s * STAGE;
-    __bf16* Alo = Ahi + TBM * TBK;
-    __bf16* Bhi = Ahi + 2 * TBM * TBK;
-    __bf16* Blo = Bhi + TBN * TBK;
+  Regs R0, R1;
+  auto fetch = [&](Regs& R, int kt) __attribute__((always_inline)) {   // k-tile kt of the load-side tile -> registers (K % 32 == 0: whole tiles only)
+    const uint32_t kw = (uint32_t)kt * 128u, ka = (uint32_t)kt * (TBK * 4u);
+    R.w0 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[0] + kw));
+    if (WJ > 1) R.w1 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 1 ? 1 : 0] + kw));
+    if (WJ > 2) R.w2 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 2 ? 2 : 0] + kw));
+    if (WJ > 3) R.w3 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 3 ? 3 : 0] + kw));
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      bf16x4_t h, l;
-      split4(ra[j], &h, &l);
-      *reinterpret_cast<bf16x4_t*>(Ahi + lds_off(ar0 + AROWS * j, ac4 * 4)) = h;
-      *reinterpret_cast<bf16x4_t*>(Alo + lds_off(ar0 + AROWS * j, ac4 * 4)) = l;
+    for (int j = 0; j < AJ; ++j) R.a[j] = *reinterpret_cast<const f32x4*>(Abase + (a_off[j] + ka));
+  };
+  // stage side: the element written to LDS lags the load side by two elements, so it keeps its own tile description
+  uint32_t st_off[AJ];
+  int st_k = 0, st_bn = 0, st_m0 = 0;
+  auto stage = [&](const Regs& R, int s) __attribute__((always_inline)) {   // registers -> LDS stage s; column tile bn refreshes p for k-tile = bn (mod tiles_n)
+#ifdef EVT_PROF
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH == 2 ? AJ + WJ : 0));
+    EVT_TICK(6);   // wait for the loads
+#endif
+    if (st_k == nk) {   // first k-tile of the next tile: the load side entered it two elements ago (and no later tile yet)
+      st_k = 0;
+      st_bn = bn_s;
+      st_m0 = m0_s;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) st_off[j] = a_off[j];
+    }
+    __bf16* Ahi = lds + s * STAGE;
+    __bf16* Alo = Ahi + TBM * TBK + APAD;
+    __bf16* Bhi = Alo + TBM * TBK;
+    __bf16* Blo = Bhi + TBN * TBK + WPAD;
+    if (APL) {   // the 16 bytes are chunk ac4 of the row's 128-byte line: chunks 0-3 hi, 4-7 lo
+      __bf16* Apl = (ac4 & 4) ? Alo : Ahi;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(Apl + lds_off(ar0 + AROWS * j, (ac4 & 3) * 8)) = R.a[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        bf16x4_t h, l;
+        split4(make_float4(R.a[j].x, R.a[j].y, R.a[j].z, R.a[j].w), &h, &l);
+        *reinterpret_cast<bf16x4_t*>(Ahi + lds_off(ar0 + AROWS * j, ac4 * 4)) = h;
+        *reinterpret_cast<bf16x4_t*>(Alo + lds_off(ar0 + AROWS * j, ac4 * 4)) = l;
+      }
     }
     __bf16* Bpl = wpl ? Blo : Bhi;
-    *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0, wc8)) = rw0;
-    if (WJ > 1) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + WROWS, wc8)) = rw1;
-    if (WJ > 2) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 2 * WROWS, wc8)) = rw2;
-    if (WJ > 3) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 3 * WROWS, wc8)) = rw3;
-    if (do_upd && (kt % tiles_n) == bn_s) {
+    *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0, wc8)) = R.w0;
+    if (WJ > 1) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + WROWS, wc8)) = R.w1;
+    if (WJ > 2) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 2 * WROWS, wc8)) = R.w2;
+    if (WJ > 3) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 3 * WROWS, wc8)) = R.w3;
+    if (!APL && do_upd && (st_k % tiles_n) == st_bn) {
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
-        if (m0_s + ar0 + AROWS * j < M) *reinterpret_cast<float4*>(Pbase + (a_off[j] + (uint32_t)kt * (TBK * 4u))) = ra[j];
+        if (st_m0 + ar0 + AROWS * j < M) *reinterpret_cast<f32x4*>(Pbase + (st_off[j] + (uint32_t)st_k * (TBK * 4u))) = R.a[j];
     }
+    ++st_k;
   };
 
   // ---- multiply side ------------------------------------------------------------------------------------------------
   f32x16 acc[MI][NJ];
-  auto clear = [&]() {
+  auto clear = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -175,46 +234,56 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   };
   clear();
   const int lr = lane & 31, lh = lane >> 5;
-  auto multiply = [&](int s) {
+  auto multiply = [&](int s) __attribute__((always_inline)) {
     const __bf16* Ahi = lds + s * STAGE;
-    const __bf16* Alo = Ahi + TBM * TBK;
-    const __bf16* Bhi = Ahi + 2 * TBM * TBK;
-    const __bf16* Blo = Bhi + TBN * TBK;
+    const __bf16* Alo = Ahi + TBM * TBK + APAD;
+    const __bf16* Bhi = Alo + TBM * TBK;
+    const __bf16* Blo = Bhi + TBN * TBK + WPAD;
     __builtin_amdgcn_s_setprio(1);
+    constexpr int HB = PP ? 2 : 1;   // k halves whose fragments are requested together
 #pragma unroll
-    for (int ks = 0; ks < TBK; ks += 16) {
-      bf16x8_t ah[MI], al[MI], bh[NJ], bl[NJ];
+    for (int ks0 = 0; ks0 < TBK; ks0 += 16 * HB) {
+      // (without ping-pong, requesting both halves up front -- 20 reads per wave, 40 more registers -- measured 4 % slower)
+      bf16x8_t ah[HB][MI], al[HB][MI], bh[HB][NJ], bl[HB][NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int ao = lds_off(wm * (MI * 32) + i * 32 + lr, ks + 8 * lh);
-        ah[i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
-        al[i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
-      }
+      for (int h = 0; h < HB; ++h) {
+        const int ks = ks0 + 16 * h;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int bo = lds_off(wn * (NJ * 32) + j * 32 + lr, ks + 8 * lh);
-        bh[j] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
-        bl[j] = *reinterpret_cast<const bf16x8_t*>(Blo + bo);
-      }
-#if EVT_ABLATE == 5   // timing experiment: no MFMA, the fragments are only pinned
-#pragma unroll
-      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
-#else
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+          const int ao = lds_off(wm * (MI * 32) + i * 32 + lr, ks + 8 * lh);
+          ah[h][i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
+          al[h][i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          const int bo = lds_off(wn * (NJ * 32) + j * 32 + lr, ks + 8 * lh);
+          bh[h][j] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
+          bl[h][j] = *reinterpret_cast<const bf16x8_t*>(Blo + bo);
         }
+      }
+      if (PP) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < HB; ++h) {
+#if EVT_ABLATE == 5   // timing experiment: no MFMA, the fragments are only pinned
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(ah[h][i]), "v"(al[h][i]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bh[h][j]), "v"(bl[h][j]));
+#else
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[h][i], bh[h][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[h][i], bl[h][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[h][i], bh[h][j], acc[i][j], 0, 0, 0);
+          }
 #endif
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto epilogue = [&](int seq) {   // bias, activation, scatter of tile `seq` from the accumulators
+  auto epilogue = [&](int seq) __attribute__((always_inline)) {   // bias, activation, scatter of tile `seq` from the accumulators
     const int tile = tile_of(seq), bm = tile / tiles_n, bn = tile - bm * tiles_n;
     const uint32_t* tab = orow_tab + (seq & 1) * TBM + wm * (MI * 32) + 4 * lh;
     const int col0 = bn * TBN + wn * (NJ * 32) + lr;   // this lane's column in accumulator j: col0 + 32 j
@@ -222,7 +291,23 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bv[j] = bias_tab[(seq & 1) * TBN + wn * (NJ * 32) + lr + 32 * j];
     char* const obase = reinterpret_cast<char*>(g.out);
-    const uint32_t cb = (uint32_t)col0 * 4u;
+    // fp32 output: this lane's column.  hl32 output (OPL): the 32 lanes of an accumulator row hold the 32 k of one 128-byte
+    // line; neighbouring lanes swap (DPP) so that even lanes store two hi values and odd lanes two lo values as one dword.
+    const uint32_t cb = OPL ? (uint32_t)(bn * TBN + wn * (NJ * 32)) * 4u + (uint32_t)((lr & 1) * 64 + (lr >> 1) * 4) : (uint32_t)col0 * 4u;
+    auto finish = [&](float v) __attribute__((always_inline)) {   // activation; OPL: the dword this lane stores
+      if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+      if (!OPL) return v;
+      asm volatile("" : "+v"(v));   // v is the ROUNDED fp32 value: no contraction of its last multiply into the residual below
+      union { bf16x2_t b; uint32_t u; } h, l;
+      h.b = __builtin_convertvector((f32x2_t){v, v}, bf16x2_t);
+      const float r = v - __uint_as_float(h.u << 16);
+      l.b = __builtin_convertvector((f32x2_t){r, r}, bf16x2_t);
+      const uint32_t mine = (h.u & 0xffffu) | (l.u << 16);   // hi | lo << 16
+      const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      const uint32_t word = (lr & 1) ? ((other >> 16) | (mine & 0xffff0000u))      // lo(k - 1), lo(k)
+                                     : ((mine & 0xffffu) | (other << 16));         // hi(k), hi(k + 1)
+      return __uint_as_float(word);
+    };
     // Interior tile (every row and column exists -- all tiles when M % 256 == 0 and Nout % TBN == 0): straight-line
     // stores, the 16 row offsets of an accumulator row block read as four 16-byte LDS loads.  (The predicated form costs
     // an LDS round trip and five branches per row; the epilogue of one group has to fit in the shadow of the other
@@ -240,8 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
           const uint32_t off = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + cb;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            float v = acc[i][j][r] + bv[j];
-            if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
+            const float v = finish(acc[i][j][r] + bv[j]);
 #if EVT_ABLATE == 6   // timing experiment: no output stores (the arithmetic stays)
             if (v == 12345.678f)
 #endif
@@ -256,47 +340,48 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t off = tab[i * 32 + (r & 3) + 8 * (r >> 2)];
-        if (off == ~0u) continue;
+        const bool rowok = off != ~0u;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (col0 + 32 * j < g.Nout) {
-            float v = acc[i][j][r] + bv[j];
-            if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-            *reinterpret_cast<float*>(obase + (off + cb + 128u * j)) = v;
-          }
+          // (hl32 output needs whole 32-column groups: the launcher guarantees Nout % 32 == 0, and the swap runs in all lanes)
+          const bool colok = OPL ? (bn * TBN + wn * (NJ * 32) + 32 * j < g.Nout) : (col0 + 32 * j < g.Nout);
+          const float v = finish(acc[i][j][r] + bv[j]);
+          if (colok && rowok) *reinterpret_cast<float*>(obase + (off + cb + 128u * j)) = v;
         }
       }
     }
   };
   // Raw barrier: __syncthreads() would also drain the global loads and stores that are meant to stay in flight across it.
-  auto barrier = [&]() {
+  auto barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
 
-  // The k-tiles of all my tiles form ONE stream x = 0 .. total - 1 (tile x / nk, k-tile x % nk); LDS stage x & 1.
-  // Iteration i stages x = i + 1, fetches x = i + 2, and multiplies x = i (group 0) or x = i + 1 (group 1, which therefore
-  // runs "multiply, then stage" between two barriers).  Every wave passes one barrier per iteration: barrier b_i separates all
-  // reads of stream element i from the writes of element i + 2 into the same stage, and all writes of i + 1 from its reads.
-  // The stream does not stop at a tile boundary: while one group of a SIMD stores a finished tile (epilogue, in front of
-  // its first multiply of the next tile), the other group is still multiplying, and the loads of the next tile are already
-  // in flight -- no prologue / drain bubble per tile, stores overlap the matrix pipe.
-  // (ONE stage site and ONE multiply site in the code: with a copy per group hipcc stops accumulating in place -- twice the
-  // accumulator registers.)
-  // (ONE fetch site as well: the loop starts two steps early, so that no loaded register is merged with a copy from a prologue
-  // fetch -- hipcc resolved that merge by moving freshly loaded registers at the loop's back edge, i.e. by waiting for the loads.)
+  // The k-tiles of all my tiles form ONE stream x = 0 .. total - 1 (tile x / nk, k-tile x % nk); LDS stage and register set
+  // x & 1.  Iteration i stages x = i + 1, fetches x = i + 3 into the registers just freed, and multiplies x = i (group 0) or
+  // x = i + 1 (group 1, which therefore runs "multiply, then stage" between two barriers).  Every wave passes one barrier per
+  // iteration: barrier b_i separates all reads of stream element i from the writes of element i + 2 into the same stage, and
+  // all writes of i + 1 from its reads.  The stream does not stop at a tile boundary: a finished tile is stored (epilogue) in
+  // front of the wave's first multiply of the next tile, whose loads are already in flight -- no prologue / drain bubble per
+  // tile.
+  // Code-generation notes: ONE fetch / stage / multiply site per register set, and the fetch unconditional (the last
+  // iterations re-read the last k-tile) -- with a prologue fetch, a conditional fetch or a multiply per wave group hipcc
+  // merged register copies at the joins: twice the accumulators, the prefetched weights parked in scratch, or freshly loaded
+  // registers moved at the back edge, each of which waits for the loads right after issuing them.
   issue_indices(0);
   enter_tile(0);
+  st_bn = bn_s;
+  st_m0 = m0_s;
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) st_off[j] = a_off[j];
   int sk = 0, sseq = 0;    // load side: k-tile / tile sequence number of the stream element fetched last
-  int mk = stage_first ? -2 : -1, mseq = 0;   // multiply side: k-tile / tile of the element this wave multiplies in iteration i
-  for (int i = -2; i < total; ++i) {
-#if EVT_ABLATE == 2   // timing experiment: staged once
-    if (i == -1) stage(sk, 0), stage(sk, 1);
-#else
-    if (i >= -1 && i + 1 < total) stage(sk, (i + 1) & 1);
-#endif
-    if (i >= -1 && i + 2 < total) {
+  int mk = stage_first ? -(DEPTH + 1) : -DEPTH, mseq = 0;   // multiply side: k-tile / tile of the element this wave multiplies in iteration i
+  auto step = [&](Regs& R, int s, int i) __attribute__((always_inline)) {   // s = (i + 1) & 1, a compile-time constant at both call sites
+    EVT_TICK(7);
+    if (i >= -1 && i + 1 < total) stage(R, s);
+    EVT_TICK(0);   // staging (incl. the wait for the loads)
+    if (i >= -DEPTH && i + 1 + DEPTH < total) {
       if (sk + 1 == nk) {
         enter_tile(++sseq);
         sk = 0;
@@ -305,23 +390,40 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
         if (sk == nk - 1 && sseq + 1 < ntile) issue_indices(sseq + 1);
       }
     }
-#if EVT_ABLATE == 1 || EVT_ABLATE == 2   // timing experiment: fetched once
-    if (i == -2)
-#endif
-    fetch(sk);   // unconditional (the last two iterations re-read the last k-tile): every iteration DEFINES the staging registers
-
-    if (i >= -1 && (!stage_first || i < 0)) barrier();
+    fetch(R, sk);
+    EVT_TICK(1);   // tile bookkeeping + issuing the loads
+    if (i >= -1 && (PP || !stage_first || i < 0)) barrier();
+    EVT_TICK(2);   // barrier in front of the multiply (group 1)
     if (mk >= 0 && mseq < ntile) {
       if (mk == 0 && mseq > 0) {
         epilogue(mseq - 1);
         clear();
+        EVT_TICK(3);   // epilogue
       }
       multiply((mseq * nk + mk) & 1);
     }
+    EVT_TICK(4);   // multiply
     if (++mk == nk) { mk = 0; ++mseq; }
-    if (stage_first && i >= 0) barrier();
+    if (i >= 0 && (PP || stage_first)) barrier();
+    EVT_TICK(5);   // barrier behind the multiply (group 0)
+  };
+  if (PP && !stage_first) barrier();   // group 1 runs one barrier interval behind group 0
+  if (DEPTH == 2) {
+    for (int i = -3; i < total; i += 2) {
+      step(R0, 0, i);       // stream element i + 1 is even
+      step(R1, 1, i + 1);
+    }
+  } else {
+    for (int i = -2; i < total; ++i) step(R0, (i + 1) & 1, i);
   }
+  if (PP && stage_first) barrier();
   epilogue(ntile - 1);
+#ifdef EVT_PROF
+  EVT_TICK(3);
+  if (prof_on && lane == 0) {
+    for (int q = 0; q < 8; ++q) evt_prof_buf[wave == 0 ? 0 : 1][q] = prof_acc[q];
+  }
+#endif
 }
 
 int cu_count() {
@@ -334,58 +436,73 @@ int cu_count() {
   return cus;
 }
 
-template <int TBM, int TBN, int WM, int WN>
-void launch_big_cfg(const LinArgs& a, hipStream_t s) {
-  const int M = a.B * a.kcap;
-  const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
-  constexpr size_t lds_bytes = (size_t)2 * (2 * TBM * 32 + 2 * TBN * 32) * 2 + (size_t)2 * TBM * 4 + (size_t)2 * TBN * 4;
+template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
+void launch_big_one(const LinArgs& a, hipStream_t s, dim3 grid, int tiles_n, int tiles_total) {
+  constexpr size_t lds_bytes = (size_t)2 * (2 * TBM * 32 + 2 * TBN * 32 + 32 + ((FMT & 1) ? 32 : 0)) * 2 + (size_t)2 * TBM * 4 + (size_t)2 * TBN * 4;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_big_kernel<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_big_kernel<EVT_ACT_NONE, TBM, TBN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_big_kernel<ACT, TBM, TBN, WM, WN, DEPTH, FMT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_set = true;
   }
-  const dim3 grid(std::min(tiles_m * tiles_n, cu_count())), block(WM * WN * 64);   // persistent: one workgroup per CU
-  if (a.act == EVT_ACT_GELU_ERF)
-    hipLaunchKernelGGL((gated_linear_split_big_kernel<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN>), grid, block, lds_bytes, s, a, tiles_n,
-                       tiles_m * tiles_n);
-  else
-    hipLaunchKernelGGL((gated_linear_split_big_kernel<EVT_ACT_NONE, TBM, TBN, WM, WN>), grid, block, lds_bytes, s, a, tiles_n,
-                       tiles_m * tiles_n);
+  hipLaunchKernelGGL((gated_linear_split_big_kernel<ACT, TBM, TBN, WM, WN, DEPTH, FMT>), grid, dim3(WM * WN * 64), lds_bytes, s, a, tiles_n,
+                     tiles_total);
+}
+
+template <int TBM, int TBN, int WM, int WN, int DEPTH>
+void launch_big_cfg(const LinArgs& a, hipStream_t s) {
+  const int M = a.B * a.kcap;
+  const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
+  const dim3 grid(std::min(tiles_m * tiles_n, cu_count()));   // persistent: one workgroup per CU
+  const int tt = tiles_m * tiles_n;
+  // formats in use: fp32 -> fp32 (any activation), fp32 -> hl32 with GELU (first half of the MLP), hl32 -> fp32 (second half)
+  if (a.a_planes) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1>(a, s, grid, tiles_n, tt);   // (one register set: room for both fragment sets)
+  else if (a.out_planes) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 2>(a, s, grid, tiles_n, tt);
+  else if (a.act == EVT_ACT_GELU_ERF) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 0>(a, s, grid, tiles_n, tt);
+  else launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, DEPTH, 0>(a, s, grid, tiles_n, tt);
 }
 
 }  // namespace
 
-// Picks a 256-row tile when the launch has enough of them to fill the chip; returns false when the 128x128 kernel
-// (or its split-K form) should run instead.  EVT_GEMM_BIG: 0 never, 1 (default) automatic, 2 always 256x256, 3 always 256x128,
-// 4 always 256x192.
-bool evt_launch_split_big(const LinArgs& a, hipStream_t s) {
+// Picks a 256-row tile when the launch has enough of them to fill the chip; 0 when the 128x128 kernel (or its split-K form)
+// should run instead.  EVT_GEMM_BIG: 0 never, 1 (default) automatic, 2 always 256x256, 3 always 256x128, 4 always 256x192.
+int evt_big_choice(const LinArgs& a) {
   static const int mode = getenv("EVT_GEMM_BIG") ? atoi(getenv("EVT_GEMM_BIG")) : 1;
   // whole 32-k tiles, at least two of them; top-k gating only (the threshold policy's masked rows stay with the 128x128 kernel,
   // which skips dead tiles)
-  if (mode == 0 || a.Wsplit == nullptr || (a.K & 31) != 0 || a.K < 64 || a.count != nullptr) return false;
+  if (mode == 0 || a.Wsplit == nullptr || (a.K & 31) != 0 || a.K < 64 || a.count != nullptr) return 0;
   // 32-bit byte offsets inside the kernel: activations (and the gate reference, same shape), weight planes and output below 4 GB
   if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) || (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
       (int64_t)a.B * a.o_rows * a.ldo * 4 >= ((int64_t)1 << 32))
-    return false;
-  const int M = a.B * a.kcap;
-  if (mode == 2) { launch_big_cfg<256, 256, 4, 2>(a, s); return true; }
-  if (mode == 3) { launch_big_cfg<256, 128, 4, 2>(a, s); return true; }
-  if (mode == 4) { launch_big_cfg<256, 192, 4, 2>(a, s); return true; }
+    return 0;
+  if (mode >= 2 && mode <= 4) return mode;
   // One persistent workgroup per CU: a launch of T tiles runs in ceil(T / CUs) rounds.  Take the widest tile whose columns
   // divide Nout (no wasted edge columns) and whose last round is at least 85 % full; measured at M = 32768 (B = 256 clips):
-  // 256x256 for Nout = 2304 / 3072 (351 / 483 us vs 380 / 531 for the 128x128 kernel), 256x192 for Nout = 768 (129 / 420 vs
+  // 256x256 for Nout = 2304 / 3072 (343 / 474 us vs 380 / 531 for the 128x128 kernel), 256x192 for Nout = 768 (126 / 418 vs
   // 134 / 443 us; 256x256 would leave a quarter of the CUs idle in its second round).
-  const int cus = cu_count();
+  const int cus = cu_count(), M = a.B * a.kcap;
   const int tiles_m = (M + 255) / 256;
   auto fills = [&](int tbn) {
     if (a.Nout % tbn != 0) return false;
     const int tiles = tiles_m * (a.Nout / tbn), rounds = (tiles + cus - 1) / cus;
     return tiles >= cus && tiles * 100 >= rounds * cus * 85;
   };
-  if (fills(256)) { launch_big_cfg<256, 256, 4, 2>(a, s); return true; }
-  if (fills(192)) { launch_big_cfg<256, 192, 4, 2>(a, s); return true; }
-  return false;
+  if (fills(256)) return 2;
+  if (fills(192)) return 4;
+  return 0;
 }
+
+bool evt_launch_split_big(const LinArgs& a, hipStream_t s) {
+  switch (evt_big_choice(a)) {
+    case 2: launch_big_cfg<256, 256, 4, 2, 1>(a, s); return true;
+    case 3: launch_big_cfg<256, 128, 4, 2, 1>(a, s); return true;
+    case 4: launch_big_cfg<256, 192, 4, 2, 2>(a, s); return true;
+    default: return false;
+  }
+}
+
+#ifdef EVT_PROF
+extern "C" __attribute__((visibility("default"))) int evt_debug_prof(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_buf), sizeof(unsigned long long) * 16);
+}
+#endif
