@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef EVT_BIG_PRIO   // 1: multiply segments at priority 1 (default); 0: no priority changes; 2: everything BUT the multiply at priority 1
+#define EVT_BIG_PRIO 1
+#endif
 #ifndef EVT_PINGPONG
 #define EVT_PINGPONG 1
 #endif
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     const __bf16* Alo = Ahi + TBM * TBK + APAD;
     const __bf16* Bhi = Alo + TBM * TBK;
     const __bf16* Blo = Bhi + TBN * TBK + WPAD;
-    __builtin_amdgcn_s_setprio(1);
+    if (EVT_BIG_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if (EVT_BIG_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     constexpr int HB = PP ? 2 : 1;   // k halves whose fragments are requested together
 #pragma unroll
     for (int ks0 = 0; ks0 < TBK; ks0 += 16 * HB) {
@@ -281,7 +285,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
 #endif
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (EVT_BIG_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (EVT_BIG_PRIO == 2) __builtin_amdgcn_s_setprio(1);
   };
   auto epilogue = [&](int seq) __attribute__((always_inline)) {   // bias, activation, scatter of tile `seq` from the accumulators
     const int tile = tile_of(seq), bm = tile / tiles_n, bn = tile - bm * tiles_n;
@@ -319,17 +324,44 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
         uint4 o4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) o4[q] = *reinterpret_cast<const uint4*>(tab + i * 32 + 8 * q);   // rows 8 q + 4 lh + 0..3
+        if (OPL) {   // two rows at a time: packed conversions, byte permutes instead of shifts and masks
+          const uint32_t sel_lane = (lr & 1) ? 0x03020706u : 0x05040100u;   // odd: lo(k-1), lo(k); even: hi(k), hi(k+1)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint4 o = o4[r >> 2];
-          const uint32_t off = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + cb;
+          for (int r = 0; r < 16; r += 2) {
+            const uint4 o = o4[r >> 2];
+            const uint32_t off0 = ((r & 3) == 0 ? o.x : o.z) + cb, off1 = ((r & 3) == 0 ? o.y : o.w) + cb;
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const float v = finish(acc[i][j][r] + bv[j]);
+            for (int j = 0; j < NJ; ++j) {
+              float v0 = acc[i][j][r] + bv[j], v1 = acc[i][j][r + 1] + bv[j];
+              if (ACT == EVT_ACT_GELU_ERF) {
+                v0 = gelu_erf(v0);
+                v1 = gelu_erf(v1);
+              }
+              asm volatile("" : "+v"(v0), "+v"(v1));   // the ROUNDED fp32 values: no contraction into the residuals below
+              union { bf16x2_t b; uint32_t u; } H, L;
+              H.b = __builtin_convertvector((f32x2_t){v0, v1}, bf16x2_t);
+              const float r0 = v0 - __uint_as_float(H.u << 16), r1 = v1 - __uint_as_float(H.u & 0xffff0000u);
+              L.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
+              const uint32_t m0 = __builtin_amdgcn_perm(L.u, H.u, 0x05040100u), m1 = __builtin_amdgcn_perm(L.u, H.u, 0x07060302u);   // hi | lo << 16
+              const uint32_t x0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m0, 0xB1, 0xf, 0xf, false);   // the neighbouring lane's
+              const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m1, 0xB1, 0xf, 0xf, false);
+              *reinterpret_cast<uint32_t*>(obase + (off0 + 128u * j)) = __builtin_amdgcn_perm(x0, m0, sel_lane);
+              *reinterpret_cast<uint32_t*>(obase + (off1 + 128u * j)) = __builtin_amdgcn_perm(x1, m1, sel_lane);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint4 o = o4[r >> 2];
+            const uint32_t off = ((r & 3) == 0 ? o.x : (r & 3) == 1 ? o.y : (r & 3) == 2 ? o.z : o.w) + cb;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const float v = finish(acc[i][j][r] + bv[j]);
 #if EVT_ABLATE == 6   // timing experiment: no output stores (the arithmetic stays)
-            if (v == 12345.678f)
+              if (v == 12345.678f)
 #endif
-            *reinterpret_cast<float*>(obase + (off + 128u * j)) = v;
+              *reinterpret_cast<float*>(obase + (off + 128u * j)) = v;
+            }
           }
         }
       }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate the rocprofv3 --pmc passes of scripts/collect_profiles.sh per kernel: HBM traffic (FETCH_SIZE / WRITE_SIZE with
 the gfx950 correction of MI355X_MICROARCH.md) and matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES)."""
-import collections, csv, glob, hashlib, json, os, sys
+import collections, csv, glob, hashlib, json, os, re, sys
 
 out, B = sys.argv[1], int(sys.argv[2])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,17 @@ NAMES = ["gated_linear_split_kernel<0", "gated_linear_split_kernel<1", "gated_li
          "av_kernel", "softmax_gate_kernel", "split_weights_kernel", "attn_dense_kernel", "splitk_finish_kernel"]
 
 
+BIG = re.compile(r"gated_linear_split_big_kernel<(\d), 256, (\d+), \d, \d, \d, (\d)>")
+FMT = {"0": "fp32", "1": "presplit_A", "2": "hl32_out"}
+
+
 def key(n):
+    m = BIG.search(n)   # the persistent 256-row kernel: one row per (activation, tile width, operand format)
+    if m:
+        k = f"gated_linear_big_kernel<{m.group(1)}|256x{m.group(2)}|{FMT.get(m.group(3), m.group(3))}"
+        if k not in NAMES:
+            NAMES.insert(0, k)
+        return k
     for k in NAMES:
         if k in n:
             return k
@@ -35,11 +45,11 @@ w = agg("WRITE_SIZE")["WRITE_SIZE"]
 sq = agg("SQ_VALU_MFMA_BUSY_CYCLES")
 gr = agg("GRBM_GUI_ACTIVE")["GRBM_GUI_ACTIVE"]
 rows = []
-for n in NAMES:
+for n in list(NAMES):
     if n in f and n in w:
         c, v, t = f[n]
         wc, wv, _ = w[n]
-        row = dict(kernel=n.replace("<0", "<ACT_NONE>").replace("<1", "<ACT_GELU>"), launches=c,
+        row = dict(kernel=n.replace("<0", "<ACT_NONE").replace("<1", "<ACT_GELU").replace("|", ", ") + (">" if "<" in n else ""), launches=c,
                    fetch_size_kb_raw=round(v / c, 1), write_size_kb=round(wv / wc, 1),
                    hbm_bytes_per_launch=int((2 * v / c + wv / wc) * 1024), avg_us_profiled=round(t / c / 1e3, 1))
         mb = sq.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get(n)
