@@ -81,6 +81,13 @@ template <> struct Tile<float> {
 // applied to BOTH the normaliser and the gathered numerators, so rows still sum to one.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+#ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/attn_prof.py)
+__device__ unsigned long long evt_prof_attn_buf[8];
+#define ATT_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
+#else
+#define ATT_TICK(slot) do { } while (0)
+#endif
+
 struct FusedArgs {
   const float* product; const float* qkv; const float* rel_y; const float* rel_x;
   void* a_state; const int32_t* idx; const int32_t* count;
@@ -130,6 +137,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
   }
   const int b = bh / a.H, h = bh - b * a.H;
   const int i0 = tile_x * FR;
+#ifdef EVT_PROF
+  const bool prof_on = blockIdx.x == 2 && blockIdx.y == 1000 && wave == 0;
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
   const int cnt = a.count ? a.count[b] : a.kcap;
   const bool rel = a.rel_y != nullptr;
   const int nrel = a.gh + a.gw;
@@ -157,6 +168,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
   const T* Vg_o = reinterpret_cast<const T*>(a.v_old_t) + (int64_t)bh * a.dh * a.kcap;
   const bool vvec = a.kcap > 0 && (a.kcap % VEC) == 0;
   uint4 vpd[VIT], vpo[VIT];
+  uint4 vpd1[VIT], vpo1[VIT];   // PF path: the second chunk's pieces, requested before the first chunk is processed
+  auto load_v_into = [&](int k0, uint4* pd, uint4* po) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
+      const bool in = kk < a.kcap;
+      const int64_t o = (int64_t)d * a.kcap + (in ? kk : 0);
+      const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+      pd[it] = in ? xd : make_uint4(0, 0, 0, 0);
+      po[it] = in ? xo : make_uint4(0, 0, 0, 0);
+    }
+  };
   auto load_v = [&](int k0) __attribute__((always_inline)) {
     // chunk k0 of dv~^T / v_old^T (k contiguous) -> registers.  Columns in [count, kcap) hold zeros (evt_v_gate
     // writes them) and meet a~ = da~ = 0 anyway; pieces past kcap are zeroed here.  Branch-free (clamped address +
@@ -243,8 +266,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
     load_pv();
   };
   if (QK && NREG > 0) {
-    prefetch();
-    asm volatile("" ::: "memory");
     // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  Wave w owns keys
     // 16w .. 16w+15 of every 64-key chunk.  Both operands go STRAIGHT from the token buffer into MFMA fragments: lane
     // (l15, kg) reads, of q row l15 / key l15, the channels its fragment holds (16 lanes x 4 kg cover whole 128-byte
@@ -285,8 +306,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
     };
-    float4 kf[4];
-    load_kf(0, kf);
+    // Two fragment register sets, used alternately (a copy `kf = kn` at the end of an iteration made hipcc wait for the
+    // prefetch it had just issued: four serialised L2 round trips per workgroup).  The score-independent requests of the
+    // chunk loop and the epilogue (`prefetch`: 16 two-byte gathers of the old a~ values among them) go out BEHIND the q rows
+    // and the first two key chunks: vmcnt retires in order, so in front of them every q.k^T wait was also a wait for the
+    // slowest gather.  In-kernel phase timing (scripts/attn_prof.py): 18.8k of a workgroup's 41k ticks were spent here.
+    float4 kA[4], kB[4];
+    load_kf(0, kA);
+    if (QKC < a.N) load_kf(QKC, kB);
+    asm volatile("" ::: "memory");
+    prefetch();
+    asm volatile("" ::: "memory");
     bf16x8_t qh[2][2], ql[2][2];
 #pragma unroll
     for (int hr = 0; hr < 2; ++hr) {
@@ -297,10 +327,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
         for (int m = 0; m < 2; ++m) split8(qf[hr][2 * m], qf[hr][2 * m + 1], &qh[hr][m], &ql[hr][m]);
       }
     }
-    for (int c0 = 0; c0 < a.N; c0 += QKC) {
-      float4 kn[4];
-      const bool more = c0 + QKC < a.N;
-      if (more) load_kf(c0 + QKC, kn);
+    auto qk_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
       const int n0 = c0 + wave * 16;
       if (n0 < a.N) {  // wave-uniform
         f32x4_acc sacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -335,12 +362,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
             for (int r = 0; r < 4; ++r) et[(hr * 16 + 4 * kg + r) * EP + j] = sacc[hr][r];
         }
       }
-      if (more) {
-#pragma unroll
-        for (int p_ = 0; p_ < 4; ++p_) kf[p_] = kn[p_];
-      }
-    }
+    };
+    // N <= 256 (entry-point check): at most four chunks, written out -- in a loop the same wait instruction would serve the
+    // first chunk (many younger requests in flight) and the later ones (none), and hipcc has to assume none.
+    static_assert(QKC == 64, "four chunks of 64 keys cover N <= 256");
+    qk_chunk(0, kA);
+    if (2 * QKC < a.N) load_kf(2 * QKC, kA);
+    if (QKC < a.N) qk_chunk(QKC, kB);
+    if (3 * QKC < a.N) load_kf(3 * QKC, kB);
+    if (2 * QKC < a.N) qk_chunk(2 * QKC, kA);
+    if (3 * QKC < a.N) qk_chunk(3 * QKC, kB);
     __syncthreads();
+    ATT_TICK(0);   // prefetch issue + q.k^T
   }
   if (NREG > 0) {
     float xv[8][NREG > 0 ? NREG : 1];
@@ -471,6 +504,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
     }
   }
 
+  ATT_TICK(1);   // softmax statistics
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
@@ -488,7 +522,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
   for (int rr = 0; rr < 8; ++rr) rinv[rr] = 1.0f / rsum[rr];
   // One chunk of 64 selected columns.  jcol: this lane's column (-1 past count); oldp: the 8 old a~ values of the
   // lane's column if they were requested ahead, else nullptr (loaded here, all 8 in flight, clamped addresses).
-  auto do_chunk = [&](int k0, int jcol, const float* oldp) __attribute__((always_inline)) {
+  auto do_chunk = [&](int k0, int jcol, const float* oldp, const bool set1, const bool ahead) __attribute__((always_inline)) {
+    // set1: this chunk's V pieces are in vpd1 / vpo1 (requested two chunks ahead); ahead: the NEXT chunk's pieces have
+    // already been requested (into the other set), nothing to request here
     // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
     const int js = jcol >= 0 ? jcol : 0;
     float oldv[8];
@@ -497,13 +533,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       const int i = i0 + wave * 8 + rr;
       oldv[rr] = oldp ? oldp[rr] : Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + js);
     }
+    // the 8 exp-tile reads of the lane's column go out together and are waited for once (hipcc otherwise sinks each read
+    // into the predicated store block of its row: eight serialised LDS round trips per chunk)
+    float ev[8];
+    if (NREG > 0) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) ev[rr] = et[(wave * 8 + rr) * EP + js];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ev[rr]));
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
       const bool ok = i < a.N && jcol >= 0;
       float e;
       if (NREG > 0) {
-        e = et[r * EP + js];
+        e = ev[rr];
       } else {
         float x = prod[(int64_t)(i < a.N ? i : 0) * a.Nk + js];
         if (rel) { const float* rv = relv + r * nrel; const int ky = fast_div(js, inv_gw); x = (x + rv[ky]) + rv[a.gh + js - ky * a.gw]; }
@@ -517,15 +562,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       Store<T>::store(An + r * P + lane, an);
       Store<T>::store(Ad + r * P + lane, ad);
     }
+    ATT_TICK(5);   // 2a: old values, exp tile reads, A gate, scattered state stores, LDS stores
     // ---- phase 2b: stage the chunk of dv~^T and v_old^T (k contiguous; requested one chunk ahead) ----
     if (vvec) {
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
         const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC;
-        *reinterpret_cast<uint4*>(Vd + d * P + jj) = vpd[it];
-        *reinterpret_cast<uint4*>(Vo + d * P + jj) = vpo[it];
+        *reinterpret_cast<uint4*>(Vd + d * P + jj) = set1 ? vpd1[it] : vpd[it];
+        *reinterpret_cast<uint4*>(Vo + d * P + jj) = set1 ? vpo1[it] : vpo[it];
       }
-      if (k0 + FKC < cnt) load_v(k0 + FKC);   // flies during the MFMA sweep of this chunk
+      if (!ahead && k0 + FKC < cnt) load_v(k0 + FKC);   // flies during the MFMA sweep of this chunk
     } else {
       for (int e = tid; e < a.dh * FKC; e += 256) {
         const int d = e / FKC, jj = e - d * FKC, kk = k0 + jj;
@@ -538,7 +584,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
         Store<T>::store(Vo + d * P + jj, vo);
       }
     }
+    ATT_TICK(6);   // 2b: V staging, next V request
     __syncthreads();
+    ATT_TICK(2);   // barrier after staging
     // ---- phase 3: matrix cores ------------------------------------------------------------------
     const T* At = (prodsel == 0 ? An : Ad) + lr * P;
     const T* Vt = (prodsel == 0 ? Vd : Vo);
@@ -546,15 +594,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
     for (int t = 0; t < TPW; ++t)
       acc[t] = Tile<T>::sweep(At, Vt + ((half + 2 * t) * 32 + lr) * P, lh, acc[t]);
     __syncthreads();
+    ATT_TICK(3);   // MFMA sweep (+ barrier)
   };
   if (PF > 0) {
-    if (cnt > 0) do_chunk(0, jpf[0], oldpf[0]);
-    if (cnt > FKC) do_chunk(FKC, jpf[PF > 1 ? 1 : 0], oldpf[PF > 1 ? 1 : 0]);
+    // the second chunk's V pieces go out now (the q.k^T fragment registers are free again) instead of during the first
+    // chunk's MFMA sweep: at r = 128 (two chunks) nothing inside the chunk loop waits for HBM / L2 any more
+    const bool two = vvec && cnt > FKC;
+    if (two) load_v_into(FKC, vpd1, vpo1);
+    if (cnt > 0) do_chunk(0, jpf[0], oldpf[0], false, two);
+    if (cnt > FKC) {
+      if (two) do_chunk(FKC, jpf[PF > 1 ? 1 : 0], oldpf[PF > 1 ? 1 : 0], true, false);
+      else do_chunk(FKC, jpf[PF > 1 ? 1 : 0], oldpf[PF > 1 ? 1 : 0], false, false);
+    }
   }
   for (int k0 = PF * FKC; k0 < cnt; k0 += FKC) {
     const int kk = k0 + lane;
     const int j = ix[kk < cnt ? kk : 0];
-    do_chunk(k0, kk < cnt ? j : -1, nullptr);
+    do_chunk(k0, kk < cnt ? j : -1, nullptr, false, false);
   }
 
   // ---- phase 4: state += round(acc1); state += round(acc2); heads merged on write ---------------
@@ -602,6 +658,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       if (ok && (tid & (a.dh / 8 - 1)) == 0) a.norm_parts[((int64_t)b * a.N + i) * a.H + h] = ss;
     }
   }
+#ifdef EVT_PROF
+  ATT_TICK(4);   // epilogue
+  if (prof_on && lane == 0)
+    for (int q = 0; q < 8; ++q) evt_prof_attn_buf[q] = prof_acc[q];
+#endif
 }
 
 template <typename T, int TPW, int NREG, int QK = 0>
@@ -666,3 +727,9 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }
+
+#ifdef EVT_PROF
+extern "C" __attribute__((visibility("default"))) int evt_debug_prof_attn(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_attn_buf), sizeof(unsigned long long) * 8);
+}
+#endif

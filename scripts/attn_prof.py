@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Phase timing inside the fused gated attention kernel (library built with -DEVT_PROF): s_memtime ticks wave 0 of one
+workgroup spends per phase of the ViViT-B launch (B clips, k = 128, bf16 store, in-kernel q.k^T, fused projection norm).
+Usage: EVT_LIB=<prof build> python scripts/attn_prof.py [--clips 256]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "eventful-transformer_amd"))
+import torch  # noqa: E402
+
+from eventful_transformer import _native as n  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--clips", type=int, default=256)
+a = ap.parse_args()
+B, N, D, H, k = a.clips, 197, 768, 12, 128
+dev = torch.device("cuda", 0)
+sdt = torch.bfloat16
+store = n.store_code(sdt)
+g = torch.Generator(device=dev).manual_seed(0)
+qkv = torch.randn(B, N, 3 * D, device=dev, generator=g)
+p = torch.randn(B, N, D, device=dev, generator=g)
+idx = torch.stack([torch.randperm(N, device=dev, generator=g)[:k].sort()[0] for _ in range(B)]).int().contiguous()
+ap_ = torch.rand(B, H, N, N, device=dev, generator=g).to(sdt)
+vp = torch.randn(B, N, D, device=dev, generator=g).to(sdt)
+pv = torch.zeros(B, N, D, device=dev, dtype=sdt)
+out = torch.empty(B, N, D, device=dev)
+vd_t = torch.empty(B, D, k, device=dev, dtype=sdt)
+vo_t = torch.empty(B, D, k, device=dev, dtype=sdt)
+nparts = torch.empty(B, N, H, device=dev)
+n.v_gate(qkv, idx, None, B, N, D, k, vp, vd_t, vo_t, store, True, transposed=True)
+for _ in range(100):
+    n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0, norm_ref=p, norm_parts=nparts)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 8)()
+lib = n.load()
+lib.evt_debug_prof_attn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+assert lib.evt_debug_prof_attn(buf) == 0
+names = ["prefetch issue + q.k^T", "softmax statistics", "barrier after staging", "MFMA sweeps (+ barrier)", "epilogue",
+         "2a: A gate + state scatter", "2b: V staging + next V request"]
+tot = sum(buf[q] for q in range(7))
+print(f"wave 0 of one workgroup: {tot} ticks")
+for q, nm in enumerate(names):
+    print(f"   {nm:30s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")
