@@ -27,6 +27,7 @@
 // column panel update (K4) touches 88 % of the state and costs more than this full recompute, and the state would
 // only be written (K4) to be read once here: K4 and 2 x 477 MB of state traffic per launch at B = 256 go away.
 #include "evt_linear.h"   // split4 (fp32 -> bf16 hi / lo)
+#include <algorithm>
 
 namespace {
 
@@ -82,7 +83,7 @@ template <> struct Tile<float> {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 #ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/attn_prof.py)
-__device__ unsigned long long evt_prof_attn_buf[8];
+__device__ unsigned long long evt_prof_attn_buf[16];
 #define ATT_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
 #else
 #define ATT_TICK(slot) do { } while (0)
@@ -96,6 +97,7 @@ struct FusedArgs {
   float scale;                                // QK mode: q / scale (blocks.py:514)
   int qk_split;                               // QK mode: 1 = bf16 hi/lo split products, 0 = exact fp32 products
   const float* norm_ref; float* norm_parts;   // optional: (B,N,D) reference of the next gate -> (B,N,H) partial ||out - ref||^2
+  const float* rel_terms;                     // optional: (B,H,N,gh+gw) rel-pos dot products from evt_rel_terms
 };
 
 constexpr int QKC = 64;       // QK mode: keys per chunk (16 per wave)
@@ -108,9 +110,10 @@ typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x32_bf16 per product, ~1e-5 relative -- the arithmetic K4 uses by default; 5x less matrix-pipe time).
 // bf16 / fp16 store at head dim 64 (ViViT / ViT-B with matmul_2_cast): three workgroups per CU, i.e. at most 168 registers per
 // lane incl. AGPRs -- at 170 the kernel dropped to two and the gated ViViT launch went from 480 to 610 us.  The fp32-store and
-// head-dim-128 variants need more registers than that (they would spill) and stay unconstrained.
+// head-dim-128 variants, and the streamed any-N variants (two row buffers in flight), need more registers than that (they
+// would spill) and stay unconstrained.
 template <typename T, int TPW, int NREG, int QK = 0>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void softmax_av_gated_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 : 1) void softmax_av_gated_kernel(const FusedArgs a) {
   constexpr int P = Tile<T>::PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* An = reinterpret_cast<T*>(smem_raw);              // [FR][P]
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
   const int b = bh / a.H, h = bh - b * a.H;
   const int i0 = tile_x * FR;
 #ifdef EVT_PROF
-  const bool prof_on = blockIdx.x == 2 && blockIdx.y == 1000 && wave == 0;
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+  const bool prof_on = blockIdx.x == 2 && blockIdx.y == (gridDim.y > 1000 ? 1000u : gridDim.y / 2) && wave == 0;
+  unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
 #endif
   const int cnt = a.count ? a.count[b] : a.kcap;
   const bool rel = a.rel_y != nullptr;
@@ -216,7 +219,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
 
   // ---- phase 1: per-row softmax statistics; wave w owns rows w*8 .. w*8+7 -----------------------
   float rmax[8], rsum[8];
-  if (rel) {
+  if (rel && a.rel_terms != nullptr) {
+    // rel-pos terms computed once per frame by evt_rel_terms: copy the tile's 32 x (gh + gw) block (contiguous rows).
+    // (Computed here, a workgroup reads 32 x (gh + gw) table rows of 256 bytes -- 688 KB at 42 x 42, 38 % of its life.)
+    const float* src = a.rel_terms + ((int64_t)bh * a.N + i0) * nrel;
+    const int rows = min(FR, a.N - i0);
+    for (int e = tid; e < rows * nrel; e += 256) relv[e] = src[e];
+    __syncthreads();
+  } else if (rel) {
     // rel-pos terms of the workgroup's 32 rows (utils.py:159-168): q rows staged once in LDS, then the
     // 32 x (gh + gw) dot products are spread over all 256 threads (8 threads per row), head dim unrolled
     // so the 16-byte table loads of one dot are all in flight together.
@@ -428,10 +438,74 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();  // each wave only ever reads back its own 8 rows
   } else {
+    ATT_TICK(9);   // (streamed path) everything before the row pass: index loads, rel-pos terms
     // any N: ONE pass over the row with an online (running max / rescaled sum) softmax, 8 independent
     // 256-byte wave loads in flight per step so the cold HBM stream is not latency-serialised.
     if (vvec) load_v(0);
     load_pv();
+    if ((a.Nk & 3) == 0) {
+      // Two rows at a time, each in its own register buffer: the loads of the next 2048-column step are requested while
+      // the current one is reduced (in-kernel phase timing, ViTDet 42 x 42: the row-after-row version spent 19k ticks per row,
+      // most of them waiting for the 8 KB it had just asked for).  Every request is unconditional (rows past N and the
+      // step after the last one re-read a valid address), so the waits can count on the younger requests being in flight.
+      const int nsteps = (a.Nk + 2047) / 2048;
+      auto issue = [&](int rr, int js, float4* x4) __attribute__((always_inline)) {
+        const int i = i0 + wave * 8 + rr;
+        const float* prow = prod + (int64_t)(i < a.N ? i : a.N - 1) * a.Nk;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = js * 2048 + (lane + 64 * u) * 4;
+          x4[u] = *reinterpret_cast<const float4*>(prow + (j < a.Nk ? j : 0));
+        }
+      };
+      auto consume = [&](int rr, int js, float4* x4, float& mx, float& sum) __attribute__((always_inline)) {
+        const float* rv = relv + (wave * 8 + rr) * nrel;
+        const int j0 = js * 2048;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + (lane + 64 * u) * 4;
+          if (j >= a.Nk) x4[u] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+          else if (rel) {
+            float* xe = reinterpret_cast<float*>(&x4[u]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int ky = fast_div(j + q, inv_gw); xe[q] = (xe[q] + rv[ky]) + rv[a.gh + j + q - ky * a.gw]; }
+          }
+        }
+        float cm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cm = fmaxf(cm, fmaxf(fmaxf(x4[u].x, x4[u].y), fmaxf(x4[u].z, x4[u].w)));
+        const float nm = fmaxf(mx, cm);
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          part += (fast_exp(x4[u].x - nm) + fast_exp(x4[u].y - nm)) + (fast_exp(x4[u].z - nm) + fast_exp(x4[u].w - nm));
+        sum = (nm == -INFINITY) ? 0.f : sum * fast_exp(mx - nm) + part;
+        mx = nm;
+      };
+      auto finish_row = [&](int rr, float mx, float sum) __attribute__((always_inline)) {
+        const bool live = i0 + wave * 8 + rr < a.N;   // wave-uniform
+        const float wmx = wave_max_dpp(mx);
+        sum = (mx == -INFINITY) ? 0.f : sum * fast_exp(mx - wmx);
+        const float ws = wave_sum_dpp(sum);
+        rmax[rr] = live ? wmx : 0.f;
+        rsum[rr] = live ? ws : 1.f;
+      };
+      float4 xa[8], xb[8];
+      issue(0, 0, xa);
+#pragma unroll
+      for (int rp = 0; rp < 8; rp += 2) {
+        float mxa = -INFINITY, suma = 0.f, mxb = -INFINITY, sumb = 0.f;
+        for (int js = 0; js < nsteps; ++js) {
+          issue(rp + 1, js, xb);
+          consume(rp, js, xa, mxa, suma);
+          const bool more = js + 1 < nsteps;
+          issue(more ? rp : (rp + 2 < 8 ? rp + 2 : rp), more ? js + 1 : 0, xa);   // (the very last one is a dummy re-read)
+          consume(rp + 1, js, xb, mxb, sumb);
+        }
+        finish_row(rp, mxa, suma);
+        finish_row(rp + 1, mxb, sumb);
+      }
+    } else
 #pragma unroll 1
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr, i = i0 + r;
@@ -440,8 +514,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       const float* rv = relv + r * nrel;
       const float* prow = prod + (int64_t)i * a.Nk;
       float mx = -INFINITY, sum = 0.f;
-      if ((a.Nk & 3) == 0) {
-        // 16-byte lane loads: 8 KB of the row in flight per wave (one step covers 2048 columns)
+      if (false) {
         for (int j0 = 0; j0 < a.Nk; j0 += 2048) {
           float4 x4[8];
 #pragma unroll
@@ -541,6 +614,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       for (int rr = 0; rr < 8; ++rr) ev[rr] = et[(wave * 8 + rr) * EP + js];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ev[rr]));
+    } else {   // streamed path: the 8 score gathers likewise (eight serialised HBM round trips per chunk otherwise)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int i = i0 + wave * 8 + rr;
+        ev[rr] = prod[(int64_t)(i < a.N ? i : 0) * a.Nk + js];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ev[rr]));
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -550,7 +631,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
       if (NREG > 0) {
         e = ev[rr];
       } else {
-        float x = prod[(int64_t)(i < a.N ? i : 0) * a.Nk + js];
+        float x = ev[rr];
         if (rel) { const float* rv = relv + r * nrel; const int ky = fast_div(js, inv_gw); x = (x + rv[ky]) + rv[a.gh + js - ky * a.gw]; }
         e = fast_exp(x - rmax[rr]);
       }
@@ -661,7 +742,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1) ? 3 : 1) void sof
 #ifdef EVT_PROF
   ATT_TICK(4);   // epilogue
   if (prof_on && lane == 0)
-    for (int q = 0; q < 8; ++q) evt_prof_attn_buf[q] = prof_acc[q];
+    for (int q = 0; q < 16; ++q) evt_prof_attn_buf[q] = prof_acc[q];
 #endif
 }
 
@@ -722,14 +803,105 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
   }
   FusedArgs a{d->product, d->qkv, d->rel_y, d->rel_x, d->a_state, d->idx, d->count, d->v_delta_t, d->v_old_t,
               d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
-              d->rel_y ? d->qw : 1, d->scale, d->qk_split, d->norm_ref, d->norm_parts};
+              d->rel_y ? d->qw : 1, d->scale, d->qk_split, d->norm_ref, d->norm_parts, d->rel_y ? d->rel_terms : nullptr};
   EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_av_gated: norm_ref / norm_parts come together");
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }
 
+namespace {
+
+// evt_rel_terms: one workgroup per (clip*head, query-grid row y or column x).  blockIdx.x < qh: the qw queries of row y
+// against rel_y[y] (gh x 64); else the qh queries of column x against rel_x[x] (gw x 64).  Queries and table slice are
+// staged in LDS (row pitch 68 floats); every thread accumulates its (query, key) dots in the order of the in-kernel
+// version (two interleaved partial sums over 16-byte pieces).
+__global__ __launch_bounds__(256) void rel_terms_kernel(const float* __restrict__ qkv, const float* __restrict__ rel_y,
+                                                        const float* __restrict__ rel_x, int H, int N, int D, int gh, int gw,
+                                                        int qw, float* __restrict__ terms) {
+  constexpr int DH = 64, LP = DH + 4;
+  extern __shared__ __attribute__((aligned(16))) float rt_smem[];
+  const int qh = N / qw, nrel = gh + gw;
+  const bool is_y = (int)blockIdx.x < qh;
+  const int pos = is_y ? (int)blockIdx.x : (int)blockIdx.x - qh;   // y, or x
+  const int nq = is_y ? qw : qh, nkey = is_y ? gh : gw;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  float* qs = rt_smem;               // [nq][LP]
+  float* ts = rt_smem + nq * LP;     // [nkey][LP]
+  const float* tab = is_y ? rel_y + (int64_t)pos * gh * DH : rel_x + (int64_t)pos * gw * DH;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < nq * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = e - r * (DH / 4);
+    const int i = is_y ? pos * qw + r : r * qw + pos;
+    *reinterpret_cast<float4*>(qs + r * LP + c4 * 4) =
+        *reinterpret_cast<const float4*>(qkv + ((int64_t)b * N + i) * 3 * D + h * DH + c4 * 4);
+  }
+  for (int e = tid; e < nkey * (DH / 4); e += 256) {
+    const int r = e / (DH / 4), c4 = e - r * (DH / 4);
+    *reinterpret_cast<float4*>(ts + r * LP + c4 * 4) = *reinterpret_cast<const float4*>(tab + (int64_t)r * DH + c4 * 4);
+  }
+  __syncthreads();
+  // 4 x 4 outputs per thread: 8 LDS reads of 16 bytes per 4 channels instead of 32
+  const int tk = (nkey + 3) / 4, tiles = ((nq + 3) / 4) * tk;
+  for (int e = tid; e < tiles; e += 256) {
+    const int r0 = (e / tk) * 4, k0 = (e - (e / tk) * tk) * 4;
+    float s0[4][4], s1[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) s0[x][y] = s1[x][y] = 0.f;
+#pragma unroll 2
+    for (int d = 0; d < DH / 4; d += 2) {
+      float4 qa[4], qb[4], ta[4], tb[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const float* q = qs + min(r0 + x, nq - 1) * LP + 4 * d;
+        const float* t = ts + min(k0 + x, nkey - 1) * LP + 4 * d;
+        qa[x] = *reinterpret_cast<const float4*>(q);
+        qb[x] = *reinterpret_cast<const float4*>(q + 4);
+        ta[x] = *reinterpret_cast<const float4*>(t);
+        tb[x] = *reinterpret_cast<const float4*>(t + 4);
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          s0[x][y] += qa[x].x * ta[y].x + qa[x].y * ta[y].y + qa[x].z * ta[y].z + qa[x].w * ta[y].w;
+          s1[x][y] += qb[x].x * tb[y].x + qb[x].y * tb[y].y + qb[x].z * tb[y].z + qb[x].w * tb[y].w;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int r = r0 + x;
+      if (r >= nq) continue;
+      const int i = is_y ? pos * qw + r : r * qw + pos;
+      float* dst = terms + ((int64_t)bh * N + i) * nrel + (is_y ? 0 : gh);
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+        if (k0 + y < nkey) dst[k0 + y] = s0[x][y] + s1[x][y];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int evt_rel_terms(const float* qkv, const float* rel_y, const float* rel_x, int32_t B, int32_t H, int32_t N,
+                             int32_t D, int32_t gh, int32_t gw, int32_t qw, float* terms, void* stream) {
+  EVT_REQUIRE(qkv && rel_y && rel_x && terms, EVT_ERR_BAD_ARG, "evt_rel_terms: null pointer");
+  EVT_REQUIRE(B >= 0 && H > 0 && N > 0 && gh > 0 && gw > 0 && qw > 0 && N % qw == 0 && D == H * 64, EVT_ERR_BAD_SHAPE,
+              "evt_rel_terms: head dim 64 and N = qh * qw required (B=%d H=%d N=%d D=%d qw=%d)", B, H, N, D, qw);
+  const int qh = N / qw;
+  const size_t lds = (size_t)(std::max(qw, qh) + std::max(gh, gw)) * 68 * sizeof(float);
+  EVT_REQUIRE(lds <= 160 * 1024, EVT_ERR_BAD_SHAPE, "evt_rel_terms: grid %dx%d too large", qh, qw);
+  if (B == 0) return EVT_OK;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rel_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(rel_terms_kernel, dim3(qh + qw, B * H), dim3(256), lds, evt_stream(stream), qkv, rel_y, rel_x, H, N, D, gh, gw,
+                     qw, terms);
+  return evt_check_launch("evt_rel_terms");
+}
+
 #ifdef EVT_PROF
 extern "C" __attribute__((visibility("default"))) int evt_debug_prof_attn(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_attn_buf), sizeof(unsigned long long) * 8);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_attn_buf), sizeof(unsigned long long) * 16);
 }
 #endif

@@ -20,11 +20,11 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 3   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 4   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_pool_kv", "evt_pool_index",
+    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense",
 )
 
@@ -90,7 +90,7 @@ class SoftmaxAvDesc(Structure):
         ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p), ("pv", c_void_p),
         ("out_f32", c_void_p), ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("dh", c_int32),
         ("store", c_int32), ("Nk", c_int32), ("qw", c_int32), ("scale", c_float), ("qk_split", c_int32),
-        ("norm_ref", c_void_p), ("norm_parts", c_void_p),
+        ("norm_ref", c_void_p), ("norm_parts", c_void_p), ("rel_terms", c_void_p),
     ]
 
 
@@ -132,6 +132,7 @@ def _bind(lib):
         "evt_pool_kv": [P, I, I, I, I, I, I, P, P],
         "evt_pool_index": [P, P, I, I, I, I, I, I, I, I, P, P, P],
         "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
+        "evt_rel_terms": [P, P, P, I, I, I, I, I, I, I, P, P],
         "evt_attention_dense": [POINTER(AttnDenseDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
@@ -394,15 +395,21 @@ def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
                                  _stream()))
 
 
+def rel_terms(qkv, rel_y, rel_x, B, H, N, D, gh, gw, qw, out):
+    """Decomposed rel-pos terms of every query token (utils.py:159-168): out (B,H,N,gh+gw), read by the fused attention
+    kernel instead of recomputing them per 32-row workgroup."""
+    _check(load().evt_rel_terms(_p(qkv), _p(rel_y), _p(rel_x), B, H, N, D, gh, gw, qw, _p(out), _stream()))
+
+
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,
                      qkv=None, rel_y=None, rel_x=None, gh=0, gw=0, Nk=None, qw=None, scale=0.0, qk_split=None,
-                     norm_ref=None, norm_parts=None):
+                     norm_ref=None, norm_parts=None, rel_terms=None):
     """K5+K6.  product None: the score rows are computed in the kernel from `qkv` ((q / scale) k^T; head dim 64,
     N == Nk <= 256) instead of being read from the q.k^T state."""
     d = SoftmaxAvDesc(_p(product), _p(qkv), _p(rel_y), _p(rel_x), gh, gw, _p(a_state), _p(idx), _p(count), kcap,
                       _p(v_delta_t), _p(v_old_t), _p(pv), _p(out_f32), B, H, N, D, D // H, store,
                       N if Nk is None else Nk, gw if qw is None else qw, float(scale),
-                      int(QK_SPLIT if qk_split is None else qk_split), _p(norm_ref), _p(norm_parts))
+                      int(QK_SPLIT if qk_split is None else qk_split), _p(norm_ref), _p(norm_parts), _p(rel_terms))
     # algorithmic bytes: q.k^T state read once, gate-reference columns read + rewritten, v delta / old reads,
     # A.v state read-modify-write, fp32 output
     es, nk = (4 if store == EVT_F32 else 2), (N if Nk is None else Nk)

@@ -54,6 +54,7 @@ LN_EPS = 1e-6
 # row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
 QK_FULL_RATIO = 0.7
 FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
+REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
 
 
 class PendingSum:
@@ -732,9 +733,15 @@ class EventfulBlock(EventfulMatmul1Block):
             pg = self.projection_gate
             fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
             nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
+            # rel-pos terms of all query tokens once per frame (evt_rel_terms): each 32-row workgroup of the fused kernel
+            # would otherwise re-read 32 x (gh + gw) table rows (head dim 64, un-pooled key grid only)
+            terms = None
+            if ry is not None and dh == 64 and REL_TERMS:
+                terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
+                _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
             _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state, attn, B, H, N, D,
                                      store, Nk=Nk, scale=self.scale, norm_ref=pg.p if fuse_norm else None,
-                                     norm_parts=nparts, **rel)
+                                     norm_parts=nparts, rel_terms=terms, **rel)
             self._norm_parts_ready = (nparts, H) if fuse_norm else None
         else:
             a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)

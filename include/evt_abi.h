@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 3   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
-                                 3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes */
+#define EVT_ABI_VERSION 4   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+                                 3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
+                                 4: evt_rel_terms, evt_softmax_av_desc.rel_terms */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -325,9 +326,20 @@ typedef struct evt_softmax_av_desc {
   const float* norm_ref;                  /* nullable (B,N,D): the NEXT gate's reference (projection_gate.p) */
   float* norm_parts;                      /* with norm_ref: (B,N,H) out, ||out_f32 - norm_ref||^2 over the   */
                                           /* head's channels -> evt_select_*_sq(parts = H)                   */
+  const float* rel_terms;                 /* ABI 4, nullable, with rel_y/rel_x: (B,H,N,gh+gw) from           */
+                                          /* evt_rel_terms -- the per-row rel-pos dot products are read      */
+                                          /* instead of recomputed by every 32-row workgroup                 */
 } evt_softmax_av_desc;
 
 EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
+
+/* Decomposed relative position terms of every query token (utils.py:159-168, the two einsums of
+ * `add_decomposed_rel_pos`): terms[b,h,i,e] = q[b,i,h,:] . rel_y[i / qw, e, :] for e < gh and
+ * q[b,i,h,:] . rel_x[i % qw, e - gh, :] for gh <= e < gh + gw.  One workgroup per (clip, head, query-grid row or
+ * column): its rel_y / rel_x slice and its q rows are read once (a 32-row attention workgroup computing the same
+ * terms for itself re-reads 32 x (gh + gw) table rows of 256 bytes).  Head dim 64, N = qh * qw. */
+EVT_API int evt_rel_terms(const float* qkv, const float* rel_y, const float* rel_x, int32_t B, int32_t H, int32_t N,
+                          int32_t D, int32_t gh, int32_t gw, int32_t qw, float* terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K/V token pooling (`pool_size`, blocks.py:303-326, 525-540).

@@ -15,10 +15,11 @@ from eventful_transformer import _native as n  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=256)
+ap.add_argument("--vitdet", action="store_true", help="one stream, N = 1764 (42 x 42 grid, rel-pos), k = 256, fp32 store, score state read from HBM")
 a = ap.parse_args()
-B, N, D, H, k = a.clips, 197, 768, 12, 128
+B, N, D, H, k = (1, 1764, 768, 12, 256) if a.vitdet else (a.clips, 197, 768, 12, 128)
 dev = torch.device("cuda", 0)
-sdt = torch.bfloat16
+sdt = torch.float32 if a.vitdet else torch.bfloat16
 store = n.store_code(sdt)
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B, N, 3 * D, device=dev, generator=g)
@@ -32,16 +33,25 @@ vd_t = torch.empty(B, D, k, device=dev, dtype=sdt)
 vo_t = torch.empty(B, D, k, device=dev, dtype=sdt)
 nparts = torch.empty(B, N, H, device=dev)
 n.v_gate(qkv, idx, None, B, N, D, k, vp, vd_t, vo_t, store, True, transposed=True)
-for _ in range(100):
+if a.vitdet:
+    product = torch.randn(B, H, N, N, device=dev, generator=g)
+    ry = torch.randn(42, 42, D // H, device=dev, generator=g) * 0.2
+    rx = torch.randn(42, 42, D // H, device=dev, generator=g) * 0.2
+    for _ in range(50):
+        n.softmax_av_gated(product, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx, gh=42, gw=42)
+else:
+  for _ in range(100):
     n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0, norm_ref=p, norm_parts=nparts)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 lib = n.load()
 lib.evt_debug_prof_attn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert lib.evt_debug_prof_attn(buf) == 0
 names = ["prefetch issue + q.k^T", "softmax statistics", "barrier after staging", "MFMA sweeps (+ barrier)", "epilogue",
          "2a: A gate + state scatter", "2b: V staging + next V request"]
-tot = sum(buf[q] for q in range(7))
+tot = sum(buf[q] for q in range(7)) + buf[9]
+if a.vitdet:
+    print(f"   (streamed path) before the row pass: index loads, rel-pos terms {buf[9]}")
 print(f"wave 0 of one workgroup: {tot} ticks")
 for q, nm in enumerate(names):
     print(f"   {nm:30s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")

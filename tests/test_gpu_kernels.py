@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 3
+    assert lib.evt_version() == n.ABI_VERSION == 4
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -654,3 +654,60 @@ def test_attention_dense_argument_errors():
         n.attention_dense(qkv, 1, 1, 300, 64, 8.0, n.store_code(torch.float32), out_f32=out)
     with pytest.raises(RuntimeError, match="head dim must be 64"):
         n.attention_dense(qkv, 1, 2, 100, 64, 8.0, n.store_code(torch.float32), out_f32=out)
+
+
+@pytest.mark.parametrize("B,H,qh,qw,gh,gw", [(1, 12, 42, 42, 42, 42), (2, 2, 6, 7, 6, 7), (1, 3, 8, 6, 4, 3), (1, 2, 64, 64, 64, 64)])
+def test_rel_terms(B, H, qh, qw, gh, gw):
+    """evt_rel_terms against the reference's two einsums (utils.py:159-168), incl. a pooled key grid (gh x gw != qh x qw)."""
+    n = native()
+    dh, N = 64, qh * qw
+    D = H * dh
+    g = torch.Generator().manual_seed(qh * 100 + qw)
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    ry = torch.randn(qh, gh, dh, generator=g) * 0.3
+    rx = torch.randn(qw, gw, dh, generator=g) * 0.3
+    q = qkv[..., :D].view(B, qh, qw, H, dh).double()
+    want_y = torch.einsum("byxhc,ykc->bhyxk", q, ry.double())
+    want_x = torch.einsum("byxhc,xkc->bhyxk", q, rx.double())
+    want = torch.cat([want_y, want_x], dim=-1).reshape(B, H, N, gh + gw)
+    out = torch.full((B, H, N, gh + gw), float("nan"), device=DEV)
+    n.rel_terms(qkv.to(DEV), ry.to(DEV), rx.to(DEV), B, H, N, D, gh, gw, qw, out)
+    assert torch.allclose(out.cpu().double(), want, atol=2e-5, rtol=1e-5), float((out.cpu().double() - want).abs().max())
+
+
+@pytest.mark.parametrize("cast,N,k", [(None, 70, 12), ("bfloat16", 42, 17), (None, 1764, 256)])
+def test_fused_attention_with_precomputed_rel_terms(cast, N, k):
+    """evt_softmax_av_gated reading the rel-pos terms from evt_rel_terms == the same launch computing them itself
+    (to fp32 rounding of the 64-term dots; one ulp of the store type where a rounding flips), state mode, streamed
+    (N = 1764) and register-resident rows."""
+    n = native()
+    B, H, dh = 1, 2, 64
+    D = H * dh
+    gw = {70: 10, 42: 7, 1764: 42}[N]
+    gh = N // gw
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator(device=DEV).manual_seed(N + k)
+    qkv = torch.randn(B, N, 3 * D, device=DEV, generator=g)
+    ry = torch.randn(gh, gh, dh, device=DEV, generator=g) * 0.2
+    rx = torch.randn(gw, gw, dh, device=DEV, generator=g) * 0.2
+    product = torch.randn(B, H, N, N, device=DEV, generator=g)
+    idx = torch.stack([torch.randperm(N, device=DEV, generator=g)[:k].sort()[0] for _ in range(B)]).int().contiguous()
+    a0 = torch.rand(B, H, N, N, device=DEV, generator=g).to(sdt)
+    vp = torch.randn(B, N, D, device=DEV, generator=g).to(sdt)
+    pv0 = torch.randn(B, N, D, device=DEV, generator=g).to(sdt)
+    vd = torch.empty(B, D, k, device=DEV, dtype=sdt)
+    vo = torch.empty(B, D, k, device=DEV, dtype=sdt)
+    n.v_gate(qkv, idx, None, B, N, D, k, vp, vd, vo, store, True, transposed=True)
+    terms = torch.empty(B, H, N, gh + gw, device=DEV)
+    n.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, gw, terms)
+    res = []
+    for t in (None, terms):
+        a_s, pv, out = a0.clone(), pv0.clone(), torch.empty(B, N, D, device=DEV)
+        n.softmax_av_gated(product, a_s, idx, None, k, vd, vo, pv, out, B, H, N, D, store, qkv=qkv, rel_y=ry, rel_x=rx,
+                           gh=gh, gw=gw, rel_terms=t)
+        res.append((a_s.float().cpu(), pv.float().cpu(), out.cpu()))
+    tol = 2e-5 if cast is None else 8e-3   # bf16: one ulp at |x| <= 1 (probabilities) .. 2 (accumulated output)
+    for x, y in zip(*res):
+        assert torch.allclose(x, y, atol=tol * max(1.0, float(y.abs().max())), rtol=0), float((x - y).abs().max())
+
