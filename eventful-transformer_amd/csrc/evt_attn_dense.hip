@@ -15,6 +15,13 @@
 // result rounded to T.
 #include "evt_common.h"
 
+#ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/attn_prof.py --dense)
+__device__ unsigned long long evt_prof_dense_buf[8];
+#define DN_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
+#else
+#define DN_TICK(slot) do { } while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -155,6 +162,10 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     }
   };
 
+#ifdef EVT_PROF
+  const bool prof_on = blockIdx.x == 2 && blockIdx.y == gridDim.y / 2 && (threadIdx.x >> 6) == 0;
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
   // ---- q rows + K chunk 0 ---------------------------------------------------------------------------------------
   float4 kr[IT];
   {
@@ -173,6 +184,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     store_k(kr);
   }
   __syncthreads();
+  DN_TICK(0);   // q rows + K chunk 0 staged
   if (KC < a.N) load_k(KC, kr);   // K chunk 1 flies during the rel-pos dots and the first MFMA sweep
   if (rel) {
     // rel-pos terms of the 32 rows (utils.py:159-168), per TABLE ROW: (yi, ky) for the <= 32/qw + 2 query grid rows
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
       }
   }
   __syncthreads();   // rel-pos dots and fragment reads are done: the q tile's storage becomes the score tile
+  DN_TICK(1);   // rel-pos dots, q fragments
 
   // ---- S = q k^T: 64-key chunks, wave w owns keys 16w .. 16w+15 of the chunk for all 32 rows -------------------------
   float4 vr[IT];
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     }
     __syncthreads();
   }
+  DN_TICK(2);   // q.k^T chunks
   store_v(vr);   // the K region is free: V^T chunk 0 lands while the softmax runs (next barrier publishes both)
 
   // ---- softmax: wave w owns rows 8w .. 8w+7; P overwrites the row's scores in place (as T) ------------------------
@@ -290,38 +304,52 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
     const int npad = (a.N + 15) & ~15;
     T* ast = reinterpret_cast<T*>(a.a_state);
-#pragma unroll 2
+    // All 8 rows of the wave together: their max / sum reductions are independent DPP chains that overlap, and the exps
+    // use v_exp_f32 and one reciprocal per row like the fused gated kernel (in-kernel phase timing: the row-after-row
+    // version with expf and a division per element took 2.3-2.8k ticks per row, a third of the workgroup's life).
+    float x[8][4], mx[8], rinv[8];
+#pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr, i = i0 + r;
+      const int r = wave * 8 + rr;
       const float* rv = relv + r * nrel;
-      float x[4];
-      float mx = -INFINITY;
+      float m = -INFINITY;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = lane + 64 * u;
-        x[u] = -INFINITY;
+        x[rr][u] = -INFINITY;
         if (j < a.N) {
           float v = Ss[r * SP + j];
           if (rel) { const int ky = fast_div(j, inv_gw); v = (v + rv[ky]) + rv[a.gh + j - ky * a.gw]; }
-          x[u] = v;
+          x[rr][u] = v;
         }
-        mx = fmaxf(mx, x[u]);
+        m = fmaxf(m, x[rr][u]);
       }
-      mx = wave_max_dpp(mx);
+      mx[rr] = m;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max_dpp(mx[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
       float sum = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        x[u] = (lane + 64 * u < a.N) ? expf(x[u] - mx) : 0.f;
-        sum += x[u];
+        x[rr][u] = (lane + 64 * u < a.N) ? __builtin_amdgcn_exp2f((x[rr][u] - mx[rr]) * 1.44269504088896340736f) : 0.f;
+        sum += x[rr][u];
       }
-      sum = wave_sum_dpp(sum);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();   // every lane has read the fp32 row before anyone overwrites it with T
+      rinv[rr] = sum;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) rinv[rr] = 1.0f / wave_sum_dpp(rinv[rr]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();   // every lane has read the fp32 rows before anyone overwrites them with T
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr, i = i0 + r;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = lane + 64 * u;
         if (j < npad) {
-          const float p = (j < a.N && i < a.N) ? Store<T>::round(x[u] / sum) : 0.f;
+          const float p = (j < a.N && i < a.N) ? Store<T>::round(x[rr][u] * rinv[rr]) : 0.f;
           Store<T>::store(Ps + r * SP * TPF + j, p);
           if (ast != nullptr && j < a.N && i < a.N) Store<T>::store(ast + ((int64_t)gh_ * a.N + i) * a.N + j, p);
         }
@@ -330,6 +358,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
   }
   __syncthreads();
 
+  DN_TICK(3);   // softmax + state write
   // ---- P . V: V^T chunks of 64 keys in the K region; wave = (dh half, 32-key half of the chunk) ----------------------
   f32x16 acc;
 #pragma unroll
@@ -350,6 +379,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     __syncthreads();
   }
 
+  DN_TICK(4);   // P.V chunks
   // ---- epilogue: add the two key halves, round, merge heads, un-window ------------------------------------------
   if (kh == 1) {
 #pragma unroll
@@ -380,6 +410,11 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
       *reinterpret_cast<float4*>(a.out_f32 + orow * a.D + h * DH + c4 * 4) = v;
     }
   }
+#ifdef EVT_PROF
+  DN_TICK(5);   // epilogue
+  if (prof_on && (threadIdx.x & 63) == 0)
+    for (int q = 0; q < 8; ++q) evt_prof_dense_buf[q] = prof_acc[q];
+#endif
 }
 
 template <typename T>
@@ -419,3 +454,9 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
   EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, stream); });
   return EVT_OK;
 }
+
+#ifdef EVT_PROF
+extern "C" __attribute__((visibility("default"))) int evt_debug_prof_dense(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_dense_buf), sizeof(unsigned long long) * 8);
+}
+#endif

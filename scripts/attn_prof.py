@@ -15,8 +15,43 @@ from eventful_transformer import _native as n  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--clips", type=int, default=256)
+ap.add_argument("--dense", choices=["vivit", "window"], default=None,
+                help="K8 (evt_attention_dense) instead: vivit = first frame of a clip (B clips, N = 197, bf16, states written); "
+                     "window = ViTDet 14 x 14 windows of a 42 x 42 frame (fp32, rel-pos)")
 ap.add_argument("--vitdet", action="store_true", help="one stream, N = 1764 (42 x 42 grid, rel-pos), k = 256, fp32 store, score state read from HBM")
 a = ap.parse_args()
+if a.dense is not None:
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    D, H = 768, 12
+    if a.dense == "vivit":
+        B, N = a.clips, 197
+        sdt = torch.bfloat16
+        qkv = torch.randn(B, N, 3 * D, device=dev, generator=g)
+        out = torch.empty(B, N, D, device=dev)
+        ap_ = torch.empty(B, H, N, N, device=dev, dtype=sdt)
+        pv = torch.empty(B, N, D, device=dev, dtype=sdt)
+        for _ in range(30):
+            n.attention_dense(qkv, B, H, N, D, 8.0, n.store_code(sdt), out_f32=out, a_state=ap_, pv=pv)
+    else:
+        G, N = 9, 196   # nine windows of one 42 x 42 frame, identity window map
+        qkv = torch.randn(G, N, 3 * D, device=dev, generator=g)
+        out = torch.empty(G, N, D, device=dev)
+        ry = torch.randn(14, 14, 64, device=dev, generator=g) * 0.2
+        rx = torch.randn(14, 14, 64, device=dev, generator=g) * 0.2
+        for _ in range(100):
+            n.attention_dense(qkv, G, H, N, D, 8.0, n.store_code(torch.float32), out_f32=out, rel_y=ry, rel_x=rx, gh=14, gw=14, qw=14)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    lib = n.load()
+    lib.evt_debug_prof_dense.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    assert lib.evt_debug_prof_dense(buf) == 0
+    names = ["q rows + K chunk 0 staged", "rel-pos dots + q fragments", "q.k^T chunks", "softmax + state write", "P.V chunks", "epilogue"]
+    tot = sum(buf[q] for q in range(6))
+    print(f"K8 {a.dense}: wave 0 of one workgroup: {tot} ticks")
+    for q, nm in enumerate(names):
+        print(f"   {nm:30s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")
+    sys.exit(0)
 B, N, D, H, k = (1, 1764, 768, 12, 256) if a.vitdet else (a.clips, 197, 768, 12, 128)
 dev = torch.device("cuda", 0)
 sdt = torch.float32 if a.vitdet else torch.bfloat16
