@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   };
   // stage side: the element written to LDS lags the load side by two elements, so it keeps its own tile description
   uint32_t st_off[AJ];
-  int st_k = 0, st_bn = 0, st_m0 = 0;
+  int st_k = 0, st_bn = 0, st_m0 = 0, st_upd = 0;   // st_upd: next k-tile whose rows this column tile writes back to the gate reference
   auto stage = [&](const Regs& R, int s) __attribute__((always_inline)) {   // registers -> LDS stage s; column tile bn refreshes p for k-tile = bn (mod tiles_n)
 #ifdef EVT_PROF
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH == 2 ? AJ + WJ : 0));
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     if (st_k == nk) {   // first k-tile of the next tile: the load side entered it two elements ago (and no later tile yet)
       st_k = 0;
       st_bn = bn_s;
+      st_upd = bn_s;
       st_m0 = m0_s;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) st_off[j] = a_off[j];
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     if (WJ > 1) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + WROWS, wc8)) = R.w1;
     if (WJ > 2) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 2 * WROWS, wc8)) = R.w2;
     if (WJ > 3) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 3 * WROWS, wc8)) = R.w3;
-    if (!APL && do_upd && (st_k % tiles_n) == st_bn) {
+    if (!APL && do_upd && st_k == st_upd) {   // k-tiles st_bn, st_bn + tiles_n, ... (a counter: the modulo cost 14 scalar instructions per k-tile)
+      st_upd += tiles_n;
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
         if (st_m0 + ar0 + AROWS * j < M) *reinterpret_cast<f32x4*>(Pbase + (st_off[j] + (uint32_t)st_k * (TBK * 4u))) = R.a[j];
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   issue_indices(0);
   enter_tile(0);
   st_bn = bn_s;
+  st_upd = bn_s;
   st_m0 = m0_s;
 #pragma unroll
   for (int j = 0; j < AJ; ++j) st_off[j] = a_off[j];
