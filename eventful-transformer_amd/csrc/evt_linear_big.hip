@@ -414,6 +414,16 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   int mk = stage_first ? -(DEPTH + 1) : -DEPTH, mseq = 0;   // multiply side: k-tile / tile of the element this wave multiplies in iteration i
   auto step = [&](Regs& R, int s, int i) __attribute__((always_inline)) {   // s = (i + 1) & 1, a compile-time constant at both call sites
     EVT_TICK(7);
+    // The prefetched indices of the next tile are loop-carried registers that a load may have written: pinned HERE, at the
+    // top of the iteration (the staging below waits for every older load anyway), they count as clean afterwards.
+    // Otherwise hipcc puts s_waitcnt vmcnt(0) in front of the register moves that merge them further down -- behind the
+    // gate-reference stores of the staging: the next fetch then waited for those stores to be acknowledged, ~1 us on every
+    // k-tile that refreshes p.
+    if (DEPTH == 1) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) asm volatile("" : "+v"(nsrc[j]));
+      asm volatile("" : "+v"(nrow), "+v"(nbias));
+    }
     if (i >= -1 && i + 1 < total) stage(R, s);
     EVT_TICK(0);   // staging (incl. the wait for the loads)
     if (i >= -DEPTH && i + 1 + DEPTH < total) {
@@ -531,7 +541,7 @@ bool evt_launch_split_big(const LinArgs& a, hipStream_t s) {
   switch (evt_big_choice(a)) {
     case 2: launch_big_cfg<256, 256, 4, 2, 1>(a, s); return true;
     case 3: launch_big_cfg<256, 128, 4, 2, 1>(a, s); return true;
-    case 4: launch_big_cfg<256, 192, 4, 2, 2>(a, s); return true;
+    case 4: launch_big_cfg<256, 192, 4, 2, 1>(a, s); return true;   // (a two-deep register prefetch measured the same: kept out)
     default: return false;
   }
 }
