@@ -726,8 +726,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     if (ok) {
 #pragma unroll
       for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + o)[q] = st8.u[q];
-      reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
-      reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+      if (a.out_f32 != nullptr) {   // wave-uniform; NULL: the caller reads the (identical) values from the A.v state
+        reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
+        reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+      }
     }
     if (a.norm_parts != nullptr) {   // wave-uniform
       // ||out - ref||^2 over this head's channels: the dh/8 threads of a row are consecutive lanes; their sums are
@@ -781,8 +783,9 @@ int launch_fused(const FusedArgs& a, void* stream) {
 
 extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) {
   EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null descriptor");
-  EVT_REQUIRE(d->a_state && d->idx && d->v_delta_t && d->v_old_t && d->pv && d->out_f32,
-              EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null pointer");
+  EVT_REQUIRE(d->a_state && d->idx && d->v_delta_t && d->v_old_t && d->pv, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: null pointer");
+  EVT_REQUIRE(d->out_f32 != nullptr || d->store != EVT_F32, EVT_ERR_BAD_ARG,
+              "evt_softmax_av_gated: out_f32 may only be omitted with a 16-bit store type (the output then IS the pv state)");
   if (d->product == nullptr) {  // QK mode: scores from the token buffer
     EVT_REQUIRE(d->qkv != nullptr && d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_softmax_av_gated: product == NULL needs qkv and scale");
     EVT_REQUIRE(d->dh == 64 && d->Nk == d->N && d->N <= 256 && d->kcap > 0, EVT_ERR_BAD_SHAPE,

@@ -11,6 +11,8 @@ struct LinArgs {
   float* ws; int64_t ws_bytes;
   // evt_linear_big.hip only (set by evt_gated_mlp for its hidden scratch): A / out hold hl32 lines instead of fp32
   int a_planes, out_planes;
+  // evt_linear_big.hip only: A is ONE bf16 plane (row pitch lda elements) of exactly bf16-representable values (ABI 4: a_bf16)
+  int a_bf16;
 };
 
 // evt_linear_big.hip: 256-row tiles for launches that fill the chip.  evt_big_choice: the tile configuration the launch would

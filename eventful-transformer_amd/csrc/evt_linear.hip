@@ -727,7 +727,20 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
   EVT_REQUIRE(d->workspace_bytes >= 0, EVT_ERR_BAD_ARG, "evt_gated_linear: negative workspace_bytes");
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
+  if (d->a_bf16) {
+    a.a_bf16 = 1;
+    EVT_REQUIRE(d->act == EVT_ACT_NONE && forced_tile_variant() < 0 && evt_big_choice(a) != 0, EVT_ERR_BAD_SHAPE,
+                "evt_gated_linear: bf16 activations only on the persistent 256-row kernel without activation (query "
+                "evt_gated_linear_big_tile first): B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
+  }
   return launch_linear(a, stream);
+}
+
+extern "C" int evt_gated_linear_big_tile(const evt_linear_desc* d) {
+  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || forced_tile_variant() >= 0) return 0;
+  LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
+            d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
+  return evt_big_choice(a);
 }
 
 extern "C" int64_t evt_gated_linear_workspace_bytes(int32_t B, int32_t kcap, int32_t K, int32_t Nout, int32_t has_count) {

@@ -41,6 +41,11 @@ __device__ unsigned long long evt_prof_buf[2][8];
 #define EVT_ABLATE 0
 #endif
 
+// FMT bit 2 (ABF): the activations are ONE bf16 plane (row pitch lda elements): values that are exactly representable in
+// bf16 -- the A.v state of a bf16 `matmul_2_cast`, which IS the attention output (blocks.py:183-189) -- have hi = the value and
+// lo = 0, so the tile is staged as a plain copy of half the bytes and the A_lo . W_hi MFMA is skipped (adding its exact zeros
+// changes nothing: results are bit-identical to the fp32-activation launch).  The gate reference is refreshed with the widened
+// values.
 // FMT bit 0 (APL): the activations are already split -- A holds hl32 lines like the weights (row pitch lda * 4 bytes, i.e. the
 // bytes of the fp32 row it replaces); staging is then a plain 16-byte copy, no conversion.  FMT bit 1 (OPL): the output is
 // written as hl32 lines instead of fp32 (same bytes).  evt_gated_mlp uses both for its hidden scratch: the first launch's
@@ -48,7 +53,8 @@ __device__ unsigned long long evt_prof_buf[2][8];
 template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel(const LinArgs g, int tiles_n, int tiles_total) {
   constexpr int NT = WM * WN * 64, TBK = 32;
-  constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0;
+  constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0, ABF = (FMT & 4) != 0;
+  static_assert(!(APL && ABF), "one activation format");
   constexpr int MI = TBM / WM / 32, NJ = TBN / WN / 32;   // 32x32 accumulators per wave: MI x NJ
   // Ping-pong pacing (pre-split activations only): TWO barriers per k-tile, the multiply-first group running one barrier
   // interval behind, so that on every SIMD one wave multiplies ALONE (all of its fragment reads requested up front) while its
@@ -95,7 +101,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
 #endif
 
-  constexpr int ACH = TBK / 4, AROWS = NT / ACH, AJ = TBM / AROWS;   // float4 chunks per A row, rows per pass, passes
+  constexpr int ACH = ABF ? TBK / 8 : TBK / 4, AROWS = NT / ACH, AJ = TBM / AROWS;   // 16-byte chunks per A row (fp32 / hl32: 8, bf16: 4), rows per pass, passes
+  constexpr uint32_t ABYTES = ABF ? TBK * 2u : TBK * 4u;   // bytes of one k-tile of an activation row
   // weight tile: TBN rows x one 128-byte hl32 line (4 hi chunks, 4 lo chunks of 16 bytes); chunk id = tid + NT * j
   constexpr int WROWS = NT / 8, WJ = TBN / WROWS;   // rows per pass, passes
   static_assert(AJ >= 1 && WJ >= 1 && WJ <= 4 && TBN % WROWS == 0, "tile / thread-count mismatch");
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
       a_off[j] = ac4 * 16;
       if (m < M) {
         const int b = m / g.kcap, i = m - b * g.kcap;
-        a_off[j] = (uint32_t)((b * g.a_rows + ((g.a_idx != nullptr) ? nsrc[j] : i)) * (int)g.lda + ac4 * 4) * 4u;
+        a_off[j] = (uint32_t)((b * g.a_rows + ((g.a_idx != nullptr) ? nsrc[j] : i)) * (int)g.lda) * (ABF ? 2u : 4u) + ac4 * 16u;
       }
     }
 #pragma unroll
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   };
   Regs R0, R1;
   auto fetch = [&](Regs& R, int kt) __attribute__((always_inline)) {   // k-tile kt of the load-side tile -> registers (K % 32 == 0: whole tiles only)
-    const uint32_t kw = (uint32_t)kt * 128u, ka = (uint32_t)kt * (TBK * 4u);
+    const uint32_t kw = (uint32_t)kt * 128u, ka = (uint32_t)kt * ABYTES;
     R.w0 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[0] + kw));
     if (WJ > 1) R.w1 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 1 ? 1 : 0] + kw));
     if (WJ > 2) R.w2 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 2 ? 2 : 0] + kw));
@@ -200,7 +207,10 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     __bf16* Alo = Ahi + TBM * TBK + APAD;
     __bf16* Bhi = Alo + TBM * TBK;
     __bf16* Blo = Bhi + TBN * TBK + WPAD;
-    if (APL) {   // the 16 bytes are chunk ac4 of the row's 128-byte line: chunks 0-3 hi, 4-7 lo
+    if (ABF) {   // 8 bf16 values = the hi plane's chunk ac4; there is no lo plane
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(Ahi + lds_off(ar0 + AROWS * j, ac4 * 8)) = R.a[j];
+    } else if (APL) {   // the 16 bytes are chunk ac4 of the row's 128-byte line: chunks 0-3 hi, 4-7 lo
       __bf16* Apl = (ac4 & 4) ? Alo : Ahi;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(Apl + lds_off(ar0 + AROWS * j, (ac4 & 3) * 8)) = R.a[j];
@@ -222,7 +232,22 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
       st_upd += tiles_n;
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
-        if (st_m0 + ar0 + AROWS * j < M) *reinterpret_cast<f32x4*>(Pbase + (st_off[j] + (uint32_t)st_k * (TBK * 4u))) = R.a[j];
+        if (st_m0 + ar0 + AROWS * j < M) {
+          if (ABF) {   // widen the 8 bf16 values: the fp32 reference row has twice the byte offset
+            union { f32x4 v; uint32_t u[4]; } in;
+            in.v = R.a[j];
+            f32x4 lo4, hi4;
+            lo4.x = __uint_as_float(in.u[0] << 16); lo4.y = __uint_as_float(in.u[0] & 0xffff0000u);
+            lo4.z = __uint_as_float(in.u[1] << 16); lo4.w = __uint_as_float(in.u[1] & 0xffff0000u);
+            hi4.x = __uint_as_float(in.u[2] << 16); hi4.y = __uint_as_float(in.u[2] & 0xffff0000u);
+            hi4.z = __uint_as_float(in.u[3] << 16); hi4.w = __uint_as_float(in.u[3] & 0xffff0000u);
+            char* dst = Pbase + (2u * st_off[j] + (uint32_t)st_k * (TBK * 4u));
+            *reinterpret_cast<f32x4*>(dst) = lo4;
+            *reinterpret_cast<f32x4*>(dst + 16) = hi4;
+          } else {
+            *reinterpret_cast<f32x4*>(Pbase + (st_off[j] + (uint32_t)st_k * (TBK * 4u))) = R.a[j];
+          }
+        }
     }
     ++st_k;
   };
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
         for (int i = 0; i < MI; ++i) {
           const int ao = lds_off(wm * (MI * 32) + i * 32 + lr, ks + 8 * lh);
           ah[h][i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
-          al[h][i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
+          if (!ABF) al[h][i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[h][i], bh[h][j], acc[i][j], 0, 0, 0);
+            if (!ABF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[h][i], bh[h][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[h][i], bl[h][j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[h][i], bh[h][j], acc[i][j], 0, 0, 0);
           }
@@ -501,7 +526,8 @@ void launch_big_cfg(const LinArgs& a, hipStream_t s) {
   const dim3 grid(std::min(tiles_m * tiles_n, cu_count()));   // persistent: one workgroup per CU
   const int tt = tiles_m * tiles_n;
   // formats in use: fp32 -> fp32 (any activation), fp32 -> hl32 with GELU (first half of the MLP), hl32 -> fp32 (second half)
-  if (a.a_planes) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1>(a, s, grid, tiles_n, tt);   // (one register set: room for both fragment sets)
+  if (a.a_bf16) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 4>(a, s, grid, tiles_n, tt);
+  else if (a.a_planes) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1>(a, s, grid, tiles_n, tt);   // (one register set: room for both fragment sets)
   else if (a.out_planes) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 2>(a, s, grid, tiles_n, tt);
   else if (a.act == EVT_ACT_GELU_ERF) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 0>(a, s, grid, tiles_n, tt);
   else launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, DEPTH, 0>(a, s, grid, tiles_n, tt);
@@ -517,7 +543,7 @@ int evt_big_choice(const LinArgs& a) {
   // which skips dead tiles)
   if (mode == 0 || a.Wsplit == nullptr || (a.K & 31) != 0 || a.K < 64 || a.count != nullptr) return 0;
   // 32-bit byte offsets inside the kernel: activations (and the gate reference, same shape), weight planes and output below 4 GB
-  if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) || (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
+  if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) ||   // (also bounds the fp32 gate reference of a bf16 launch) (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
       (int64_t)a.B * a.o_rows * a.ldo * 4 >= ((int64_t)1 << 32))
     return 0;
   if (mode >= 2 && mode <= 4) return mode;

@@ -24,7 +24,7 @@ ABI_VERSION = 4   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_linear_workspace_bytes", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
+    "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense",
 )
 
@@ -35,7 +35,7 @@ class LinearDesc(Structure):
         ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
         ("o_idx", c_void_p), ("o_rows", c_int32), ("count", c_void_p), ("p_upd", c_void_p),
         ("B", c_int32), ("kcap", c_int32), ("K", c_int32), ("Nout", c_int32), ("act", c_int32),
-        ("W_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("W_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64), ("a_bf16", c_int32),
     ]
 
 
@@ -124,6 +124,7 @@ def _bind(lib):
         "evt_gate_gather_update": [P, P, P, P, I, I, I, I, P, P, I, P],
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
+        "evt_gated_linear_big_tile": [POINTER(LinearDesc)],
         "evt_gated_mlp": [POINTER(MlpDesc), P],
         "evt_split_weights": [P, P, c_int64, c_int64, P],
         "evt_qk": [POINTER(QkDesc), P],
@@ -314,11 +315,21 @@ def _splitk_workspace(device, has_count, *shapes):
     return scratch("splitk_ws", (need // 4,), torch.float32, device), need
 
 
+def gated_linear_big_tile(lda, gathered, a_rows, ldo, scattered, o_rows, has_count, B, kcap, K, Nout, has_split=True):
+    """Tile configuration of the persistent 256-row kernel a launch of this shape runs on (0: the 128x128 kernel): the
+    launches that accept bf16 activations (`a_bf16`).  Shape-only -- the descriptor's pointers are only compared with NULL."""
+    one = ctypes.c_void_p(1)
+    d = LinearDesc(one, lda, one if gathered else None, a_rows, one, one, one, ldo, one if scattered else None, o_rows,
+                   one if has_count else None, None, B, kcap, K, Nout, ACT_NONE, one if has_split else None, None, 0, 0)
+    return int(load().evt_gated_linear_big_tile(ctypes.byref(d)))
+
+
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
-                 W_split=None):
+                 W_split=None, a_bf16=False):
+    """a_bf16: A is a bfloat16 tensor of exactly representable activations (the A.v state; see evt_abi.h)."""
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
-                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes)
+                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16))
     _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 

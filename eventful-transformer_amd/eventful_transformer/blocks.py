@@ -54,6 +54,7 @@ LN_EPS = 1e-6
 # row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
 QK_FULL_RATIO = 0.7
 FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
+PROJ_FROM_STATE = os.environ.get("EVT_PROJ_FROM_STATE", "1") != "0"   # bf16 cast: projection reads the A.v state, no fp32 attention output
 REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
 
 
@@ -463,9 +464,12 @@ class EventfulTokenwiseBlock(Block):
             linear_fn(c, idx, count, buffer.b, None, B, cap)
         else:
             parts = 0
+            src16 = None
             if ln is None and res is None:
                 c = src  # the gate input already exists in HBM: only the norms are new
                 ready, self._norm_parts_ready = getattr(self, "_norm_parts_ready", None), None
+                if tag == "projection":
+                    src16, self._proj_state_src = getattr(self, "_proj_state_src", None), None
                 if ready is not None and tag == "projection":
                     norms, parts = ready   # ||src - p||^2 per head came out of the fused attention epilogue
                 else:
@@ -474,17 +478,21 @@ class EventfulTokenwiseBlock(Block):
                 _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
                                  p=gate.p, norms=norms)
             idx, count, cap = self._select(gate, c, norms, B, N, tag, parts=parts)
-            linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap)
+            if src16 is not None:   # the fp32 attention output was not written: the projection reads the bf16 A.v state
+                assert parts and count is None and not stgt
+                linear_fn(src16, idx, count, buffer.b, gate.p, B, cap, a_bf16=True)
+            else:
+                linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap)
             if stgt:
                 _native.row_pass(c, rows, D, c_out=gate.p)
         return buffer.b, idx, count, cap
 
     def _linear_fn(self, layer):
-        def run(a, idx, count, out, p_upd, B, cap):
+        def run(a, idx, count, out, p_upd, B, cap, a_bf16=False):
             N = out.shape[1]
             _native.gated_linear(a, layer.in_features, idx, N if idx is not None else cap, layer.weight, layer.bias,
                                  out, layer.out_features, idx, N if idx is not None else cap, count, p_upd, B, cap,
-                                 layer.in_features, layer.out_features, W_split=layer.split_planes())
+                                 layer.in_features, layer.out_features, W_split=layer.split_planes(), a_bf16=a_bf16)
             if layer.count_mode:
                 layer.count_rows(self._n_rows(B, cap, count))
         return run
@@ -733,16 +741,26 @@ class EventfulBlock(EventfulMatmul1Block):
             pg = self.projection_gate
             fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
             nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
+            # bf16 `matmul_2_cast`: the attention output IS the A.v state (out == pv.float()).  When the projection then runs
+            # on the persistent GEMM (which takes bf16 activations: half the bytes, no split, two MFMAs of three), it reads the
+            # state directly and this launch does not write the fp32 copy at all.
+            state_src = False
+            if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+                    and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
+                cap_p = pg.policy.capacity(N)
+                state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
             # rel-pos terms of all query tokens once per frame (evt_rel_terms): each 32-row workgroup of the fused kernel
             # would otherwise re-read 32 x (gh + gw) table rows (head dim 64, un-pooled key grid only)
             terms = None
             if ry is not None and dh == 64 and REL_TERMS:
                 terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
                 _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
-            _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state, attn, B, H, N, D,
+            _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state,
+                                     None if state_src else attn, B, H, N, D,
                                      store, Nk=Nk, scale=self.scale, norm_ref=pg.p if fuse_norm else None,
                                      norm_parts=nparts, rel_terms=terms, **rel)
             self._norm_parts_ready = (nparts, H) if fuse_norm else None
+            self._proj_state_src = acc._state if state_src else None   # consumed by the projection group (`attn` is unwritten)
         else:
             a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)
             a_delta = self._ws("a_delta", (B, H, N, cap_k), sdt, qkv)

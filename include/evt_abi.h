@@ -33,7 +33,8 @@ extern "C" {
 
 #define EVT_ABI_VERSION 4   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
-                                 4: evt_rel_terms, evt_softmax_av_desc.rel_terms */
+                                 4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
+                                    evt_gated_linear_big_tile */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -142,9 +143,18 @@ typedef struct evt_linear_desc {
   const void* W_split;                     /* nullable: evt_split_weights(W) -> split-precision  */
                                            /* MFMA path (3 bf16 MFMAs per fp32 product)          */
   void* workspace;       int64_t workspace_bytes;  /* nullable: split-K partial sums (see below) */
+  int32_t a_bf16;                          /* ABI 4.  1: A points to bf16 values (row stride lda elements) -- activations that */
+                                           /* are exactly bf16-representable, i.e. the A.v state of a bf16 matmul_2_cast,    */
+                                           /* which IS the attention output (blocks.py:183-189): half the bytes, no split,   */
+                                           /* one MFMA of three skipped, bit-identical results.  p_upd still receives fp32.  */
+                                           /* Only launches for which evt_gated_linear_big_tile() != 0 accept it.            */
 } evt_linear_desc;
 
 EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
+
+/* The tile configuration of the persistent 256-row kernel this launch would run on (0: it runs on the 128x128 kernel or its
+ * split-K form).  Shape-only: pointers are compared with NULL, nothing is dereferenced, no GPU needed. */
+EVT_API int evt_gated_linear_big_tile(const evt_linear_desc* d);
 
 /* Split-K for launches with few output tiles (one stream, small r: ViTDet, batch 1).  When the
  * 128x128 tiling yields fewer workgroups than the chip has CUs, the split-precision kernel divides K
@@ -316,7 +326,8 @@ typedef struct evt_softmax_av_desc {
   const int32_t* idx; const int32_t* count; int32_t kcap;
   const void* v_delta_t; const void* v_old_t;
   void* pv;                               /* (B,N,D) store type: matmul_accumulator_2.product    */
-  float* out_f32;                         /* (B,N,D)                                             */
+  float* out_f32;                         /* (B,N,D); ABI 4: nullable with a 16-bit store type   */
+                                          /* (the output then equals the pv state, widened)       */
   int32_t B, H, N, D, dh;
   int32_t store;
   int32_t Nk, qw;                         /* key count (== N unless pooled), query grid width    */

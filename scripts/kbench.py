@@ -96,6 +96,8 @@ def main():
                                ("TF", 2.0 * M * D * 3 * D)),
         "linear_proj": (lambda: n.gated_linear(x, D, idx, N, Wp, b1, buf, D, idx, N, None, p, B, k, D, D, W_split=Sp),
                         ("TF", 2.0 * M * D * D)),
+        "linear_proj_bf16": (lambda: n.gated_linear(vp, D, idx, N, Wp, b1, buf, D, idx, N, None, p, B, k, D, D, W_split=Sp, a_bf16=True),
+                             ("TF", 2.0 * M * D * D)),
         "linear_mlp1_gelu": (lambda: n.gated_linear(x, D, idx, N, W1, b4, hidden, 4 * D, None, k, None, p, B, k, D, 4 * D, act=n.ACT_GELU,
                                                     W_split=S1), ("TF", 2.0 * M * D * 4 * D)),
         "linear_mlp2": (lambda: n.gated_linear(hidden, 4 * D, None, k, W2, b1, buf, D, idx, N, None, None, B, k, 4 * D, D, W_split=S2),
@@ -113,6 +115,9 @@ def main():
                              ("GB/s", B * H * N * (4 * N + 2 * es * k) + B * N * D * (4 + 2 * es))),
         "softmax_av_fused_qk": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0),
                                 ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 2 * es))),
+        "softmax_av_fused_qk_norm_noout": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, None, B, H, N, D, store, qkv=qkv, scale=8.0,
+                                                                      norm_ref=p, norm_parts=nparts),
+                                           ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 2 * es))),
         "softmax_av_fused_qk_norm": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0,
                                                                 norm_ref=p, norm_parts=nparts),
                                      ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 4 + 2 * es))),

@@ -60,6 +60,30 @@ def main():
         if act:
             yd = torch.nn.functional.gelu(yd)
         assert torch.allclose(out.cpu(), yd.float(), atol=2e-4, rtol=1e-4)
+    # bf16 activations (the A.v state of a bf16 matmul_2_cast feeding the projection): bit-identical to the same values as fp32
+    for B, N, K, Nout, k in [(3, 300, 96, 520, 140), (64, 197, 768, 768, 128)]:
+        g = torch.Generator().manual_seed(B + N + K + Nout + 7)
+        Ab = (torch.randn(B, N, K, generator=g) * 2).to(torch.bfloat16)
+        W = torch.randn(Nout, K, generator=g) * 0.05
+        bias = torch.randn(Nout, generator=g)
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)]).int()
+        buf0 = torch.randn(B, N, Nout, generator=g)
+        p0 = torch.randn(B, N, K, generator=g)
+        Wd, bd, idxd = W.to(DEV), bias.to(DEV), idx.to(DEV)
+        Ws = n.split_weight(Wd)
+        assert n.gated_linear_big_tile(K, True, N, Nout, True, N, False, B, k, K, Nout) != 0
+        res = []
+        for a_bf16 in (False, True):
+            A = Ab.to(DEV) if a_bf16 else Ab.float().to(DEV)
+            buf, pd = buf0.to(DEV), p0.to(DEV)
+            n.gated_linear(A, K, idxd, N, Wd, bd, buf, Nout, idxd, N, None, pd, B, k, K, Nout, 0, W_split=Ws, a_bf16=a_bf16)
+            res.append((buf.cpu(), pd.cpu()))
+        assert torch.equal(res[0][0], res[1][0]), "bf16 activations: output differs from the fp32 launch"
+        assert torch.equal(res[0][1], res[1][1]), "bf16 activations: gate reference refresh differs"
+        rows = Ab.float().gather(1, idx.long().unsqueeze(-1).expand(-1, -1, K))
+        y = torch.nn.functional.linear(rows.double(), W.double(), bias.double())
+        ref = buf0.clone().scatter_(1, idx.long().unsqueeze(-1).expand(-1, -1, Nout), y.float())
+        assert torch.allclose(res[1][0], ref, atol=3e-4, rtol=1e-4), float((res[1][0] - ref).abs().max())
     # gated MLP: under a forced tile both launches run on the 256-row kernel, so the hidden scratch holds pre-split hl32
     # lines (written by the first launch's epilogue, staged without conversion by the second)
     for B, N, D, Dh, k in [(3, 300, 96, 160, 140), (64, 197, 768, 3072, 128)]:
@@ -92,6 +116,41 @@ def main():
         n.gated_linear(Ad, D, idxd, N, W1d, b1d, hid2, Dh, None, k, None, None, B, k, D, Dh, n.ACT_GELU, W_split=S1)
         n.gated_linear(hid2, Dh, None, k, W2d, b2d, buf2, D, idxd, N, None, None, B, k, Dh, D, 0, W_split=S2)
         assert torch.equal(buf2.cpu(), buf.cpu()), "pre-split hidden differs from fp32 hidden"
+    # block level: with a bf16 A.v cast the projection reads the A.v state (no fp32 attention output is written) whenever
+    # its launch runs on the 256-row kernel -- forced here at a small batch.  Two ViViT-sized EventfulBlocks, 3 clips x 4
+    # frames: bit-identical to the fp32-output path, and the state path is really taken.
+    from eventful_transformer import blocks as EB, policies
+    from eventful_transformer.backbones import ViTBackbone
+    torch.manual_seed(11)
+    bb = ViTBackbone(block_config=dict(dim=768, heads=12, mlp_ratio=4, matmul_2_cast="bfloat16"), depth=2,
+                     position_encoding_size=(14, 14), input_size=(14, 14), block_class="EventfulBlock", has_class_token=True)
+    for p_ in bb.parameters():
+        torch.nn.init.normal_(p_, std=0.02)
+    bb = bb.eval().to(DEV)
+    for m in bb.modules():
+        if hasattr(m, "policy"):
+            m.policy = policies.TokenNormTopK(k=128)
+    g = torch.Generator().manual_seed(5)
+    xs = (torch.randn(4, 3, 197, 768, generator=g) * 0.5).to(DEV)
+    xs[1:] = xs[0] + 0.02 * torch.randn(3, 3, 197, 768, generator=g).to(DEV)
+    taken = []
+    orig = n.gated_linear
+
+    def spy(*args, **kw):
+        taken.append(bool(kw.get("a_bf16", False)))
+        return orig(*args, **kw)
+
+    n.gated_linear = spy
+    runs = []
+    with torch.inference_mode():
+        for on in (True, False):
+            EB.PROJ_FROM_STATE = on
+            taken.clear()
+            bb.reset()
+            runs.append(torch.stack([bb(xs[t]).clone() for t in range(xs.shape[0])]))
+            assert any(taken) == on, (on, taken)
+    n.gated_linear = orig
+    assert torch.isfinite(runs[0]).all() and torch.equal(runs[0], runs[1]), "projection from the A.v state differs"
     print("BIG_TILES_OK")
 
 
