@@ -11,7 +11,7 @@ NAMES = ["gated_linear_split_kernel<0", "gated_linear_split_kernel<1", "gated_li
 
 
 BIG = re.compile(r"gated_linear_split_big_kernel<(\d), 256, (\d+), \d, \d, \d, (\d)>")
-FMT = {"0": "fp32", "1": "presplit_A", "2": "hl32_out"}
+FMT = {"0": "fp32", "1": "presplit_A", "2": "hl32_out", "4": "bf16_A"}
 
 
 def key(n):
