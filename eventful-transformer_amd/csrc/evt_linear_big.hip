@@ -1,18 +1,22 @@
 // evt_linear_big.hip -- K3/K7, split-precision gated linear for launches that fill the chip: 256-row workgroup tiles.
 //
-// Why a second kernel.  Ablations of the 128x128 kernel (evt_linear.hip, EVT_ABLATE builds, B = 256 clips) showed that its
-// matrix pipe is starved by the operand path, not by instruction issue: MFMAs alone run the K = 3072 product in 240 us, the
-// load path alone (global loads + split + LDS staging, no MFMA) takes 299 us, both together 442 us, and dropping only the
-// in-loop global loads gives back 25 %.  A 128x128 tile moves 1024 operand bytes through L2 -> CU per k for 32768 FLOP
-// (32 FLOP/B); at 340 TF that is ~11 TB/s of L2 reads for A and W tiles, every workgroup waiting ~1.5 us per k-tile for them.
-// This kernel halves the bytes per FLOP (256x256: 64 FLOP/B; 256x128: 43) and hides what is left behind a full k-tile:
+// Why a second kernel.  Ablations of the 128x128 kernel (evt_linear.hip, EVT_ABLATE builds, B = 256 clips): MFMAs alone run
+// the K = 3072 product in 240 us, the load path alone (global loads + split + LDS staging, no MFMA) takes 299 us, both together
+// 442 us, and dropping only the in-loop global loads gives back 25 %.  A 128x128 tile moves 1024 operand bytes through
+// L2 -> CU per k for 32768 FLOP (32 FLOP/B): ~11 TB/s of L2 reads at 340 TF.  This kernel halves the bytes per FLOP (256x256:
+// 64 FLOP/B; 256x192: 55) and the per-element staging work (each activation is converted for half as many column tiles):
 //
-//   * one workgroup per CU, 8 waves (4 x 2): 64x128 per wave (2x4 accumulators of 32x32) for 256x256, 64x64 for 256x128;
+//   * ONE persistent workgroup per CU, 8 waves (4 x 2): 64x128 per wave (2x4 accumulators of 32x32) for 256x256, 64x96 for
+//     256x192; the workgroups of an XCD walk a contiguous run of tiles side by side;
 //   * TWO LDS stages of hi/lo bf16 tiles (128 KB for 256x256), ONE barrier per k-tile: k-tile t+1 is split and written into
-//     the other stage while k-tile t is multiplied; the global loads of k-tile t+2 are in flight meanwhile;
+//     the other stage while k-tile t is multiplied; the global loads of k-tile t+2 are in flight meanwhile; the k-tile stream
+//     does not stop at a tile boundary (the next tile's loads are in flight while a finished tile is stored);
 //   * the waves of a SIMD are dealt into two groups that run the two halves of an iteration in opposite order (group 0:
-//     stage, then multiply; group 1: multiply, then stage): right after the barrier half of the waves feed the matrix pipe
-//     while the other half convert and store, instead of all sixteen converting at once with the pipe idle.
+//     stage, then multiply; group 1: multiply, then stage).  With fp32 activations this measured neutral (the staging segment
+//     is longer than a multiply); with pre-split activations it becomes a two-barrier ping-pong (PP below).
+//
+// What the in-kernel phase profile (-DEVT_PROF, scripts/gemm_prof.py) says is left: the loads are not waited for; the kernel
+// is issue-bound (~250 non-MFMA instructions per wave and k-tile beside 36-48 MFMAs).  DESIGN.md section 6.
 //
 // Operands, arithmetic, gather / scatter / p refresh / epilogue are those of gated_linear_split_kernel: results are
 // bitwise the same (the k order inside a tile and the accumulation order over tiles do not change).
