@@ -711,8 +711,7 @@ extern "C" int evt_softmax_gate(const evt_softmax_desc* d, void* stream) {
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t s = evt_stream(stream);
   EVT_DISPATCH_STORE(d->store, T, {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_gate_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    EVT_ALLOW_LDS(softmax_gate_kernel<T>, lds);
     hipLaunchKernelGGL(softmax_gate_kernel<T>, grid, block, lds, s, a);
   });
   return evt_check_launch("evt_softmax_gate");

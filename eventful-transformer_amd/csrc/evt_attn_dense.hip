@@ -422,8 +422,7 @@ int launch_dense(const DenseArgs& a, void* stream) {
   const size_t lds = ((size_t)KC * QP + (size_t)dense_tile_floats(a.N) + (size_t)AR * (a.gh + a.gw) + a.N) * sizeof(float);
   const dim3 grid((a.N + AR - 1) / AR, a.G * a.H);
   if (grid.y == 0) return EVT_OK;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EVT_ALLOW_LDS(attn_dense_kernel<T>, lds);
   hipLaunchKernelGGL(attn_dense_kernel<T>, grid, dim3(256), lds, evt_stream(stream), a);
   return evt_check_launch("evt_attention_dense");
 }

@@ -750,9 +750,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 
 template <typename T, int TPW, int NREG, int QK = 0>
 void launch_fused_inst(const FusedArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_av_gated_kernel<T, TPW, NREG, QK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EVT_ALLOW_LDS((softmax_av_gated_kernel<T, TPW, NREG, QK>), lds);
   hipLaunchKernelGGL((softmax_av_gated_kernel<T, TPW, NREG, QK>), grid, dim3(256), lds, s, a);
 }
 
@@ -896,8 +894,7 @@ extern "C" int evt_rel_terms(const float* qkv, const float* rel_y, const float* 
   const size_t lds = (size_t)(std::max(qw, qh) + std::max(gh, gw)) * 68 * sizeof(float);
   EVT_REQUIRE(lds <= 160 * 1024, EVT_ERR_BAD_SHAPE, "evt_rel_terms: grid %dx%d too large", qh, qw);
   if (B == 0) return EVT_OK;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rel_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EVT_ALLOW_LDS(rel_terms_kernel, lds);
   hipLaunchKernelGGL(rel_terms_kernel, dim3(qh + qw, B * H), dim3(256), lds, evt_stream(stream), qkv, rel_y, rel_x, H, N, D, gh, gw,
                      qw, terms);
   return evt_check_launch("evt_rel_terms");

@@ -23,6 +23,25 @@ int evt_check_launch(const char* what);
 
 static inline hipStream_t evt_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-DEVICE host caches (one process may drive several GPUs; hipFuncSetAttribute applies to the current device only).
+constexpr int EVT_MAX_DEVICES = 64;
+static inline int evt_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < EVT_MAX_DEVICES ? dev : 0;
+}
+// Raises a kernel's dynamic-LDS limit to `bytes` when that exceeds what this call site has already set on the current
+// device (one static table per call site = per kernel instantiation): no runtime call on the launch path afterwards.
+#define EVT_ALLOW_LDS(kernel, bytes)                                                                            \
+  do {                                                                                                           \
+    static int evt_lds_set_[EVT_MAX_DEVICES] = {0};                                                              \
+    const int evt_dev_ = evt_current_device();                                                                   \
+    if ((int)(bytes) > 64 * 1024 && evt_lds_set_[evt_dev_] < (int)(bytes)) {                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      evt_lds_set_[evt_dev_] = (int)(bytes);                                                                     \
+    }                                                                                                            \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // device side
 // ---------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // product that feeds it): 6 FMAs, 4 squarings, one reciprocal, no branches, about a third of the instructions of the device
 // library's erff.  The epilogue of the 256-row kernel is not hidden behind other workgroups' MFMAs: with erff the MLP-1
 // launch spent a quarter of its time there (474 -> 454 us at B = 256 with this form).  -DEVT_EXACT_ERF builds the erff form.
+// Used by the split-precision kernels only; the fp32-MFMA kernel calls gelu_erf_exact below.
 __device__ __forceinline__ float gelu_erf(float x) {
 #ifndef EVT_EXACT_ERF
   const float z = fabsf(x) * 0.70710678118654752440f;
@@ -48,6 +49,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 #endif
 }
+// The exact-fp32 arithmetic mode (EVT_GEMM=f32: gated_linear_kernel, v_mfma_f32_32x32x2_f32) keeps the reference's GELU, erff.
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ---------------------------------------------------------------------------------------------
 // Split weights, "hl32" layout (evt_split_weights): every fp32 weight w is written w = hi + lo + O(2^-17 |w|) with

@@ -500,25 +500,21 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
 #endif
 }
 
-int cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+int cu_count() {   // per device: one process may drive several GPUs
+  static int cus[EVT_MAX_DEVICES] = {0};
+  const int dev = evt_current_device();
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
   }
-  return cus;
+  return cus[dev];
 }
 
 template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
 void launch_big_one(const LinArgs& a, hipStream_t s, dim3 grid, int tiles_n, int tiles_total) {
   constexpr size_t lds_bytes = (size_t)2 * (2 * TBM * 32 + 2 * TBN * 32 + 32 + ((FMT & 1) ? 32 : 0)) * 2 + (size_t)2 * TBM * 4 + (size_t)2 * TBN * 4;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gated_linear_split_big_kernel<ACT, TBM, TBN, WM, WN, DEPTH, FMT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
-  }
+  EVT_ALLOW_LDS((gated_linear_split_big_kernel<ACT, TBM, TBN, WM, WN, DEPTH, FMT>), lds_bytes);   // once per instantiation and device
   hipLaunchKernelGGL((gated_linear_split_big_kernel<ACT, TBM, TBN, WM, WN, DEPTH, FMT>), grid, dim3(WM * WN * 64), lds_bytes, s, a, tiles_n,
                      tiles_total);
 }
@@ -547,7 +543,9 @@ int evt_big_choice(const LinArgs& a) {
   // which skips dead tiles)
   if (mode == 0 || a.Wsplit == nullptr || (a.K & 31) != 0 || a.K < 64 || a.count != nullptr) return 0;
   // 32-bit byte offsets inside the kernel: activations (and the gate reference, same shape), weight planes and output below 4 GB
-  if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) ||   // (also bounds the fp32 gate reference of a bf16 launch) (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
+  // (the activation bound is taken at 4 bytes per element also for a bf16 launch: it then covers the fp32 gate reference)
+  if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) ||
+      (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
       (int64_t)a.B * a.o_rows * a.ldo * 4 >= ((int64_t)1 << 32))
     return 0;
   if (mode >= 2 && mode <= 4) return mode;

@@ -2,11 +2,14 @@
 //
 // One 256-thread workgroup per clip.  The clip's norms are staged once in LDS as order-preserving
 // uint keys; the k-th largest key is found by a 4-pass 8-bit radix select (LDS histograms, 16 private copies per bin
-// so that the norms of a clip -- which share their exponent byte -- do not serialise on one LDS atomic); the
-// selected tokens are then emitted in ASCENDING index order by wavefront-ballot compaction:
-// per 256-token round each wave ranks its lanes with a 64-bit ballot + popcount of the lower
-// lanes, and the 4 per-wave counts are combined through LDS.  Ties at the k-th key are resolved
-// to the lowest token index.  The variable count of the threshold policy stays on the device.
+// so that the norms of a clip -- which share their exponent byte -- do not serialise on one LDS atomic).  The
+// selected tokens are then emitted in ASCENDING index order by a single-pass ordered compaction: every thread owns
+// a contiguous chunk of tokens, counts its keys above / equal to the k-th key, an exclusive scan over the workgroup
+// (`__shfl_up` wave scan + four wave totals through LDS, one barrier) gives the counts in front of the chunk, and the
+// thread writes its selected tokens at their final positions.  (This replaced the round-1 wavefront-ballot
+// compaction -- ballot + popcount per 256-token round, three barriers per round, 21 of them at N = 1764; the
+// north_star names ballot compaction, the chunk scan does the same job with one barrier.)  Ties at the k-th key are
+// resolved to the lowest token index.  The variable count of the threshold policy stays on the device.
 #include "evt_common.h"
 
 namespace {
@@ -156,8 +159,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
                   int32_t* rest, void* stream, int parts = 0) {
   const size_t lds = (size_t)(N + 256 + SEL_COPIES * 256 + 8 + 4) * sizeof(uint32_t);
-  if (lds > 64 * 1024)  // N near SEL_MAX_N: above the 64 KB default dynamic-LDS limit
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  EVT_ALLOW_LDS(select_kernel, lds);   // N near SEL_MAX_N: above the 64 KB default dynamic-LDS limit (set once per device)
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), lds, evt_stream(stream), norms, N, k, thr, mode, kcap,
                      idx, count, rest, parts);
   return evt_check_launch("evt_select");

@@ -33,20 +33,33 @@ class ViTBackbone(ExtendedModule):
         x = self.position_encoding(x)
         # Between consecutive eventful blocks the residual stream travels as an unevaluated sum (blocks.PendingSum): the
         # next block's first row pass performs the add together with its LayerNorm + delta norm.  Same arithmetic, one
-        # launch and one HBM round trip of the stream less per block boundary.  Blocks are still invoked through
-        # __call__ (forward hooks keep working); callers of the backbone only ever see tensors.
+        # launch and one HBM round trip of the stream less per block boundary.  A PendingSum never reaches user code:
+        # a block boundary is only chained when neither side (nor the container, nor torch's global registry) carries a
+        # forward / pre-forward hook -- hooked blocks take and return plain tensors, and a hooked `blocks` container is
+        # invoked as the nn.Sequential it is.
+        if not CHAIN_BLOCKS or _hooked(self.blocks):
+            return self.blocks(x)
         mods = list(self.blocks)
         for i, blk in enumerate(mods):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if CHAIN_BLOCKS and _chains(blk) and nxt is not None and _chains(nxt):
-                blk._defer_output = True
-            x = blk(x)
+            if nxt is not None and _chains(blk) and _chains(nxt):
+                x = blk(x, _defer_output=True)
+            else:
+                x = blk(x)
         return x.materialize() if isinstance(x, blocks.PendingSum) else x
 
 
 CHAIN_BLOCKS = os.environ.get("EVT_CHAIN_BLOCKS", "1") != "0"
 
 
+def _hooked(module):
+    """True when a forward or pre-forward hook would observe this module's call (its own or a global one)."""
+    from torch.nn.modules import module as _m
+
+    return bool(module._forward_hooks or module._forward_pre_hooks or _m._global_forward_hooks
+                or _m._global_forward_pre_hooks)
+
+
 def _chains(blk):
-    """Blocks that can pass / take a pending residual sum: the eventful classes without adaptive token sampling."""
-    return isinstance(blk, blocks.EventfulTokenwiseBlock) and blk.ats_fraction is None
+    """Blocks that can pass / take a pending residual sum: un-hooked eventful classes without adaptive token sampling."""
+    return isinstance(blk, blocks.EventfulTokenwiseBlock) and blk.ats_fraction is None and not _hooked(blk)

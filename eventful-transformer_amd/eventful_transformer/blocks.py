@@ -56,6 +56,10 @@ QK_FULL_RATIO = 0.7
 FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
 PROJ_FROM_STATE = os.environ.get("EVT_PROJ_FROM_STATE", "1") != "0"   # bf16 cast: projection reads the A.v state, no fp32 attention output
 REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
+# Diagnostic tap: a callable (block, gate tag, idx (B,cap) int32, count or None) invoked after every fused gate selection
+# with the DEVICE index list (scratch memory: clone to keep).  bench.py's self-check records the timed run's index sets
+# through it -- unlike forward hooks it leaves the launch sequence (block chaining included) untouched.
+INDEX_TAP = None
 
 
 class PendingSum:
@@ -404,6 +408,8 @@ class EventfulTokenwiseBlock(Block):
             rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
             self._rest = rest if tag == "qkv" else self._rest
             policy.select_into(norms, B, N, idx, count, rest, parts=parts)
+            if INDEX_TAP is not None:
+                INDEX_TAP(self, tag, idx, count)
             return idx, count, cap
         # Any other callable gets the delta tensor like in the reference (modules.py:149).
         index = policy(c - gate.p, dim=-1)
@@ -420,9 +426,12 @@ class EventfulTokenwiseBlock(Block):
         """Gated row total for MAC accounting (one readback, counting mode only)."""
         return B * cap if count is None else int(count.sum().item())
 
-    def _group(self, gate, buffer, src, res, ln, linear_fn, out_features, tag, sum_out=None, count_res=True):
+    def _group(self, gate, buffer, src, res, ln, linear_fn, out_features, tag, sum_out=None, count_res=True,
+               norm_parts=None, state_src=None):
         """Generic gate group.  src (+res) -> [LN] -> gate -> linear_fn on gated rows -> buffer rows.
 
+        norm_parts / state_src (projection group only): what the fused attention kernel of THIS forward call handed over
+        -- ((B,N,parts) partial squares of ||src - p||, parts) and the bf16 A.v state standing in for an unwritten `src`.
         Returns (buffer state, idx, count, cap); idx is None on the first frame of a clip."""
         B, N, D = src.shape
         rows = B * N
@@ -467,11 +476,9 @@ class EventfulTokenwiseBlock(Block):
             src16 = None
             if ln is None and res is None:
                 c = src  # the gate input already exists in HBM: only the norms are new
-                ready, self._norm_parts_ready = getattr(self, "_norm_parts_ready", None), None
-                if tag == "projection":
-                    src16, self._proj_state_src = getattr(self, "_proj_state_src", None), None
-                if ready is not None and tag == "projection":
-                    norms, parts = ready   # ||src - p||^2 per head came out of the fused attention epilogue
+                src16 = state_src
+                if norm_parts is not None:
+                    norms, parts = norm_parts   # ||src - p||^2 per head came out of the fused attention epilogue
                 else:
                     _native.row_pass(src, rows, D, p=gate.p, norms=norms)
             else:
@@ -516,12 +523,15 @@ class EventfulTokenwiseBlock(Block):
         return self._group(self.qkv_gate, self.qkv_accumulator, x, res, 1, self._linear_fn(self.qkv), 3 * self.dim,
                            "qkv", sum_out=sum_out, count_res=False)
 
-    def _forward_post_attention(self, attn, skip, defer=False):
+    def _forward_post_attention(self, attn, skip, defer=False, fused=None):
         """projection group, +skip, LN2, mlp group, +skip (blocks.py:430-450).  defer: leave the last add to the
-        next block's first row pass (returns a PendingSum)."""
+        next block's first row pass (returns a PendingSum).  fused: hand-over of the fused attention kernel
+        (`norm_parts`, `state_src`; see _group), valid for this call only."""
         B, N, D = attn.shape
+        fused = fused or {}
         proj, _, _, _ = self._group(self.projection_gate, self.projection_accumulator, attn, None, None,
-                                    self._linear_fn(self.projection), D, "projection")
+                                    self._linear_fn(self.projection), D, "projection",
+                                    norm_parts=fused.get("norm_parts"), state_src=fused.get("state_src"))
         x2 = self._ws("x_mid", (B, N, D), torch.float32, attn)
         mlp, _, _, _ = self._group(self.mlp_gate, self.mlp_accumulator, proj, skip, 2, self._mlp_fn, D, "mlp",
                                    sum_out=x2)
@@ -533,13 +543,14 @@ class EventfulTokenwiseBlock(Block):
         return out
 
     def _forward_attention(self, qkv, idx, count, cap, B, N):
-        """-> (attention output, ATS indices or None)"""
+        """-> (attention output, ATS indices or None, fused hand-over dict or None)"""
         attn = self._ws("attn_out", (B, N, self.dim), torch.float32, qkv)
         ats = self._attention_dense(qkv, B, N, attn)
-        return ats if ats is not None else (attn, None)
+        return (ats[0], ats[1], None) if ats is not None else (attn, None, None)
 
-    def forward(self, x):
-        defer, self._defer_output = getattr(self, "_defer_output", False), False   # set by ViTBackbone, one call only
+    def forward(self, x, _defer_output=False):
+        """_defer_output (ViTBackbone only, never with hooks registered): return the block output as a PendingSum."""
+        defer = _defer_output
         if isinstance(x, PendingSum):
             B, N, D = x.shape
             xin = self._ws("x_in", (B, N, D), torch.float32, x.src)
@@ -549,9 +560,9 @@ class EventfulTokenwiseBlock(Block):
             x = self._check_input(x)
             B, N, _ = x.shape
             qkv, idx, count, cap = self._forward_pre_attention(x)
-        attn, ats_index = self._forward_attention(qkv, idx, count, cap, B, N)
+        attn, ats_index, fused = self._forward_attention(qkv, idx, count, cap, B, N)
         skip = x if ats_index is None else self._ats_rows(x, ats_index)   # blocks.py:426,493
-        return self._forward_post_attention(attn, skip, defer=defer and ats_index is None)
+        return self._forward_post_attention(attn, skip, defer=defer and ats_index is None, fused=fused)
 
 
 class EventfulMatmul1Block(EventfulTokenwiseBlock):
@@ -644,12 +655,12 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         store = _native.store_code(sdt)
         if self.ats_fraction is not None:
             product = self._scores(qkv, idx, count, cap, B, N)[0]
-            return self._ats_attention(product, qkv, B, N, eventful=False)
+            return self._ats_attention(product, qkv, B, N, eventful=False) + (None,)
         if idx is None:
             attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
             if self._first_frame_fused(qkv, B, N, attn):
                 self.matmul.count_product(B * H * N * (D // H), N)
-                return attn, None
+                return attn, None, None
         product, kv, Nk, _, _, _ = self._scores(qkv, idx, count, cap, B, N)
         ry, rx, gh, gw, qw = self._rel_tables()
         a_s = self._ws("attn_probs", (B, H, N, Nk), sdt, qkv)
@@ -659,7 +670,7 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
         _native.av(a_s, v_s, Nk, B, H, N, Nk, D, store, out_f32=attn)
         self.matmul.count_product(B * H * N * (D // H), Nk)
-        return attn, None
+        return attn, None, None
 
 
 class EventfulBlock(EventfulMatmul1Block):
@@ -684,7 +695,7 @@ class EventfulBlock(EventfulMatmul1Block):
                                           "count for the whole batch (and ATS needs batch == heads > 1)")
             product = self._scores(qkv, idx, count, cap, B, N)[0]
             self._ats_idx_k = None if idx is None else idx.long()
-            return self._ats_attention(product, qkv, B, N, eventful=True)
+            return self._ats_attention(product, qkv, B, N, eventful=True) + (None,)
         if acc.first and idx is None and self.matmul_accumulator_1.first:
             a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
             pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
@@ -696,7 +707,7 @@ class EventfulBlock(EventfulMatmul1Block):
                 acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
                 self._v_full(qkv, None, B, N, N, vg._state, store)
                 acc.matmul.count_product(B * H * N * dh, N)
-                return attn, None
+                return attn, None, None
         acc1 = self.matmul_accumulator_1
         in_kernel_qk = (not acc.first and not acc1.first and self.pool_size is None and
                         _native.fused_qk_fits(N, N, D, H, cap))
@@ -729,7 +740,8 @@ class EventfulBlock(EventfulMatmul1Block):
             self._v_full(qkv, kv, B, N, Nk, vg._state, store)
             _native.av(ag.p, vg._state, Nk, B, H, N, Nk, D, store, pv=acc._state, out_f32=attn)
             acc.matmul.count_product(B * H * N * dh, Nk)
-            return attn, None
+            return attn, None, None
+        fused = None
         if dh in (64, 128):
             # K6a with k-contiguous outputs + fused K5/K6: a~ / da~ stay in LDS
             v_delta = self._ws("v_delta_t", (B, D, cap_k), sdt, qkv)
@@ -759,8 +771,8 @@ class EventfulBlock(EventfulMatmul1Block):
                                      None if state_src else attn, B, H, N, D,
                                      store, Nk=Nk, scale=self.scale, norm_ref=pg.p if fuse_norm else None,
                                      norm_parts=nparts, rel_terms=terms, **rel)
-            self._norm_parts_ready = (nparts, H) if fuse_norm else None
-            self._proj_state_src = acc._state if state_src else None   # consumed by the projection group (`attn` is unwritten)
+            # handed to the projection group of this call (with `state_src` the fp32 `attn` scratch is NOT written)
+            fused = dict(norm_parts=(nparts, H) if fuse_norm else None, state_src=acc._state if state_src else None)
         else:
             a_new = self._ws("a_new", (B, H, N, cap_k), sdt, qkv)
             a_delta = self._ws("a_delta", (B, H, N, cap_k), sdt, qkv)
@@ -778,7 +790,7 @@ class EventfulBlock(EventfulMatmul1Block):
             if acc.count_mode:
                 acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
             acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
-        return attn, None
+        return attn, None, fused
 
     def reset_self(self):
         super().reset_self()

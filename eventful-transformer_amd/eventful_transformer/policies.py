@@ -1,7 +1,7 @@
 """Token-selection policies (API of the reference's policies.py).
 
 A policy maps a tensor of per-token deltas to the indices of the tokens to recompute.  Here the
-L2 norm is one row pass (K1a) and the selection is the LDS radix-select / wavefront-ballot
+L2 norm is one row pass (K1a) and the selection is the LDS radix-select / ordered chunk-scan
 compaction kernel (K1).  Indices come back int64 and ASCENDING -- a documented tightening of the
 reference, whose `topk(sorted=False)` order is implementation-defined (policies.py:63); ties at
 the k-th norm go to the lowest token index.

@@ -78,7 +78,7 @@ EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* 
 
 /* ------------------------------------------------------------------------------------------ *
  * K1  Token selection from per-token delta norms.  One workgroup per clip; norms staged in LDS;
- *     radix select of the k-th largest key, then wavefront-ballot compaction in index order.
+ *     radix select of the k-th largest key, then a single-pass ordered compaction (per-thread chunk counts + workgroup scan) in index order.
  *
  * evt_select_topk: idx[b, 0..k) = the k tokens with the largest norms, ASCENDING; ties at the
  *   k-th value go to the LOWEST index.  Replaces `vector_norm(...).topk(k, sorted=False)[1]`
