@@ -1,0 +1,790 @@
+// evt_attn_stream.hip -- attention of EventfulBlock for LARGE token counts (N > 256: the global blocks of ViTDet,
+// N = 1764 / 4096), scores computed in the kernel.  One launch per frame and block:
+//
+//   gated frame   softmax statistics of all N columns + [rel-pos]                    blocks.py:518-522
+//                 -> the k selected columns: a~, da~ = a~ - p[:, idx], p[:, idx] = a~  modules.py:187-201 ("col")
+//                 -> state += round(a~ . dv~); state += round(da~ . v_old), heads merged modules.py:285-295
+//   first frame   a = round(softmax(..)) -> matmul_gate reference p; state = out = round(a . round(v))
+//                                                                                     modules.py:183-185, 277-283
+//
+// Why a second fused kernel.  For these shapes evt_softmax_av_gated read the (B,H,N,N) fp32 q.k^T state once per frame
+// (149 MB per block at 672^2, 805 MB at 1024^2) after evt_qk had patched its k rows and k columns (86 MB of scattered
+// writes at 672^2), and gathered / scattered the gate reference p with one 4-byte (2-byte) access per element at a
+// stride of a whole state row: one video stream spent 193 us (672^2) / 824 us (1024^2) per global block in evt_qk +
+// evt_softmax_av_gated.  Here
+//   * the scores are never stored: a workgroup (32 or 48 query rows) recomputes (q / scale) k^T for its rows against all N keys on
+//     the matrix cores, straight from the token buffer (q and k go from L2 into MFMA fragments, bf16 hi/lo split
+//     products like evt_qk, or exact fp32 products with qk_split = 0), keeping only running (max, sum) pairs -- 2 N^2 D
+//     FLOP per block (14 GFLOP of bf16 MFMA work at 672^2: microseconds) instead of the state traffic, and the q.k^T
+//     state, evt_qk and the state's memory (4 x 149 MB / 4 x 805 MB per stream) disappear;
+//   * the scores of the k selected columns are then computed once more (k x 64 key rows gathered through idx);
+//   * the gate reference is kept TRANSPOSED, (B,H,Nk,N): the rows of a workgroup are contiguous bytes of a selected
+//     column (16 lanes read / rewrite 16 consecutive rows of one column).
+// Score layout.  The key rows are the A operand and the query rows the B operand of v_mfma_f32_16x16x32_bf16, so a lane
+// holds, of ONE query row, the scores of 4 consecutive keys per tile: the online softmax rescales once per 4 scores (one
+// exponential per score + one per group; a lane owning 8 different rows paid a rescale per score), keeps (max, sum) of
+// 2-4 rows instead of 8, and the cross-lane combine is two shuffle steps.  In-kernel phase timing (scripts/
+// onestream_bench.py, -DEVT_PROF) of the row-per-lane-group version: 49 % of a workgroup's life in the statistics pass at
+// 1700 cycles per 64-key chunk and wave.
+// Tile height.  672 workgroups of 32 rows on 512 slots (2 per CU) run in 1.31 rounds, i.e. the time of two: the launcher
+// picks 32 or 48 rows (NHR = 2, 3 MFMA row groups of 16) minimising rounds x per-workgroup cost; 1764 tokens x 12
+// heads: 48 rows = 444 workgroups = one round.
+// The A.v part (LDS tiles of a~ / da~, both products on the matrix cores, state read-modify-write epilogue, per-head
+// partial ||out - ref||^2 for the projection gate) is that of evt_softmax_av_gated; every rounding point of the reference
+// is kept.  Head dim 64, N % 4 == 0, un-pooled keys.
+#include "evt_attn_tiles.h"
+#include <algorithm>
+#include <stdlib.h>
+
+namespace {
+
+struct StreamArgs {
+  const float* qkv; const float* rel_terms;
+  void* a_state_t; const int32_t* idx; const int32_t* count;
+  const void* v_delta_t; const void* v_old_t; const void* v_state; void* pv; float* out_f32;
+  const float* norm_ref; float* norm_parts;
+  int B, H, N, D, kcap, gh, gw;
+  float scale;
+};
+
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+
+#ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/onestream_bench.py with a -DEVT_PROF build)
+__device__ unsigned long long evt_prof_stream_buf[16];
+#define STR_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
+#else
+#define STR_TICK(slot) do { } while (0)
+#endif
+
+// four consecutive elements of the store type as ONE LDS access (4 selected columns of a row of the a~ / da~ tiles)
+template <typename T> struct Quad { union { uint2 v; T t[4]; }; };
+template <> struct Quad<float> { union { float4 v; float t[4]; }; };
+
+constexpr int SDH = 64;   // head dim
+
+// 16 rows x 16 channels += A-tile rows (16 x k) . V^T-tile rows (16 channels x k) over the k range [KB, KB + KLEN) of a chunk.
+// a: first element of this lane's tile row (row l15 of the group), b: of this lane's channel row; kg = lane >> 4.
+template <typename T> struct Sweep16;
+template <> struct Sweep16<bf16_t> {
+  template <int KB, int KLEN>
+  static __device__ __forceinline__ f32x4_acc run(const bf16_t* a, const bf16_t* b, int kg, f32x4_acc acc) {
+#pragma unroll
+    for (int kk = KB; kk < KB + KLEN; kk += 32) {
+      const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(a + kk + 8 * kg);
+      const bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(b + kk + 8 * kg);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct Sweep16<f16_t> {
+  template <int KB, int KLEN>
+  static __device__ __forceinline__ f32x4_acc run(const f16_t* a, const f16_t* b, int kg, f32x4_acc acc) {
+#pragma unroll
+    for (int kk = KB; kk < KB + KLEN; kk += 32) {
+      const f16x8_t fa = *reinterpret_cast<const f16x8_t*>(a + kk + 8 * kg);
+      const f16x8_t fb = *reinterpret_cast<const f16x8_t*>(b + kk + 8 * kg);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+template <> struct Sweep16<float> {
+  template <int KB, int KLEN>   // permuted k: lane group kg covers [KB + kg * KLEN / 4, + KLEN / 4)
+  static __device__ __forceinline__ f32x4_acc run(const float* a, const float* b, int kg, f32x4_acc acc) {
+#pragma unroll
+    for (int q = 0; q < KLEN / 4; q += 4) {
+      const float4 fa = *reinterpret_cast<const float4*>(a + KB + kg * (KLEN / 4) + q);
+      const float4 fb = *reinterpret_cast<const float4*>(b + KB + kg * (KLEN / 4) + q);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+// QK: 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = q, k as bf16 hi + lo (three v_mfma_f32_16x16x32_bf16 per
+// product, ~1e-5 relative; the arithmetic of evt_qk's split mode).  FIRST: first frame of a clip (see the header).
+// NHR: MFMA row groups of 16 query rows per workgroup (tile height 16 NHR).
+template <typename T, bool FIRST, int QK, int NHR>
+__global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a, int tiles_x, int tiles_total) {
+  constexpr int P = Tile<T>::PITCH, FRT = 16 * NHR;
+  static_assert((size_t)2 * FRT * SDH * sizeof(float) <= (size_t)(2 * FRT + 2 * SDH) * P * sizeof(T), "the epilogue tiles alias the chunk tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char stream_smem[];
+  T* An = reinterpret_cast<T*>(stream_smem);            // [FRT][P] a~ (first frame: a) of the chunk
+  T* Ad = An + FRT * P;                                 // [FRT][P] da~
+  T* Vd = Ad + FRT * P;                                 // [64][P]  dv~^T (first frame: v^T) of the chunk
+  T* Vo = Vd + SDH * P;                                 // [64][P]  v_old^T
+  const int nrel = a.gh + a.gw, RP = nrel | 1;          // odd pitch: the 16 rows of a lane group hit different banks
+  float* relv = reinterpret_cast<float*>(Vo + SDH * P); // [FRT][RP] rel-pos terms of the tile's rows
+  float* wst = relv + FRT * RP;                         // [4][FRT][2] per-wave (max, sum) of each row
+  float* fin = wst + 4 * FRT * 2;                       // [FRT][2] row max, 1 / row sum
+  float* red1 = reinterpret_cast<float*>(stream_smem);  // [FRT][64] epilogue (the chunk tiles are idle then)
+  float* red2 = red1 + FRT * SDH;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware placement (workgroup w runs on XCD w % 8): each XCD owns a contiguous run of (head, row tile) pairs, so
+  // the K rows of one head are fetched into one or two private L2s instead of all eight.
+  int t;
+  {
+    const int w = blockIdx.x, x = w & 7, sidx = w >> 3, q8 = tiles_total / 8, r8 = tiles_total % 8;
+    t = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + sidx;
+  }
+  const int bh = t / tiles_x, tile_x = t - bh * tiles_x;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int i0 = tile_x * FRT;
+#ifdef EVT_PROF
+  const bool prof_on = blockIdx.x == 100 && wave == 0;
+  unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
+  const bool rel = a.rel_terms != nullptr;
+  const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int64_t rs = 3 * (int64_t)a.D;
+  const float* clip = a.qkv + (int64_t)b * a.N * rs;
+  T* stT = reinterpret_cast<T*>(a.a_state_t) + (int64_t)bh * a.N * a.N;   // [key j][row i]
+
+  // channel of float4 piece p (0..3) of this lane (see evt_attn_fused.hip): QK == 1, 16x16x4 fp32 tiles with k
+  // permuted, 16 contiguous channels 16 kg + 4 p; QK == 2, 16x16x32 bf16 tiles, k-block p >> 1 holds 32 (p >> 1) + 8 kg .. + 8
+  auto chan = [&](int p_) __attribute__((always_inline)) { return QK == 1 ? 16 * kg + 4 * p_ : 32 * (p_ >> 1) + 8 * kg + 4 * (p_ & 1); };
+  auto split8 = [&](const float4 u, const float4 v, bf16x8_t* hi, bf16x8_t* lo) __attribute__((always_inline)) {
+    bf16x4_t h0, l0, h1, l1;
+    split4(u, &h0, &l0);
+    split4(v, &h1, &l1);
+    *hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  // ---- q rows of the tile -> MFMA fragments (kept for both passes); rel-pos terms -> LDS -------------------------
+  float4 qf[NHR][4];
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) {
+    const int i = i0 + hr * 16 + l15;
+    const float* qp = clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * SDH;
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qp + chan(p_));
+  }
+  auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps) -> 4 pieces
+    const float* kp = clip + (int64_t)j * rs + a.D + h * SDH;
+#pragma unroll
+    for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
+  };
+  float4 kA[4], kB[4];
+  {
+    const int j0 = wave * 16 + l15;
+    load_kf(j0 < a.N ? j0 : a.N - 1, kA);
+    load_kf(64 + j0 < a.N ? 64 + j0 : a.N - 1, kB);
+  }
+  if (rel) {
+    // the tile's rows are contiguous in rel_terms: a flat copy, 8 loads in flight per thread before the first LDS store
+    // (a loop of load -> store pairs is 16-24 serialised round trips: 12 us of a 60 us workgroup)
+    const float* src = a.rel_terms + ((int64_t)bh * a.N + i0) * nrel;
+    const int total = min(FRT, a.N - i0) * nrel;
+    const float inv_nrel = 1.0f / (float)nrel;
+    for (int e0 = 0; e0 < total; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + tid + 256 * u; v[u] = src[e < total ? e : total - 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + tid + 256 * u;
+        if (e < total) { const int r = fast_div(e, inv_nrel); relv[r * RP + (e - r * nrel)] = v[u]; }
+      }
+    }
+  }
+  {
+    const float inv = 1.0f / a.scale;
+    const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) {   // q / self.scale (blocks.py:514); a power-of-two scale: exact multiply
+        float4 q = qf[hr][p_];
+        if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
+        else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
+        qf[hr][p_] = q;
+      }
+  }
+  bf16x8_t qh[NHR][2], ql[NHR][2];
+  if (QK == 2) {
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) split8(qf[hr][2 * m], qf[hr][2 * m + 1], &qh[hr][m], &ql[hr][m]);
+  }
+  // k (q / scale)^T: the 16 keys whose fragments are in kf against the tile's rows.  Keys are the A operand: sacc[hr][r] is
+  // the score of query row 16 hr + l15 and key 4 kg + r of the 16.
+  auto scores = [&](const float4* kf, f32x4_acc* sacc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) sacc[hr] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+    if (QK == 1) {
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+        for (int hr = 0; hr < NHR; ++hr) {
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].x, qf[hr][p_].x, sacc[hr], 0, 0, 0);
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].y, qf[hr][p_].y, sacc[hr], 0, 0, 0);
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].z, qf[hr][p_].z, sacc[hr], 0, 0, 0);
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].w, qf[hr][p_].w, sacc[hr], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        bf16x8_t kh, kl;
+        split8(kf[2 * m], kf[2 * m + 1], &kh, &kl);
+#pragma unroll
+        for (int hr = 0; hr < NHR; ++hr) {
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[hr][m], sacc[hr], 0, 0, 0);
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[hr][m], sacc[hr], 0, 0, 0);
+          sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[hr][m], sacc[hr], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // + rel-pos terms of the lane's 4 keys js[0..3] (valid key indices), in the reference's order (x + ty) + tx (utils.py:166-172)
+  auto with_rel = [&](f32x4_acc* sacc, const int* js) __attribute__((always_inline)) {
+    if (!rel) return;
+    int oy[4], ox[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ky = fast_div(js[r], inv_gw);
+      oy[r] = ky;
+      ox[r] = a.gh + js[r] - ky * a.gw;
+    }
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      const float* rv = relv + (16 * hr + l15) * RP;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[hr][r] = (sacc[hr][r] + rv[oy[r]]) + rv[ox[r]];
+    }
+  };
+  __syncthreads();   // rel-pos tile
+  STR_TICK(0);   // prologue: q rows, first key fragments requested, rel-pos tile
+
+  // ---- pass A: running (max, sum) of every row over all N keys; wave w owns keys 16 w .. 16 w + 15 of each 64-key chunk ----
+  float rm[NHR], rsum[NHR];
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) { rm[hr] = -1.0e30f; rsum[hr] = 0.f; }
+  auto stats = [&](int c0, const float4* kf) __attribute__((always_inline)) {
+    f32x4_acc sacc[NHR];
+    scores(kf, sacc);
+    const int jb = c0 + wave * 16 + 4 * kg;
+    int js[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) js[r] = jb + r < a.N ? jb + r : a.N - 1;
+    with_rel(sacc, js);
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      // 4 scores of ONE row: one rescale of the running sum per group, one exponential per score
+      float x[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = jb + r < a.N ? sacc[hr][r] : -INFINITY;
+      const float nm = fmaxf(rm[hr], fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));   // finite: rm starts at -1e30
+      const float part = (fast_exp(x[0] - nm) + fast_exp(x[1] - nm)) + (fast_exp(x[2] - nm) + fast_exp(x[3] - nm));
+      rsum[hr] = fmaf(rsum[hr], fast_exp(rm[hr] - nm), part);
+      rm[hr] = nm;
+    }
+  };
+  // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
+  // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
+  for (int c0 = 0; c0 < a.N; c0 += 128) {
+    stats(c0, kA);
+    { const int j = c0 + 128 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
+    if (c0 + 64 < a.N) stats(c0 + 64, kB);
+    { const int j = c0 + 192 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+  }
+  bool rok[NHR];   // query row 16 hr + l15 of the tile exists
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) rok[hr] = i0 + 16 * hr + l15 < a.N;
+  // ---- gated frame: selected-column bookkeeping.  The first two chunks' column indices, and the first chunk's key rows
+  // and old reference values, are requested HERE -- they do not depend on the statistics -- so that their two dependent
+  // round trips overlap the combine below.
+  const int cnt = FIRST ? 0 : (a.count ? a.count[b] : a.kcap);
+  const int32_t* ix = a.idx + (int64_t)b * a.kcap;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int VIT = SDH * (FKC / VEC) / 256;   // 16-byte pieces of dv~^T / v_old^T per thread and chunk
+  const T* Vg_d = reinterpret_cast<const T*>(a.v_delta_t) + (int64_t)bh * SDH * a.kcap;
+  const T* Vg_o = reinterpret_cast<const T*>(a.v_old_t) + (int64_t)bh * SDH * a.kcap;
+  const bool vvec = (a.kcap % VEC) == 0;
+  // The chain index -> key row of the selected column -> scores -> gate is latency-bound (two dependent round trips per
+  // chunk): the column indices are fetched two chunks ahead and the key rows + old reference values one chunk ahead,
+  // into two register sets used alternately (no register copies of loaded values at the loop's back edge).
+  struct Cols { int frag; int g[4]; };   // this lane's fragment column (key row it loads) and its 4 gate columns; -1 past the count
+  auto cols_of = [&](int c) __attribute__((always_inline)) {
+    Cols q;
+    const int kf_ = c * FKC + wave * 16 + l15;
+    const int jf = ix[kf_ < cnt ? kf_ : 0];
+    q.frag = kf_ < cnt ? jf : -1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = c * FKC + wave * 16 + 4 * kg + r;
+      const int j = ix[kk < cnt ? kk : 0];
+      q.g[r] = kk < cnt ? j : -1;
+    }
+    return q;
+  };
+  auto request_old = [&](const Cols& q, T (*old)[4]) __attribute__((always_inline)) {   // old reference values of the lane's 4 columns
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      const int i = rok[hr] ? i0 + 16 * hr + l15 : 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) old[hr][r] = stT[(int64_t)(q.g[r] >= 0 ? q.g[r] : 0) * a.N + i];
+    }
+  };
+  auto load_v = [&](int k0, uint4* pd, uint4* po) __attribute__((always_inline)) {   // chunk k0 of dv~^T / v_old^T -> registers (branch-free, clamped)
+    // columns in [count, kcap) hold zeros (evt_v_gate writes them); pieces past kcap are zeroed here
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kv = k0 + jj;
+      const bool in = kv < a.kcap;
+      const int64_t o = (int64_t)d * a.kcap + (in ? kv : 0);
+      const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+      pd[it] = in ? xd : make_uint4(0, 0, 0, 0);
+      po[it] = in ? xo : make_uint4(0, 0, 0, 0);
+    }
+  };
+  constexpr bool VPRE = sizeof(T) == 2;   // 16-bit store: V pieces requested a whole chunk ahead (see the chunk loop)
+  uint4 vnd[VPRE ? VIT : 1], vno[VPRE ? VIT : 1];
+  const int nch = FIRST ? 0 : (cnt + FKC - 1) / FKC;
+  T old[NHR][4];   // ONE set: the next chunk's values are requested as soon as the gate has consumed this chunk's
+  Cols qA, qB;
+  uint4 v0d[VPRE ? 1 : VIT], v0o[VPRE ? 1 : VIT];   // fp32: the first chunk's V pieces, in registers across the combine only
+  if (!FIRST && nch > 0) {
+    qA = cols_of(0);
+    qB = cols_of(1);
+    load_kf(qA.frag >= 0 ? qA.frag : 0, kA);
+    request_old(qA, old);
+    if (vvec) {
+      if (VPRE) load_v(0, vnd, vno);
+      else load_v(0, v0d, v0o);
+    }
+  }
+  STR_TICK(1);   // pass A
+  // combine the 4 key groups of a row (lanes l15, l15 + 16, + 32, + 48), then the 4 waves through LDS
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) {
+    float m = rm[hr], s = rsum[hr];
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+      const float M = fmaxf(m, m2);
+      s = s * fast_exp(m - M) + s2 * fast_exp(m2 - M);
+      m = M;
+    }
+    if (kg == 0) {
+      wst[(wave * FRT + 16 * hr + l15) * 2] = m;
+      wst[(wave * FRT + 16 * hr + l15) * 2 + 1] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < FRT) {
+    float m = wst[tid * 2], s = wst[tid * 2 + 1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float m2 = wst[(w * FRT + tid) * 2], s2 = wst[(w * FRT + tid) * 2 + 1];
+      const float M = fmaxf(m, m2);
+      s = s * fast_exp(m - M) + s2 * fast_exp(m2 - M);
+      m = M;
+    }
+    fin[tid * 2] = m;
+    fin[tid * 2 + 1] = 1.0f / s;   // softmax normaliser as a reciprocal: e * (1 / sum) is within 1 ulp of e / sum before the rounding
+  }
+  __syncthreads();
+  float fm[NHR], fi[NHR];
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) {
+    fm[hr] = fin[(16 * hr + l15) * 2];
+    fi[hr] = fin[(16 * hr + l15) * 2 + 1];
+  }
+  if (!FIRST && !VPRE && vvec && nch > 0) {   // fp32: the first chunk's V pieces -> LDS (the V tiles are idle until the chunk loop)
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC;
+      *reinterpret_cast<uint4*>(Vd + d * P + jj) = v0d[VPRE ? 0 : it];
+      *reinterpret_cast<uint4*>(Vo + d * P + jj) = v0o[VPRE ? 0 : it];
+    }
+  }
+  STR_TICK(2);   // statistics combine
+
+  // ---- pass B ----------------------------------------------------------------------------------------------------
+  const int half = wave & 1, psel = wave >> 1;   // gated: product (0: a~ . dv~, 1: da~ . v_old); first frame: key half of the chunk
+  f32x4_acc acc[NHR][2];   // rows 16 hr + 4 kg + r, channel 32 half + 16 cg + l15
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) acc[hr][cg] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+  T* pv = reinterpret_cast<T*>(a.pv);
+  // epilogue pieces of this thread: 8 channels of one row each
+  constexpr int PIT = (FRT * 8 + 255) / 256;
+  union Pv8 { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; };
+  union Ref8 { float4 v[2]; float f[8]; };
+  Pv8 pvr[PIT];
+  Ref8 nrr[PIT];
+  auto piece = [&](int it, int* row, int* c8, int64_t* off) __attribute__((always_inline)) {
+    const int e = tid + 256 * it, rr = e >> 3, i = i0 + rr;
+    *row = rr;
+    *c8 = (e & 7) * 8;
+    *off = ((int64_t)b * a.N + (i < a.N ? i : a.N - 1)) * a.D + h * SDH + (e & 7) * 8;
+    return e < FRT * 8 && i < a.N;
+  };
+  typedef Quad<T> QuadT;
+  // both accumulator products of the chunk staged in LDS: rows of a~ / da~ (A operand) x channels of dv~^T / v_old^T (B)
+  auto sweep = [&](const T* At, const T* Vt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg)
+        acc[hr][cg] = Sweep16<T>::template run<0, FKC>(At + (16 * hr + l15) * P, Vt + (32 * half + 16 * cg + l15) * P, kg, acc[hr][cg]);
+  };
+
+  if (FIRST) {
+    const T* vst = reinterpret_cast<const T*>(a.v_state) + (int64_t)b * a.N * a.D + h * SDH;
+    { const int j = wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
+    { const int j = 64 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+    auto first_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
+      // the chunk's 64 value rows (16 channels per thread), requested ahead of the score MFMAs
+      const int vkey = tid >> 2, vc0 = (tid & 3) * 16, vj = c0 + vkey;
+      union { uint4 u[(16 * sizeof(T)) / 16]; T t[16]; } vv;
+#pragma unroll
+      for (int q = 0; q < (int)((16 * sizeof(T)) / 16); ++q)
+        vv.u[q] = reinterpret_cast<const uint4*>(vst + (int64_t)(vj < a.N ? vj : a.N - 1) * a.D + vc0)[q];
+      f32x4_acc sacc[NHR];
+      scores(kf, sacc);
+      const int jb = c0 + wave * 16 + 4 * kg;
+      int js[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) js[r] = jb + r < a.N ? jb + r : a.N - 1;
+      with_rel(sacc, js);
+#pragma unroll
+      for (int hr = 0; hr < NHR; ++hr) {
+        QuadT nw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rok[hr] && jb + r < a.N;
+          const float an = Store<T>::round(fast_exp(sacc[hr][r] - fm[hr]) * fi[hr]);
+          Store<T>::store(&nw.t[r], ok ? an : 0.f);
+          if (ok) Store<T>::store(stT + (int64_t)(jb + r) * a.N + i0 + 16 * hr + l15, an);
+        }
+        *reinterpret_cast<decltype(nw.v)*>(An + (16 * hr + l15) * P + wave * 16 + 4 * kg) = nw.v;
+      }
+      T z;
+      Store<T>::store(&z, 0.f);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Vd[(vc0 + q) * P + vkey] = vj < a.N ? vv.t[q] : z;
+      __syncthreads();
+      // keys 0..31 of the chunk on waves 0, 1, keys 32..63 on waves 2, 3 (summed unrounded in the epilogue)
+#pragma unroll
+      for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+          const T* At = An + (16 * hr + l15) * P;
+          const T* Vt = Vd + (32 * half + 16 * cg + l15) * P;
+          if (psel == 0) acc[hr][cg] = Sweep16<T>::template run<0, 32>(At, Vt, kg, acc[hr][cg]);
+          else acc[hr][cg] = Sweep16<T>::template run<32, 32>(At, Vt, kg, acc[hr][cg]);
+        }
+      __syncthreads();
+    };
+    for (int c0 = 0; c0 < a.N; c0 += 128) {
+      first_chunk(c0, kA);
+      { const int j = c0 + 128 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
+      if (c0 + 64 < a.N) first_chunk(c0 + 64, kB);
+      { const int j = c0 + 192 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+    }
+    STR_TICK(3);   // pass B (first frame: all keys)
+    // ---- epilogue: out = state = round(acc(keys 0..31 of each chunk) + acc(keys 32..63)) ------------------------
+    float* redp = (psel == 0) ? red1 : red2;
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redp[(16 * hr + 4 * kg + r) * SDH + 32 * half + 16 * cg + l15] = acc[hr][cg][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      int row, c8; int64_t eo;
+      if (!piece(it, &row, &c8, &eo)) continue;
+      Pv8 st8;
+      Ref8 o8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = Store<T>::round(red1[row * SDH + c8 + q] + red2[row * SDH + c8 + q]);
+        Store<T>::store(&st8.t[q], v);
+        o8.f[q] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + eo)[q] = st8.u[q];
+      if (a.out_f32 != nullptr) {
+        reinterpret_cast<float4*>(a.out_f32 + eo)[0] = o8.v[0];
+        reinterpret_cast<float4*>(a.out_f32 + eo)[1] = o8.v[1];
+      }
+    }
+#ifdef EVT_PROF
+    STR_TICK(4);
+    if (prof_on && lane == 0)
+      for (int q = 0; q < 16; ++q) evt_prof_stream_buf[q] = prof_acc[q];
+#endif
+    return;
+  }
+
+  // ---- gated frame: the k selected columns in chunks of 64 (declarations: in front of the statistics combine) ----
+  // `full` (wave-uniform): every row of the tile and every column of the chunk exists -- the reference stores are then
+  // unconditional.  (Predicated stores sit in exec-masked branches; hipcc cannot count them and waits vmcnt(0) at the next
+  // counted wait, i.e. for the prefetched loads of the NEXT chunk and for the stores' own acknowledgements.)
+  const bool tile_full = i0 + FRT <= a.N;
+  auto process = [&](int k0, const Cols& q, const Cols& qnext, const float4* kf, uint4* vpd, uint4* vpo) __attribute__((always_inline)) {
+    f32x4_acc sacc[NHR];
+    scores(kf, sacc);
+    int js[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) js[r] = q.g[r] >= 0 ? q.g[r] : 0;
+    with_rel(sacc, js);
+    const bool full = tile_full && k0 + FKC <= cnt;
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      QuadT nw, dl;
+      float anv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = rok[hr] && q.g[r] >= 0;
+        const float an = Store<T>::round(fast_exp(sacc[hr][r] - fm[hr]) * fi[hr]);
+        const float ad = Store<T>::round(an - Store<T>::load(&old[hr][r]));
+        anv[r] = an;
+        Store<T>::store(&nw.t[r], ok ? an : 0.f);
+        Store<T>::store(&dl.t[r], ok ? ad : 0.f);
+      }
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Store<T>::store(stT + (int64_t)js[r] * a.N + i0 + 16 * hr + l15, anv[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (rok[hr] && q.g[r] >= 0) Store<T>::store(stT + (int64_t)q.g[r] * a.N + i0 + 16 * hr + l15, anv[r]);
+      }
+      *reinterpret_cast<decltype(nw.v)*>(An + (16 * hr + l15) * P + wave * 16 + 4 * kg) = nw.v;
+      *reinterpret_cast<decltype(dl.v)*>(Ad + (16 * hr + l15) * P + wave * 16 + 4 * kg) = dl.v;
+    }
+    request_old(qnext, old);   // (past the last chunk: dummy re-reads of column 0)
+    STR_TICK(5);   // chunk: key rows + old values waited for, scores, gate
+    // V pieces.  16-bit store (VPRE): this chunk's pieces were requested a chunk ago (16 registers carried over the loop's
+    // back edge); they go to LDS now and the next chunk's are requested.  fp32 (32 registers): the NEXT chunk's pieces are
+    // requested here -- the score / gate registers are dead -- fly during the barrier + MFMA sweep, and are written to the
+    // (then idle) V tiles behind the sweep; this chunk's pieces are already in LDS.
+    uint4 lpd[VIT], lpo[VIT];
+    if (vvec && VPRE) {
+#pragma unroll
+      for (int it = 0; it < VIT; ++it) {
+        const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC;
+        *reinterpret_cast<uint4*>(Vd + d * P + jj) = vpd[it];
+        *reinterpret_cast<uint4*>(Vo + d * P + jj) = vpo[it];
+      }
+      load_v(k0 + FKC, vpd, vpo);   // (past the last chunk: a dummy, clamped)
+    } else if (vvec) {
+      if (k0 + FKC < cnt) load_v(k0 + FKC, lpd, lpo);
+    } else {
+      for (int e = tid; e < SDH * FKC; e += 256) {
+        const int d = e / FKC, jj = e - d * FKC, kv = k0 + jj;
+        float vd = 0.f, vo = 0.f;
+        if (kv < cnt) {
+          vd = Store<T>::load(Vg_d + (int64_t)d * a.kcap + kv);
+          vo = Store<T>::load(Vg_o + (int64_t)d * a.kcap + kv);
+        }
+        Store<T>::store(Vd + d * P + jj, vd);
+        Store<T>::store(Vo + d * P + jj, vo);
+      }
+    }
+    STR_TICK(6);   // chunk: V staging
+    __syncthreads();
+    STR_TICK(7);   // chunk: barrier
+    sweep(psel == 0 ? An : Ad, psel == 0 ? Vd : Vo);
+    STR_TICK(8);   // chunk: MFMA sweep
+    __syncthreads();
+    if (vvec && !VPRE && k0 + FKC < cnt) {   // (wave-uniform) the next chunk's pieces -> the V tiles nobody reads any more
+#pragma unroll
+      for (int it = 0; it < VIT; ++it) {
+        const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC;
+        *reinterpret_cast<uint4*>(Vd + d * P + jj) = lpd[it];
+        *reinterpret_cast<uint4*>(Vo + d * P + jj) = lpo[it];
+      }
+    }
+    STR_TICK(9);   // chunk: barrier
+  };
+  // Issue order per chunk (vmcnt retires in order): the NEXT chunk's key rows, the column indices of the chunk after that,
+  // then the chunk itself; behind its gate the next chunk's old reference values and V pieces.  Every wait leaves the
+  // younger requests in flight.
+  if (nch > 0) {
+    for (int c = 0; c < nch; c += 2) {
+      load_kf(qB.frag >= 0 ? qB.frag : 0, kB);   // chunk c + 1 (a dummy re-read of key 0 past the last chunk)
+      const Cols n0 = cols_of(c + 2);
+      process(c * FKC, qA, qB, kA, vnd, vno);
+      qA = n0;
+      if (c + 1 < nch) {
+        load_kf(qA.frag >= 0 ? qA.frag : 0, kA);   // chunk c + 2
+        const Cols n1 = cols_of(c + 3);
+        process((c + 1) * FKC, qB, qA, kB, vnd, vno);
+        qB = n1;
+      }
+    }
+  }
+
+  // the A.v state rows (and the next gate's reference) of the epilogue: requested here, behind the last chunk -- held
+  // across the chunk loop they cost 24-32 registers (spills in the 48-row variants)
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    int row, c8; int64_t eo;
+    piece(it, &row, &c8, &eo);
+#pragma unroll
+    for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) pvr[it].u[q] = reinterpret_cast<const uint4*>(pv + eo)[q];
+    if (a.norm_ref != nullptr) {
+      nrr[it].v[0] = reinterpret_cast<const float4*>(a.norm_ref + eo)[0];
+      nrr[it].v[1] = reinterpret_cast<const float4*>(a.norm_ref + eo)[1];
+    }
+  }
+  STR_TICK(3);   // pass B (selected columns)
+  // ---- epilogue: state += round(a~ . dv~); state += round(da~ . v_old); heads merged on write; per-head ||out - ref||^2 ----
+  {
+    float* redp = (psel == 0) ? red1 : red2;
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          redp[(16 * hr + 4 * kg + r) * SDH + 32 * half + 16 * cg + l15] = Store<T>::round(acc[hr][cg][r]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    int row, c8; int64_t eo;
+    const bool ok = piece(it, &row, &c8, &eo);
+    const int rrow = row < FRT ? row : 0;
+    Pv8 st8 = pvr[it];
+    Ref8 o8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[rrow * SDH + c8 + q]);   // += a~ . dv~
+      v = Store<T>::round(v + red2[rrow * SDH + c8 + q]);                                   // += da~ . v_old
+      Store<T>::store(&st8.t[q], v);
+      o8.f[q] = v;
+    }
+    if (ok) {
+#pragma unroll
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + eo)[q] = st8.u[q];
+      if (a.out_f32 != nullptr) {   // NULL: the caller reads the (identical) values from the A.v state
+        reinterpret_cast<float4*>(a.out_f32 + eo)[0] = o8.v[0];
+        reinterpret_cast<float4*>(a.out_f32 + eo)[1] = o8.v[1];
+      }
+    }
+    if (a.norm_parts != nullptr) {   // the 8 threads of a row are consecutive lanes: fixed butterfly order (deterministic)
+      float ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float d = o8.f[q] - nrr[it].f[q]; ss = fmaf(d, d, ss); }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      if (ok && (tid & 7) == 0) a.norm_parts[((int64_t)b * a.N + i0 + row) * a.H + h] = ss;
+    }
+  }
+#ifdef EVT_PROF
+  STR_TICK(4);   // epilogue
+  if (prof_on && lane == 0)
+    for (int q = 0; q < 16; ++q) evt_prof_stream_buf[q] = prof_acc[q];
+#endif
+}
+
+template <typename T, int NHR>
+size_t stream_lds_bytes(int nrel) {
+  constexpr int P = Tile<T>::PITCH, FRT = 16 * NHR;
+  return (size_t)(2 * FRT + 2 * SDH) * P * sizeof(T) + ((size_t)FRT * (nrel | 1) + 4 * FRT * 2 + FRT * 2) * sizeof(float);
+}
+
+template <typename T, bool FIRST, int QK, int NHR>
+void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
+  constexpr int FRT = 16 * NHR;
+  const size_t lds = stream_lds_bytes<T, NHR>(a.gh + a.gw);
+  const int tiles_x = (a.N + FRT - 1) / FRT, total = tiles_x * a.B * a.H;
+  EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
+  hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
+}
+
+int stream_cu_count() {
+  static int cus[EVT_MAX_DEVICES] = {0};
+  const int dev = evt_current_device();
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+// Tile height: the launch runs in ceil(workgroups / slots) rounds of (almost) equal length, slots = CUs x workgroups per
+// CU (two by registers; fewer when LDS says so), and a workgroup of NHR row groups costs ~(1 + NHR) units (the key
+// fragments are split once per workgroup, everything else is per row group).  EVT_STREAM_NHR forces 2 or 3.
+template <typename T>
+int stream_pick_nhr(const StreamArgs& a) {
+  static const int forced = getenv("EVT_STREAM_NHR") ? atoi(getenv("EVT_STREAM_NHR")) : 0;
+  if (forced >= 2 && forced <= 3) return forced;
+  const int cus = stream_cu_count(), nrel = a.gh + a.gw;
+  const size_t lds[2] = {stream_lds_bytes<T, 2>(nrel), stream_lds_bytes<T, 3>(nrel)};
+  int best = 2;
+  int64_t best_cost = -1;
+  for (int nhr = 2; nhr <= 3; ++nhr) {   // (64-row tiles, NHR = 4, spill 60-600 registers in the gated variants: not built)
+    const int per_cu = (int)std::min<size_t>(2, (160 * 1024) / lds[nhr - 2]);
+    if (per_cu < 1) continue;
+    const int64_t wgs = (int64_t)((a.N + 16 * nhr - 1) / (16 * nhr)) * a.B * a.H, slots = (int64_t)cus * per_cu;
+    const int64_t cost = ((wgs + slots - 1) / slots) * (1 + nhr) * (per_cu == 1 ? 3 : 4);   // one workgroup per CU runs ~25 % faster
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nhr; }
+  }
+  return best;
+}
+
+template <typename T, bool FIRST>
+void launch_stream(const StreamArgs& a, int qk_split, hipStream_t s) {
+  if (!qk_split) { launch_stream_inst<T, FIRST, 1, 2>(a, s); return; }   // exact fp32 products: 32-row tiles only
+  switch (stream_pick_nhr<T>(a)) {
+    case 3: launch_stream_inst<T, FIRST, 2, 3>(a, s); break;
+    default: launch_stream_inst<T, FIRST, 2, 2>(a, s); break;
+  }
+}
+
+}  // namespace
+
+extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream) {
+  EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_attention_stream: null descriptor");
+  EVT_REQUIRE(d->qkv && d->a_state_t && d->pv, EVT_ERR_BAD_ARG, "evt_attention_stream: null qkv / a_state_t / pv");
+  EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->D == d->H * 64, EVT_ERR_BAD_SHAPE,
+              "evt_attention_stream: head dim 64 required (B=%d H=%d N=%d D=%d)", d->B, d->H, d->N, d->D);
+  EVT_REQUIRE((d->N & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_attention_stream: N=%d must be a multiple of 4", d->N);
+  EVT_REQUIRE(d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_attention_stream: scale must be positive");
+  EVT_REQUIRE(d->rel_terms == nullptr || (d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N), EVT_ERR_BAD_SHAPE,
+              "evt_attention_stream: rel-pos key grid %dx%d does not match N=%d", d->gh, d->gw, d->N);
+  EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_attention_stream: norm_ref / norm_parts come together");
+  if (d->first) {
+    EVT_REQUIRE(d->v_state != nullptr, EVT_ERR_BAD_ARG, "evt_attention_stream: first frame needs v_state");
+    EVT_REQUIRE(d->norm_ref == nullptr, EVT_ERR_BAD_ARG, "evt_attention_stream: norm_ref is a gated-frame output");
+  } else {
+    EVT_REQUIRE(d->idx && d->v_delta_t && d->v_old_t && d->kcap >= 0, EVT_ERR_BAD_ARG, "evt_attention_stream: gated frame needs idx, v_delta_t, v_old_t");
+    EVT_REQUIRE(d->out_f32 != nullptr || d->store != EVT_F32, EVT_ERR_BAD_ARG,
+                "evt_attention_stream: out_f32 may only be omitted with a 16-bit store type (the output then IS the pv state)");
+  }
+  if (d->B == 0) return EVT_OK;
+  const bool rel = d->rel_terms != nullptr;
+  StreamArgs a{d->qkv, d->rel_terms, d->a_state_t, d->idx, d->count, d->v_delta_t, d->v_old_t, d->v_state, d->pv, d->out_f32,
+               d->norm_ref, d->norm_parts, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale};
+  hipStream_t s = evt_stream(stream);
+  EVT_DISPATCH_STORE(d->store, T, {
+    if (d->first) launch_stream<T, true>(a, d->qk_split, s);
+    else launch_stream<T, false>(a, d->qk_split, s);
+  });
+  return evt_check_launch("evt_attention_stream");
+}
+
+#ifdef EVT_PROF
+extern "C" __attribute__((visibility("default"))) int evt_debug_prof_stream(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_stream_buf), sizeof(unsigned long long) * 16);
+}
+#endif

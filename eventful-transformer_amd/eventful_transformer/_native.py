@@ -20,12 +20,12 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 4   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 5   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense",
+    "evt_attention_dense", "evt_attention_stream",
 )
 
 
@@ -103,6 +103,16 @@ class AttnDenseDesc(Structure):
     ]
 
 
+class AttnStreamDesc(Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("rel_terms", c_void_p), ("gh", c_int32), ("gw", c_int32), ("a_state_t", c_void_p),
+        ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p),
+        ("v_state", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("store", c_int32), ("scale", c_float),
+        ("qk_split", c_int32), ("first", c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -135,6 +145,7 @@ def _bind(lib):
         "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
         "evt_rel_terms": [P, P, P, I, I, I, I, I, I, I, P, P],
         "evt_attention_dense": [POINTER(AttnDenseDesc), P],
+        "evt_attention_stream": [POINTER(AttnStreamDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -432,6 +443,33 @@ def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv,
 def fused_qk_fits(N, Nk, D, H, kcap):
     """K5+K6 can compute the score rows itself (product=None): head dim 64, un-pooled, at most 256 tokens."""
     return FUSED_QK and D == 64 * H and N == Nk and 0 < N <= 256 and kcap > 0
+
+
+STREAM_QK = os.environ.get("EVT_STREAM_QK", "1") != "0"   # global blocks with N > 256: in-kernel scores (evt_attention_stream)
+
+
+def attention_stream_fits(N, D, H):
+    """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest), N % 4 == 0."""
+    return STREAM_QK and FUSED_QK and D == 64 * H and N > 256 and N % 4 == 0
+
+
+def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_terms=None, gh=0, gw=0, idx=None, count=None,
+                     kcap=0, v_delta_t=None, v_old_t=None, v_state=None, out_f32=None, norm_ref=None, norm_parts=None,
+                     qk_split=None):
+    """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N)."""
+    d = AttnStreamDesc(_p(qkv), _p(rel_terms), gh, gw, _p(a_state_t), _p(idx), _p(count), kcap, _p(v_delta_t), _p(v_old_t),
+                       _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts), B, H, N, D, store, float(scale),
+                       int(QK_SPLIT if qk_split is None else qk_split), int(first))
+    # algorithmic bytes: q, k read once per clip (8ND), rel terms, gate-reference columns read + rewritten (first frame:
+    # written whole), v pieces, A.v state read-modify-write (first frame: v state read, state written), fp32 output
+    es = 4 if store == EVT_F32 else 2
+    rel_b = 4.0 * H * N * (gh + gw) if rel_terms is not None else 0.0
+    if first:
+        work = B * (8.0 * N * D + rel_b + 1.0 * es * H * N * N + 2.0 * es * N * D + 4.0 * N * D)
+    else:
+        work = B * (8.0 * N * D + rel_b + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D +
+                    (4.0 * N * D if out_f32 is not None else 0.0))
+    _timed("attn", work, lambda: _check(load().evt_attention_stream(ctypes.byref(d), _stream())))
 
 
 def attention_dense_fits(N, D, H):

@@ -696,6 +696,8 @@ class EventfulBlock(EventfulMatmul1Block):
             product = self._scores(qkv, idx, count, cap, B, N)[0]
             self._ats_idx_k = None if idx is None else idx.long()
             return self._ats_attention(product, qkv, B, N, eventful=True) + (None,)
+        if self.pool_size is None and _native.attention_stream_fits(N, D, H):
+            return self._attention_stream(qkv, idx, count, cap, B, N)
         if acc.first and idx is None and self.matmul_accumulator_1.first:
             a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
             pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
@@ -790,6 +792,66 @@ class EventfulBlock(EventfulMatmul1Block):
             if acc.count_mode:
                 acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
             acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+        return attn, None, fused
+
+    def _attention_stream(self, qkv, idx, count, cap, B, N):
+        """More than 256 tokens at head dim 64 (ViTDet global blocks): ONE evt_attention_stream launch per frame computes
+        the scores in the kernel from the token buffer -- no q.k^T state, no K4 -- with the matmul_gate reference stored
+        transposed (`matmul_gate.p` is a transposed view of it, same logical (B,H,N,N) tensor as in the reference).
+        `matmul_accumulator_1.product` is refreshed lazily if anybody reads it (MatmulBuffer.defer)."""
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        vg, ag, acc, acc1 = self.v_gate, self.matmul_gate, self.matmul_accumulator_2, self.matmul_accumulator_1
+        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+        ry, rx, gh, gw, qw = self._rel_tables()
+        terms = None
+        if ry is not None:   # decomposed rel-pos terms of every query token, once per frame (utils.py:159-168)
+            terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
+            _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
+            self.relative_position.count_fused(B, H)
+        if acc.first:   # first frame of the clip: gate reference, value state, A.v state and the output in one launch
+            vg.first = ag.first = acc.first = acc1.first = False
+            ag._state_t = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)   # [b][h][key][row]
+            ag.p = ag._state_t.transpose(-1, -2)
+            vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            acc._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            self._v_full(qkv, None, B, N, N, vg._state, store)
+            _native.attention_stream(qkv, ag._state_t, acc._state, B, H, N, D, self.scale, store, True, rel_terms=terms,
+                                     gh=gh, gw=gw, v_state=vg._state, out_f32=attn)
+            self._defer_scores(B, N)
+            acc1.matmul.count_product(B * H * N * N, dh)
+            acc.matmul.count_product(B * H * N * dh, N)
+            return attn, None, None
+        v_delta = self._ws("v_delta_t", (B, D, cap), sdt, qkv)
+        v_old = self._ws("v_old_t", (B, D, cap), sdt, qkv)
+        _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
+        pg = self.projection_gate
+        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
+        nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
+        state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
+        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+                and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
+            cap_p = pg.policy.capacity(N)
+            state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
+        _native.attention_stream(qkv, ag._state_t, acc._state, B, H, N, D, self.scale, store, False, rel_terms=terms,
+                                 gh=gh, gw=gw, idx=idx, count=count, kcap=cap, v_delta_t=v_delta, v_old_t=v_old,
+                                 out_f32=None if state_src else attn, norm_ref=pg.p if fuse_norm else None,
+                                 norm_parts=nparts)
+        self._defer_scores(B, N)
+        if self.count_mode or acc.count_mode or vg.count_mode or acc1.matmul.count_mode:
+            n = self._n_rows(B, cap, count)
+            if acc1.matmul.count_mode:   # the reference's delta update of the q.k^T state (modules.py:232-247)
+                acc1.matmul.count_product(2 * H * N * n, dh)
+            self._count_gate(vg, B * N * D)
+            self._count_gate(ag, B * H * N * N)
+            if acc.count_mode:
+                acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
+            acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+        fused = dict(norm_parts=(nparts, H) if fuse_norm else None, state_src=acc._state if state_src else None)
         return attn, None, fused
 
     def reset_self(self):

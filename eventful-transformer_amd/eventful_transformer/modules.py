@@ -46,10 +46,12 @@ class _GateBase(ExtendedModule):
         self.first = True
         self.policy = None
         self.p = None
+        self._state_t = None   # EventfulBlock's large-N path keeps the "col" gate reference transposed; `p` is a view of it
 
     def reset_self(self):
         self.first = True
         self.p = None
+        self._state_t = None
 
     # -- selection --------------------------------------------------------------------------------
     def _select_rows(self, c, forced_index):

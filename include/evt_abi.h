@@ -31,10 +31,11 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 4   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+#define EVT_ABI_VERSION 5   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
-                                    evt_gated_linear_big_tile */
+                                    evt_gated_linear_big_tile;
+                                 5: evt_attention_stream */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -351,6 +352,43 @@ EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
  * terms for itself re-reads 32 x (gh + gw) table rows of 256 bytes).  Head dim 64, N = qh * qw. */
 EVT_API int evt_rel_terms(const float* qkv, const float* rel_y, const float* rel_x, int32_t B, int32_t H, int32_t N,
                           int32_t D, int32_t gh, int32_t gw, int32_t qw, float* terms, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * K5+K6 for LARGE token counts, scores computed in the kernel (ABI 5; ViTDet global blocks, N = 1764 / 4096):
+ * ONE launch per frame and block replaces evt_qk + evt_softmax_av_gated (gated frames) and evt_qk +
+ * evt_softmax_gate + evt_av (first frame), and the (B,H,N,N) fp32 q.k^T state is neither kept nor read.
+ *
+ *   scores   x[i,j] = (q[i] / scale) . k[j]  (+ rel_terms[i, j / gw] + rel_terms[i, gh + j % gw])   blocks.py:514-521
+ *            recomputed on the matrix cores from the packed token buffer for the 32 rows of a workgroup against all N
+ *            keys; only running (max, sum) pairs are kept (softmax, blocks.py:522)
+ *   first=1  a = round(softmax(x)) -> a_state_t (the matmul_gate reference, modules.py:183-185);
+ *            pv = out = round(a . v_state)  (MatmulDeltaAccumulator first frame, modules.py:277-283)
+ *   first=0  for the selected key columns idx: a~ = round(softmax(x)[:, idx]); da~ = round(a~ - ref[:, idx]);
+ *            ref[:, idx] = a~  (TokenDeltaGate "col", modules.py:187-201);
+ *            pv += round(a~ . dv~); pv += round(da~ . v_old)  (modules.py:285-295); out = pv, heads merged.
+ *
+ * a_state_t is the gate reference TRANSPOSED, (B,H,Nkeys,Nrows): the 32 rows a workgroup owns of a selected column
+ * are contiguous.  Head dim 64, N % 4 == 0, un-pooled keys (Nk == N).  v_delta_t / v_old_t, norm_ref / norm_parts,
+ * out_f32 == NULL: as in evt_softmax_av_desc.  rel_terms: evt_rel_terms output or NULL (no relative position).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_attn_stream_desc {
+  const float* qkv;                       /* (B,N,3D) packed token buffer (qkv_accumulator.b)                */
+  const float* rel_terms; int32_t gh, gw; /* nullable (B,H,N,gh+gw); key grid gh x gw == N                   */
+  void* a_state_t;                        /* (B,H,N,N) store type, [b][h][key][row]: matmul_gate.p^T         */
+  const int32_t* idx; const int32_t* count; int32_t kcap;   /* gated frame: selected key columns             */
+  const void* v_delta_t; const void* v_old_t;               /* gated frame: (B,D,kcap) from evt_v_gate       */
+  const void* v_state;                    /* first frame: (B,N,D) store type, round(v) (evt_v_gate FULL)     */
+  void* pv;                               /* (B,N,D) store type: matmul_accumulator_2.product                */
+  float* out_f32;                         /* (B,N,D); nullable on gated frames with a 16-bit store type      */
+  const float* norm_ref; float* norm_parts;   /* gated frame, nullable pair: see evt_softmax_av_desc         */
+  int32_t B, H, N, D;
+  int32_t store;                          /* evt_dtype of a_state_t / v_* / pv                               */
+  float scale;                            /* q / scale (blocks.py:514)                                       */
+  int32_t qk_split;                       /* 1 = q, k as bf16 hi + lo (3 bf16 MFMAs per product), 0 = exact fp32 MFMA */
+  int32_t first;                          /* 1 = first frame of a clip                                       */
+} evt_attn_stream_desc;
+
+EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K/V token pooling (`pool_size`, blocks.py:303-326, 525-540).

@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 4
+    assert lib.evt_version() == n.ABI_VERSION == 5
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -711,3 +711,79 @@ def test_fused_attention_with_precomputed_rel_terms(cast, N, k):
     for x, y in zip(*res):
         assert torch.allclose(x, y, atol=tol * max(1.0, float(y.abs().max())), rtol=0), float((x - y).abs().max())
 
+
+
+@pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
+                                             (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True)])
+@pytest.mark.parametrize("qk_split", [0, 1])
+def test_attention_stream_matches_oracle(cast, N, gw, k, rel, qk_split):
+    """evt_attention_stream (N > 256, scores computed in the kernel, TRANSPOSED gate reference): first frame + 3 gated
+    frames against the oracle's softmax / delta gates / accumulator on the same token buffers -- incl. a device-side
+    count < kcap, rel-pos terms from evt_rel_terms, a partial last row tile (N % 32 != 0) and the fused per-head
+    ||out - ref||^2 partials."""
+    n = native()
+    B, H, dh, scale = 2, 2, 64, 8.0
+    D = H * dh
+    gh = N // gw
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(N * 13 + k)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    apT = torch.full((B, H, N, N), float("nan"), dtype=sdt, device=DEV)   # [b][h][key][row]
+    vp = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv = torch.full((B, N, D), float("nan"), dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    ry = torch.randn(gh, gh, dh, generator=g) * 0.2 if rel else None
+    rx = torch.randn(gw, gw, dh, generator=g) * 0.2 if rel else None
+    tol = (3e-5 if not qk_split else 3e-4) if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+    for t in range(4):
+        buf = torch.randn(B, N, 3 * D, generator=g) * 1.5
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        q, kk, v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        scores = (q / scale) @ kk.transpose(-2, -1)
+        logits = O.add_relative(scores.clone(), q, ry, rx, (gh, gw), inplace=False) if rel else scores
+        a = logits.softmax(dim=-1)
+        if cast is not None:
+            a, v = a.to(sdt), v.to(sdt)
+        else:
+            v = v.clone()
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        bd, idxd = buf.to(DEV), idx.int().to(DEV)
+        terms = None
+        if rel:
+            terms = torch.empty(B, H, N, gh + gw, device=DEV)
+            n.rel_terms(bd, ry.to(DEV), rx.to(DEV), B, H, N, D, gh, gw, gw, terms)
+        relkw = dict(rel_terms=terms, gh=gh, gw=gw) if rel else {}
+        if t == 0:
+            n.v_gate(bd, None, None, B, N, D, 0, vp, None, None, store, False)
+            n.attention_stream(bd, apT, pv, B, H, N, D, scale, store, True, v_state=vp, out_f32=out, qk_split=qk_split, **relkw)
+        else:
+            cap = k if t != 2 else k + 8
+            idx_cap = torch.full((B, cap), 0, dtype=torch.int32, device=DEV)
+            idx_cap[:, :k] = idxd
+            count = None if cap == k else torch.full((B,), k, dtype=torch.int32, device=DEV)
+            v_del = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            v_old = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            n.v_gate(bd, idx_cap, count, B, N, D, cap, vp, v_del, v_old, store, True, transposed=True)
+            ref_next = torch.randn(B, N, D, generator=g).to(DEV)
+            parts = torch.full((B, N, H), float("nan"), device=DEV)
+            n.attention_stream(bd, apT, pv, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap,
+                               v_delta_t=v_del, v_old_t=v_old, out_f32=out, norm_ref=ref_next, norm_parts=parts,
+                               qk_split=qk_split, **relkw)
+            want_parts = (out - ref_next).view(B, N, H, dh).pow(2).sum(-1)
+            assert torch.allclose(parts, want_parts, rtol=1e-5, atol=1e-6), float((parts - want_parts).abs().max())
+        atol_p = {None: tol * 0.1 + 3e-6, "bfloat16": 4e-3, "float16": 5e-4}[cast]
+        got_p = apT.float().cpu().transpose(-1, -2)
+        assert torch.allclose(got_p, ag.t.float(), atol=atol_p), (cast, t, float((got_p - ag.t.float()).abs().max()))
+        err = float((out.cpu() - ref).abs().max())
+        bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        assert err <= bar, (cast, N, k, t, err, bar)
+        assert torch.equal(out.cpu(), pv.float().cpu())
+    if cast is not None:   # 16-bit store: the fp32 output may be omitted (the caller reads the A.v state)
+        pv2 = pv.clone()
+        n.attention_stream(bd, apT.clone(), pv2, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap,
+                           v_delta_t=v_del, v_old_t=v_old, out_f32=None, qk_split=qk_split, **relkw)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        n.attention_stream(bd, apT, pv, 1, H, 262, D, scale, store, True, v_state=vp, out_f32=out)
