@@ -20,6 +20,10 @@ struct LinArgs {
 int evt_big_choice(const LinArgs& a);
 bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
 
+// evt_linear_small.hip: latency-oriented kernel for small gated row counts (one video stream).  Returns the K split it
+// launched with (0 = not taken; > 1 = partial planes in the workspace, the caller runs the finish pass).
+int evt_launch_split_small(const LinArgs& a, hipStream_t s);
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

@@ -610,6 +610,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const LinArgs g, int
   *reinterpret_cast<float4*>(g.out + orow * g.ldo + c) = v;
 }
 
+void launch_finish(const LinArgs& a, hipStream_t s, int ksplit, int dyn, int tiles_n) {
+  const int64_t work = (int64_t)a.B * a.kcap * (a.Nout / 4);
+  const dim3 fg((unsigned)((work + 255) / 256));
+  if (a.act == EVT_ACT_GELU_ERF) hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_GELU_ERF>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
+  else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
+}
+
 template <int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
 void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn = 0) {
   const int M = a.B * a.kcap;
@@ -627,12 +634,7 @@ void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn =
   else
     hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN, WDMA>), grid, block, lds_bytes, s, a,
                        tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
-  if (ksplit > 1) {
-    const int64_t work = (int64_t)M * (a.Nout / 4);
-    const dim3 fg((unsigned)((work + 255) / 256));
-    if (a.act == EVT_ACT_GELU_ERF) hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_GELU_ERF>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
-    else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
-  }
+  if (ksplit > 1) launch_finish(a, s, ksplit, dyn, tiles_n);
 }
 
 int forced_tile_variant() {
@@ -644,6 +646,11 @@ void launch_split(const LinArgs& a, hipStream_t s) {
   const int forced = forced_tile_variant();
   const int variant = forced < 0 ? 0 : forced;
   if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_big.hip)
+  if (forced < 0) {   // a few hundred gated rows (one video stream): the latency-oriented kernel (evt_linear_small.hip)
+    const int ks = evt_launch_split_small(a, s);
+    if (ks > 1) launch_finish(a, s, ks, 0, (a.Nout + 127) / 128);
+    if (ks >= 1) return;
+  }
   static const int splitk_on = getenv("EVT_GEMM_SPLITK") ? atoi(getenv("EVT_GEMM_SPLITK")) : 1;
   if (variant == 0 && splitk_on && a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {
     const int M = a.B * a.kcap;
