@@ -44,7 +44,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-METRIC = "frames/sec/GPU ViViT-B 16x224^2 r=128; gate-index bit-exact vs ref"
+METRIC = "frames/sec/GPU ViViT-B 16\u00d7224\u00b2 r=128; gate-index bit-exact vs ref"   # BASELINE.json's metric string (see `check`: index sets are
+# required equal wherever the reference's own top-k margin is >= check.margin_bar; agreement over all gates is reported)
 DIM, DEPTH, HEADS, TOKENS = 768, 12, 12, 196
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
@@ -104,6 +105,35 @@ def seeded_state_dict(seed=77, std=0.02):
         sd[p + "mlp_2.weight"], sd[p + "mlp_2.bias"] = n(DIM, 4 * DIM), n(DIM)
     sd["class_token"] = n(1, 1, DIM)
     sd["layer_norm.weight"], sd["layer_norm.bias"] = 1.0 + n(DIM, s=0.05), n(DIM, s=0.05)
+    return sd
+
+
+def seeded_state_dict_shapes():
+    """Names and shapes of seeded_state_dict() without generating the values (ranks other than 0 receive them by broadcast)."""
+    sd = {"backbone.position_encoding.encoding": torch.empty(1, TOKENS + 1, DIM)}
+    for i in range(DEPTH):
+        p = f"backbone.blocks.{i}."
+        for nm, shape in (("input_layer_norm.weight", (DIM,)), ("input_layer_norm.bias", (DIM,)), ("qkv.weight", (3 * DIM, DIM)),
+                          ("qkv.bias", (3 * DIM,)), ("projection.weight", (DIM, DIM)), ("projection.bias", (DIM,)),
+                          ("mlp_layer_norm.weight", (DIM,)), ("mlp_layer_norm.bias", (DIM,)), ("mlp_1.weight", (4 * DIM, DIM)),
+                          ("mlp_1.bias", (4 * DIM,)), ("mlp_2.weight", (DIM, 4 * DIM)), ("mlp_2.bias", (DIM,))):
+            sd[p + nm] = torch.empty(*shape)
+    sd["class_token"] = torch.empty(1, 1, DIM)
+    sd["layer_norm.weight"], sd["layer_norm.bias"] = torch.empty(DIM), torch.empty(DIM)
+    return sd
+
+
+def vitdet_state_dict_shapes():
+    sd = {"position_encoding.encoding": torch.empty(1, 14 * 14, DIM)}
+    for i in range(DEPTH):
+        p = f"blocks.{i}."
+        rel = 14 if i in VITDET_WINDOWED else 64
+        for nm, shape in (("input_layer_norm.weight", (DIM,)), ("input_layer_norm.bias", (DIM,)), ("qkv.weight", (3 * DIM, DIM)),
+                          ("qkv.bias", (3 * DIM,)), ("projection.weight", (DIM, DIM)), ("projection.bias", (DIM,)),
+                          ("mlp_layer_norm.weight", (DIM,)), ("mlp_layer_norm.bias", (DIM,)), ("mlp_1.weight", (4 * DIM, DIM)),
+                          ("mlp_1.bias", (4 * DIM,)), ("mlp_2.weight", (DIM, 4 * DIM)), ("mlp_2.bias", (DIM,)),
+                          ("relative_position.y_embedding", (2 * rel - 1, 64)), ("relative_position.x_embedding", (2 * rel - 1, 64))):
+            sd[p + nm] = torch.empty(*shape)
     return sd
 
 
@@ -438,18 +468,23 @@ class _ReplayTopK:
         return self.forced
 
 
-def self_check_vivit(model, clips, sd, cast, k):
+def self_check_vivit(model, clips, sd, cast, k, max_frames=None):
     """After the timed region: runs the timed model once more on the same resident batch (identical launches) and
     reads back clip 0's class embeddings and -- through the package's diagnostic INDEX_TAP -- clip 0's three gate index
     sets per block per frame.  The CPU oracle then replays clip 0 with THOSE index sets forced into its gates (so a
     near-tie decided the other way cannot fork the two states) while recording what its own top-k selects:
       * max_abs_err: class embeddings of every frame, HIP vs oracle;
       * index_sets_equal: the HIP set equals the oracle's own selection for every gate whose margin is >= margin_bar
-        (1e-3; 3e-3 with the bf16 A.v cast, whose rounding noise sits in the projection gate's input)."""
+        (1e-3; 3e-3 with the bf16 A.v cast, whose rounding noise sits in the projection gate's input);
+      * per_gate: the same counts per gate kind (qkv / projection / mlp) -- the projection gate's input carries the A.v
+        rounding noise and its margins are the small ones (median 1.7e-4).
+    max_frames: the oracle replays only the first frames of the clip (the short legs of the other workloads)."""
     from eventful_transformer import _native
 
     T, B = clips.shape[0], clips.shape[1]
-    dev = clips.device
+    if getattr(model, "graphs", None) is not None:   # a graph replay cannot call the index tap: check the eager launches
+        model.graphs.release()
+        model.graphs = None
     from eventful_transformer import blocks as evt_blocks
 
     taps = []   # (gate tag, clip 0's index list) in launch order: 3 per block per gated frame
@@ -473,6 +508,8 @@ def self_check_vivit(model, clips, sd, cast, k):
     x0 = clips[:, :1].cpu()
     bar = 1e-3 if cast is None else 3e-3
     worst, checked, equal_on_margin, equal_all, total = 0.0, 0, 0, 0, 0
+    per_gate = {g: {"total": 0, "equal": 0, "checked": 0, "equal_on_margin": 0} for g in ("qkv", "projection", "mlp")}
+    T = T if max_frames is None else min(T, max_frames)
     with torch.inference_mode():
         oracle.reset()
         for t in range(T):
@@ -490,9 +527,14 @@ def self_check_vivit(model, clips, sd, cast, k):
                     same = bool(torch.equal(pol.forced, pol.own))
                     total += 1
                     equal_all += same
+                    pg = per_gate[("qkv", "projection", "mlp")[gi]]
+                    pg["total"] += 1
+                    pg["equal"] += same
                     if pol.margin >= bar:
                         checked += 1
                         equal_on_margin += same
+                        pg["checked"] += 1
+                        pg["equal_on_margin"] += same
     # fp32: 1e-3 (north_star).  bf16 A.v cast: a different fp32 summation order flips single bf16 roundings (2^-9
     # relative) of A.v state elements, which persist in the state; over 12 blocks x T frames the class embedding
     # moves by ~1e-2 (the reference's own fp32-vs-bf16 gap on this model is 6.6e-2).
@@ -500,7 +542,7 @@ def self_check_vivit(model, clips, sd, cast, k):
     return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol,
             "gates_checked": checked, "index_sets_equal": bool(checked == equal_on_margin),
             "gates_total": total, "agreement_rate_all_margins": round(equal_all / total, 4) if total else None,
-            "margin_bar": bar,
+            "margin_bar": bar, "per_gate": per_gate,
             "mode": "CPU oracle replays clip 0 of the timed batch with the HIP index sets forced into its gates; its own "
                     "top-k must pick the same set wherever its margin >= bar",
             "ok": bool(worst <= tol and checked == equal_on_margin)}
@@ -580,6 +622,244 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def build_workload(name, device, world, rank, clips=256, total_clips=None, frames=None, k=None, cast_arg=None, threshold=1.0,
+                   streams=1):
+    """Model + resident synthetic data of one workload on this rank -> dict (model, data, sd, policy, ...)."""
+    kind, block_class, wl_frames, wl_k, cast, grid = WORKLOADS[name]
+    frames = frames if frames is not None else wl_frames
+    k = k if k is not None else wl_k
+    if cast_arg is not None:
+        cast = None if cast_arg in ("none", "fp32", "None") else cast_arg
+    if kind == "vitdet":
+        # `streams` video streams per GPU as ONE batch (top-k only: the threshold policy is batch-1, policies.py:25);
+        # videos shard over GPUs like clips
+        resident, total, scaling = streams, world * streams, "weak"
+    else:
+        resident = clips
+        total = 8 * resident if total_clips is None else total_clips
+        scaling = "strong" if total > 0 else "weak"
+        if total == 0:
+            total = world * resident
+    my_batches = batches_for_rank(total, world, rank, resident)
+    # weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective); the other ranks only
+    # allocate the same shapes
+    if kind == "vivit":
+        sd = seeded_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes().items()}
+    else:
+        sd = vitdet_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()}
+    if world > 1:
+        broadcast_weights(sd, {}, device, rank)
+    if kind == "vivit":
+        model = SpatialModel(sd, cast, k, device, block_class=block_class)
+        data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device) for b in my_batches]
+        policy = ("topk", k)
+    else:
+        from eventful_transformer import policies
+        if name == "vitdet672":
+            policy = ("topk", k)
+            model = DetModel(sd, cast, lambda: policies.TokenNormTopK(k=k), grid, device)
+            data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device, tokens=grid * grid) for b in my_batches]
+        else:
+            assert streams == 1, "the threshold policy is batch-1 (policies.py:25)"
+            policy = ("thr", threshold)
+            model = DetModel(sd, cast, lambda: policies.TokenNormThreshold(threshold=threshold), grid, device)
+            data = [threshold_stream(frames, 1000 + b[0], device, grid * grid) for b in my_batches]
+    return dict(name=name, kind=kind, block_class=block_class, frames=frames, k=k, cast=cast, grid=grid, resident=resident,
+                total=total, scaling=scaling, batches=my_batches, sd=sd, model=model, data=data, policy=policy)
+
+
+def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False):
+    """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + synchronize; max over ranks.
+    Returns (elapsed seconds, roofline dict or None)."""
+    from eventful_transformer import _native
+
+    model, data, kind = w["model"], w["data"], w["kind"]
+    if graphs:
+        model.use_graphs()
+        events_on = False
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        out = None
+        for clips in data:
+            out = model.clip(clips)
+        return out
+
+    timed_kernel = "gemm" if kind == "vivit" else "attn"
+    with torch.inference_mode():
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        events = [] if events_on else None
+        _native.set_kernel_events(timed_kernel, events)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        _native.set_kernel_events(timed_kernel, None)
+    if world > 1:
+        elapsed = max_over_ranks(elapsed, device)
+    roofline = None
+    if events:
+        ms = sum(ev[0].elapsed_time(ev[1]) for ev in events)
+        work = sum(ev[2] for ev in events)
+        launches = sum(ev[3] for ev in events)
+        if timed_kernel == "gemm":
+            achieved = work / (ms * 1e-3) / 1e12
+            split = _native.GEMM_MODE == "split"
+            # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
+            # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
+            # of `frac`; `mfma_issue_frac` = issued bf16 MFMA FLOP/s over the same peak (matrix-pipe utilisation).
+            peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            traffic, traffic_src, pmc_util = pmc_traffic(w["resident"], w["frames"], w["k"], w["cast"], _native.GEMM_MODE)
+            roofline = {"bound": "mfma", "kernel": _native.gemm_kernel_name() + " (evt_gated_linear / evt_gated_mlp)",
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_note": (f"HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), {traffic_src}"
+                                         if traffic_src else "no PMC file under profiles/ matches this tree's GEMM source: null"),
+                        "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
+                        "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
+                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+            if pmc_util:   # counter-measured (same PMC file): SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x 1024 SIMDs)
+                roofline.update(pmc_util)
+                roofline["mfma_util_note"] = ("matrix-pipe busy fraction of the launch's shader cycles at the sustained clock "
+                                              "(rocprofv3 PMC); mfma_issue_frac prices the same launches at the 2.4 GHz-spec peak")
+        else:
+            achieved = work / (ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "attn_stream_kernel / softmax_av_gated_kernel (global-block attention)",
+                        "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                        "algorithmic_bytes": "q, k read once + rel-pos terms + gate-reference columns read and rewritten + v pieces "
+                                             "+ A.v state RMW + fp32 output per launch (the N^2 score state is no longer kept)",
+                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+    return elapsed, roofline
+
+
+def release_workload(w):
+    """Drop a workload's model, data and the scratch pool (the next leg needs the memory)."""
+    from eventful_transformer import _native
+
+    for key in ("model", "data"):
+        w.pop(key, None)
+    _native.clear_scratch()
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def other_workload_leg(name, device, budget_s=12.0, cpu=True, **kw):
+    """One of the non-headline BASELINE configs, short (N = 1 only, after the headline's timed region): frames/s, the dominant
+    kernel's roofline fraction, an oracle check and a bounded CPU figure."""
+    t_start = time.perf_counter()
+    steps = kw.pop("steps", 3)
+    graphs = kw.pop("graphs", False)
+    w = build_workload(name, device, 1, 0, **kw)
+    try:
+        roofline_eager = None
+        if graphs and w["kind"] == "vitdet":   # a graph replay cannot bracket launches with events: dominant-kernel roofline from an eager step
+            _, roofline_eager = time_workload(w, 1, 1, 1, device)
+        elapsed, roofline = time_workload(w, steps, 1, 1, device, graphs=graphs)
+        roofline = roofline or roofline_eager
+        frames_total = w["total"] * w["frames"] * steps
+        leg = {"frames_s": round(frames_total / elapsed, 2), "ms_per_frame": round(elapsed / frames_total * 1e3, 4),
+               "steps": steps, "frames_per_step": w["total"] * w["frames"], "launch": "hip-graph replay" if graphs else "eager",
+               "config": f"{name}: {w['kind']} frames={w['frames']} k={w['k']} cast={w['cast']} resident={w['resident']}",
+               "roofline_frac": roofline["frac"] if roofline else None,
+               "roofline": ({kk: roofline[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us")} if roofline else None)}
+        if w["kind"] == "vitdet":
+            # per-frame latency protocol of scripts/time/vitdet_vid.py:28-55 (synchronised per frame), first / non-first
+            leg.update(vitdet_latency(w))
+            leg["check"] = self_check_vitdet(w)
+        else:
+            leg["check"] = self_check_vivit(w["model"], w["data"][0], w["sd"], w["cast"], w["k"], max_frames=6)
+        if cpu and time.perf_counter() - t_start < 3 * budget_s:
+            if w["kind"] == "vivit":
+                n8, el8 = _cpu_sample(w["sd"], w["cast"], w["k"], w["frames"], w["block_class"], min(8, usable_cores()), budget_s * 0.4)
+                leg["cpu_frames_s"] = round(n8 * w["frames"] / el8, 3)
+            else:
+                leg["cpu_frames_s"] = cpu_baseline_vitdet(w["sd"], w["cast"], w["policy"], w["grid"], w["data"][0][:2, :1].cpu())["value"]
+        leg["leg_seconds"] = round(time.perf_counter() - t_start, 1)
+        return leg
+    finally:
+        release_workload(w)
+
+
+def vitdet_latency(w):
+    """Device-synchronised wall clock per frame (scripts/time/vitdet_vid.py:28-55), eager and graph-replayed."""
+    from eventful_transformer.graphs import FrameGraphs
+
+    model, clips = w["model"], w["data"][0]
+    out = {}
+    for tag, runner in (("eager", model.net), ("graphs", FrameGraphs(model.net))):
+        times = []
+        with torch.inference_mode():
+            for rep in range(3):
+                if tag == "eager":
+                    model.reset()
+                else:
+                    runner.reset()
+                times = []
+                for t in range(clips.shape[0]):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    runner(clips[t])
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - t0)
+        nf = times[1:]
+        out[f"latency_ms_first_{tag}"] = round(times[0] * 1e3, 3)
+        out[f"latency_ms_non_first_{tag}"] = round(sum(nf) / len(nf) * 1e3, 3)
+        if tag == "graphs":
+            runner.release()
+    return out
+
+
+def self_check_vitdet(w, frames=3):
+    """Stream 0 of a ViTDet workload, first `frames` frames, HIP vs the CPU oracle: the backbone output (every 64th token)
+    and every gate's selected-token count per frame (top-k: the index sets themselves)."""
+    from eventful_transformer import blocks as evt_blocks
+
+    model, clips = w["model"], w["data"][0][:frames, :1]
+    taps = []
+    evt_blocks.INDEX_TAP = lambda _blk, tag, idx, count: taps.append((idx[0].clone(), None if count is None else count[:1].clone()))
+    outs = []
+    try:
+        with torch.inference_mode():
+            model.reset()
+            for t in range(frames):
+                outs.append(model.net(clips[t])[0, ::64].cpu())
+    finally:
+        evt_blocks.INDEX_TAP = None
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    bb, oblocks = vitdet_oracle_model(w["sd"], w["cast"], w["policy"], w["grid"])
+    worst, sets_equal, sets_total = 0.0, 0, 0
+    x_cpu = clips.cpu()
+    with torch.inference_mode():
+        for t in range(frames):
+            ref = bb.forward(x_cpu[t].clone())
+            worst = max(worst, float((outs[t] - ref[0, ::64]).abs().max()))
+            if t == 0:
+                continue
+            for bi, ob in enumerate(oblocks):
+                for gi, gname in enumerate(("qkv_index", "projection_index", "mlp_index")):
+                    idx, count = taps[((t - 1) * DEPTH + bi) * 3 + gi]
+                    want = ob.trace[gname].reshape(-1).sort()[0]
+                    n = int(count[0]) if count is not None else idx.numel()
+                    sets_total += 1
+                    sets_equal += bool(n == want.numel() and torch.equal(idx[:n].cpu().long(), want))
+    tol = 1e-3 if w["cast"] is None else 2e-3
+    return {"frames": frames, "max_abs_err": round(worst, 6), "tolerance": tol, "index_sets_equal": sets_equal,
+            "index_sets_total": sets_total, "mode": "free-running vs the CPU oracle (output tokens 0, 64, 128, ...; every gate's index set)",
+            "ok": bool(worst <= tol and sets_equal == sets_total)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -593,10 +873,12 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="backbone frames per clip (T)")
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--threshold", type=float, default=1.0, help="vitdet1024: TokenNormThreshold threshold")
+    ap.add_argument("--streams", type=int, default=1, help="vitdet672: video streams per GPU processed as one batch (top-k allows batch > 1)")
     ap.add_argument("--cast", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the EVT_GEMM=f32 side measurement")
+    ap.add_argument("--no-other", action="store_true", help="skip the short legs of the other BASELINE configs (other_workloads)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel's launches with HIP events")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the per-frame launches (small --clips: "
                     "host-bound otherwise); implies --no-kernel-events")
@@ -611,12 +893,6 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-
-    kind, block_class, frames, k, cast, grid = WORKLOADS[args.workload]
-    frames = args.frames if args.frames is not None else frames
-    k = args.k if args.k is not None else k
-    if args.cast is not None:
-        cast = None if args.cast in ("none", "fp32", "None") else args.cast
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -635,135 +911,59 @@ def main():
     _native.load()  # fail loudly here if the HIP library is missing
     log(f"library loaded, workload {args.workload}, world {world}")
 
-    # ---- clip set and its sharding ---------------------------------------------------------------------
-    if kind == "vitdet":
-        resident, total, scaling = 1, world, "weak"   # one video stream per GPU: videos shard like clips
-    else:
-        resident = args.clips
-        total = 8 * resident if args.total_clips is None else args.total_clips
-        scaling = "strong" if total > 0 else "weak"
-        if total == 0:
-            total = world * resident
-    my_batches = batches_for_rank(total, world, rank, resident)
-
-    # ---- weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective) ------
-    sd = seeded_state_dict() if kind == "vivit" else vitdet_state_dict()
-    if world > 1:
-        broadcast_weights(sd, {}, device, rank)
-    if kind == "vivit":
-        model = SpatialModel(sd, cast, k, device, block_class=block_class)
-        data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device) for b in my_batches]
-        policy = ("topk", k)
-    else:
-        from eventful_transformer import policies
-        if args.workload == "vitdet672":
-            policy = ("topk", k)
-            model = DetModel(sd, cast, lambda: policies.TokenNormTopK(k=k), grid, device)
-            data = [synthetic_clips(1, frames, k, 1000 + b[0], device, tokens=grid * grid) for b in my_batches]
-        else:
-            policy = ("thr", args.threshold)
-            model = DetModel(sd, cast, lambda: policies.TokenNormThreshold(threshold=args.threshold), grid, device)
-            data = [threshold_stream(frames, 1000 + b[0], device, grid * grid) for b in my_batches]
-    if args.graphs:
-        model.use_graphs()
-        args.no_kernel_events = True
+    w = build_workload(args.workload, device, world, rank, clips=args.clips, total_clips=args.total_clips, frames=args.frames,
+                       k=args.k, cast_arg=args.cast, threshold=args.threshold, streams=args.streams)
+    kind, block_class, frames, k, cast, grid = w["kind"], w["block_class"], w["frames"], w["k"], w["cast"], w["grid"]
+    model, data, sd, policy = w["model"], w["data"], w["sd"], w["policy"]
     log(f"model + {len(data)} resident batch(es) of synthetic clips ready")
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step():
-        out = None
-        for clips in data:
-            out = model.clip(clips)
-        return out
-
-    timed_kernel = "gemm" if kind == "vivit" else "attn"
-    with torch.inference_mode():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        log(f"{args.warmup} warm-up step(s) done")
-        events = None if args.no_kernel_events else []
-        _native.set_kernel_events(timed_kernel, events)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        _native.set_kernel_events(timed_kernel, None)
+    elapsed, roofline = time_workload(w, args.steps, args.warmup, world, device, events_on=not args.no_kernel_events, graphs=args.graphs)
     log(f"timed region: {args.steps} step(s) in {elapsed:.2f}s")
 
-    if world > 1:
-        elapsed = max_over_ranks(elapsed, device)
-    clips_per_step = total
+    clips_per_step = w["total"]
     frames_total = clips_per_step * frames * args.steps
     value = frames_total / elapsed
-
-    roofline = None
-    if events:
-        ms = sum(ev[0].elapsed_time(ev[1]) for ev in events)
-        work = sum(ev[2] for ev in events)
-        launches = sum(ev[3] for ev in events)
-        if timed_kernel == "gemm":
-            achieved = work / (ms * 1e-3) / 1e12
-            split = _native.GEMM_MODE == "split"
-            # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
-            # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
-            # of `frac`; `mfma_issue_frac` = issued bf16 MFMA FLOP/s over the same peak (matrix-pipe utilisation).
-            peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-            traffic, traffic_src, pmc_util = pmc_traffic(resident, frames, k, cast, _native.GEMM_MODE)
-            roofline = {"bound": "mfma", "kernel": _native.gemm_kernel_name() + " (evt_gated_linear / evt_gated_mlp)",
-                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_note": (f"HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), {traffic_src}"
-                                         if traffic_src else "no PMC file under profiles/ matches this tree's GEMM source: null"),
-                        "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
-                        "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
-                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
-            if pmc_util:   # counter-measured (same PMC file): SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x 1024 SIMDs)
-                roofline.update(pmc_util)
-                roofline["mfma_util_note"] = ("matrix-pipe busy fraction of the launch's shader cycles at the sustained clock "
-                                              "(rocprofv3 PMC); mfma_issue_frac prices the same launches at the 2.4 GHz-spec peak")
-        else:
-            achieved = work / (ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "softmax_av_gated_kernel / attn_dense_kernel (global-block attention)",
-                        "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
-                        "algorithmic_bytes": "N^2 state read once + gate-reference gather/scatter + A.v state RMW per launch",
-                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                        "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
-
+    ok = True
     line = None
     if rank == 0:
         wl = {"vivit": f"ViViT-B spatial {frames}x224^2 (N=197, D=768, 12 {block_class}s)" +
                        (f" top-k r={k}" if k else " dense") + f", T={frames} frames/clip incl. dense first frame, matmul_2_cast={cast}",
               "vitdet": f"ViTDet-B backbone {grid * 16}^2 (N={grid * grid}, 4 global EventfulBlocks + 8 windowed "
                         f"EventfulTokenwiseBlocks) policy={policy}, T={frames} frames/video incl. first, matmul_2_cast={cast}, "
-                        "one video stream per GPU"}[kind]
+                        f"{w['resident']} video stream(s) per GPU"}[kind]
         line = {
             "metric": METRIC if args.workload == "vivit16" else f"frames/sec/GPU {args.workload}",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None,
+            "scaling": w["scaling"], "vs_baseline": None,
             "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
                       (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
             "data": "synthetic", "per_gpu": round(value / world, 2),
-            "config": {"workload": wl, "clips_per_step": clips_per_step, "resident_clips_per_gpu": resident,
-                       "batches_per_gpu_per_step": len(my_batches), "frames_per_step": clips_per_step * frames,
+            "config": {"workload": wl, "clips_per_step": clips_per_step, "resident_clips_per_gpu": w["resident"],
+                       "batches_per_gpu_per_step": len(w["batches"]), "frames_per_step": clips_per_step * frames,
                        "parallelism": f"clip-sharded x{world} (clip i -> rank i mod {world})",
                        "launch": "hip-graph replay" if args.graphs else "eager"},
             "roofline": roofline,
         }
-    # ---- after the timed region, rank 0 at N = 1 only: self-check, exact-fp32 side number, CPU baseline ------
+    # ---- after the timed region, rank 0 at N = 1 only: self-checks, exact-fp32 side number, CPU baseline, other configs ----
     if rank == 0 and world == 1:
         if not args.no_check and kind == "vivit":
             line["check"] = self_check_vivit(model, data[0], sd, cast, k)
             log(f"self-check vs CPU oracle: {line['check']}")
+            ok = ok and line["check"]["ok"]
+            if cast is not None and k > 0:
+                # the same model in the reference's fp32 mode (no A.v cast), 4 clips: where north_star's 1e-3 / bit-exact bar holds
+                w32 = build_workload(args.workload, device, 1, 0, clips=4, total_clips=4, frames=frames, k=k, cast_arg="none")
+                try:
+                    line["check_fp32"] = self_check_vivit(w32["model"], w32["data"][0], w32["sd"], None, k)
+                finally:
+                    release_workload(w32)
+                log(f"self-check (fp32 mode) vs CPU oracle: {line['check_fp32']}")
+                ok = ok and line["check_fp32"]["ok"]
+        elif not args.no_check and kind == "vitdet":
+            line["check"] = self_check_vitdet(w)
+            line.update(vitdet_latency(w))
+            log(f"self-check vs CPU oracle: {line['check']}")
+            ok = ok and line["check"]["ok"]
         if not args.no_exact and kind == "vivit" and _native.GEMM_MODE == "split":
             line["exact_fp32_frames_s"] = exact_fp32_rate(model, data[0], frames)
             log(f"exact-fp32 arithmetic: {line['exact_fp32_frames_s']} frames/s")
@@ -773,11 +973,29 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_vivit(sd, cast, k, frames, args.workload, kind=block_class)
             else:
                 n_cpu = 3 if grid <= 42 else 2
-                line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu].cpu())
+                line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu, :1].cpu())
+        if not args.no_other and args.workload == "vivit16" and not args.graphs:
+            release_workload(w)
+            legs = {}
+            for name, kw in (("vivit16_B1_graphs", dict(workload="vivit16", clips=1, total_clips=1, graphs=True, steps=20)),
+                             ("vivit_dense", dict(clips=64, total_clips=64, steps=2)),
+                             ("vivit32", dict(clips=128, total_clips=128, steps=2)),
+                             ("vitdet672", dict(steps=5, graphs=True)),
+                             ("vitdet672_S8", dict(workload="vitdet672", streams=8, steps=3)),
+                             ("vitdet1024", dict(steps=3, graphs=True))):
+                wl_name = kw.pop("workload", name)
+                try:
+                    legs[name] = other_workload_leg(wl_name, device, cpu=not args.no_cpu_baseline, **kw)
+                except Exception as exc:   # a leg must not take the headline line down
+                    legs[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                log(f"other workload {name}: {legs[name]}")
+            line["other_workloads"] = legs
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        sys.exit(3)   # a failed self-check is a failed run
 
 
 def exact_fp32_rate(model, clips, frames):
@@ -807,7 +1025,8 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.init_process_group(args.backend)
     dev = torch.device("cpu")
-    sd = {"w": torch.full((4,), float(rank + 1))}
+    # rank 0 generates the weights, every other rank only allocates the shapes and receives them (as build_workload does)
+    sd = {"w": torch.full((4,), 1.0)} if rank == 0 else {"w": torch.zeros(4)}
     if world > 1:
         broadcast_weights(sd, {}, dev, rank)
     total = 8 * args.clips if args.total_clips is None else args.total_clips
@@ -822,14 +1041,19 @@ def dry_run(args, world, rank):
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = max_over_ranks(elapsed, dev)
-        counts = [None] * world
+        counts, batches, covers = [None] * world, [None] * world, [None] * world
         dist.all_gather_object(counts, sum(len(b) for b in mine))
+        dist.all_gather_object(batches, [len(b) for b in mine])
+        dist.all_gather_object(covers, [c for b in mine for c in b])
     else:
-        counts = [sum(len(b) for b in mine)]
+        counts, batches, covers = [sum(len(b) for b in mine)], [[len(b) for b in mine]], [[c for b in mine for c in b]]
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "value": round(total * args.steps / elapsed, 2), "unit": "clips/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling,
-                          "clips_per_rank": counts, "weights_from_rank0": bool(float(sd["w"][0]) == 1.0),
+                          "clips_per_rank": counts, "batches_per_rank": batches,
+                          "disjoint_cover": sorted(c for cv in covers for c in cv) == list(range(total)),
+                          "config": {"clips_per_step": total, "resident_clips_per_gpu": args.clips},
+                          "weights_from_rank0": bool(float(sd["w"][0]) == 1.0),
                           "ms_per_step": round(elapsed / args.steps * 1e3, 3)}), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -79,3 +79,40 @@ def test_batches_for_rank_cover_the_clip_set():
                 assert 0 < len(b) <= resident and all(c % world == r for c in b)
                 seen += b
         assert sorted(seen) == list(range(total))
+
+
+def _dry_run(gpus, *extra):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
+                          "--dry-run", "--backend", "gloo"] + list(extra), capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_eight_rank_dry_run_is_the_strong_scaling_split_of_the_one_rank_run():
+    """The driver's scaling curve compares N = 1, 2, 4, 8 like for like: the SAME clip set (config.clips_per_step) at every
+    N.  World size 8 over gloo with the bench's default sizes (2048 clips, 256 resident): one resident batch per rank, a
+    disjoint cover of the set, weights generated on rank 0 only and received by the others, ONE JSON line."""
+    one = _dry_run(1, "--clips", "256", "--total-clips", "2048")
+    eight = _dry_run(8, "--clips", "256", "--total-clips", "2048")
+    assert one["config"]["clips_per_step"] == eight["config"]["clips_per_step"] == 2048
+    assert one["scaling"] == eight["scaling"] == "strong"
+    assert one["batches_per_rank"] == [[256] * 8] and eight["batches_per_rank"] == [[256]] * 8
+    assert one["disjoint_cover"] and eight["disjoint_cover"]
+    assert eight["n_gpus"] == 8 and eight["clips_per_rank"] == [256] * 8 and eight["weights_from_rank0"] is True
+
+
+def test_only_rank0_generates_weights():
+    """build_workload: ranks other than 0 allocate the state_dict's shapes without generating values (they are overwritten
+    by the flat broadcast); the shape tables match the generators key for key."""
+    import bench
+
+    for gen, shapes in ((bench.seeded_state_dict, bench.seeded_state_dict_shapes), (bench.vitdet_state_dict, bench.vitdet_state_dict_shapes)):
+        a, b = gen(), shapes()
+        assert list(a) == list(b)
+        assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)

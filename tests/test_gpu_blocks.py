@@ -133,8 +133,8 @@ def _grab_index_sets(bb, k, sink):
     return [blk.register_forward_hook(grab) for blk in bb.blocks]
 
 
-@pytest.mark.parametrize("fixture,k,mode,cast,tol", [("vivit_b.npz", 128, "fp32", None, 1e-3), ("vivit_b.npz", 128, "bf16", "bfloat16", 1e-1),
-                                                     ("vivit_b_k64.npz", 64, "fp32", None, 1e-3), ("vivit_b_k64.npz", 64, "bf16", "bfloat16", 2e-1)])
+@pytest.mark.parametrize("fixture,k,mode,cast,tol", [("vivit_b.npz", 128, "fp32", None, 1e-3), ("vivit_b.npz", 128, "bf16", "bfloat16", None),
+                                                     ("vivit_b_k64.npz", 64, "fp32", None, 1e-3), ("vivit_b_k64.npz", 64, "bf16", "bfloat16", None)])
 def test_vivit_b_full_size(golden_dir, fixture, k, mode, cast, tol):
     """ViViT-B spatial model, 197 tokens, 12 EventfulBlocks, B=1, FREE-RUNNING against the reference's golden
     class-token features and gate index sets: BASELINE config 2 (k=128, 6 frames) and config 4's shape (k=64,
@@ -175,15 +175,29 @@ def test_vivit_b_full_size(golden_dir, fixture, k, mode, cast, tol):
         h.remove()
     print(f"\n[free-running {fixture} {mode}] index-set agreement {agree}/{total} = {agree / total:.4f}; "
           f"margin>=1e-3: {strict_ok}/{strict}; max feature error {worst:.3e}")
-    # fp32: free-running features track the reference to 1e-3.  bf16 A.v cast: gate decisions with margins down to
-    # 1e-9 flip under ANY rounding-order change and each flip moves features by O(1e-2) (the reference's own
-    # fp32-vs-bf16 gap on this model is 6.6e-2); the strict bf16 check is the teacher-forced test.
-    # Identical sets wherever the margin is >= 1e-3 are REQUIRED in fp32 mode.  With the bf16 A.v cast a free run
-    # forks at the first near-tie (reference margins go down to 1e-9) and the states then differ by bf16 ulps, so
-    # later sets differ too; there the rate is reported and the strict check is the teacher-forced test.
+    # The bar is the reference's OWN free-running divergence when only the fp32 summation order changes (1, 2, 4 vs 8 ATen
+    # threads; oracle/gen_golden.py::gen_envelope -> tests/golden/envelope.npz) -- a different summation order is exactly what
+    # a GPU kernel is.  fp32: the reference agrees with itself on 100 % of the index sets to 3e-6; so must the HIP path (to
+    # 1e-3 on features, north_star).  bf16 A.v cast: every flipped bf16 rounding of an A.v state element persists and
+    # gates with margins down to 1e-9 fork; the reference then agrees with itself on 74-82 % of all sets (k = 128: 100 %
+    # of the sets with margin >= 1e-3; k = 64, 31 gated frames: 86-87 %) with feature gaps of 6.7e-2 / 8.2e-2.  The HIP
+    # path (split-precision GEMMs: 1e-5 instead of 1e-6 relative on top of the reordering) must stay within 0.12 of the
+    # reference's lowest self-agreement over all gates, within 0.06 on the margin >= 1e-3 subset, and within 1.5 x its
+    # largest feature gap; the strict bf16 check is the teacher-forced test below.
+    env = H.load_npz(os.path.join(golden_dir, "envelope.npz"))
+    tag = "k128" if k == 128 else "k64"
+    ref_all = float(env[f"{tag}__{mode}__agreement_all"].min())
+    ref_strict = float(env[f"{tag}__{mode}__agreement_margin_1e-3"].min())
+    ref_gap = float(env[f"{tag}__{mode}__feature_gap"].max())
+    print(f"    reference vs itself (1/2/4 vs 8 threads): agreement >= {ref_all:.4f}, margin>=1e-3 >= {ref_strict:.4f}, "
+          f"feature gap <= {ref_gap:.3e}")
     if cast is None:
-        assert strict_ok == strict and strict >= total // 2, (strict_ok, strict, total)
-    assert worst <= tol, (mode, worst)
+        assert ref_all == 1.0 and strict_ok == strict and strict >= total // 2, (strict_ok, strict, total)
+        assert worst <= tol, (mode, worst)
+    else:
+        assert agree / total >= ref_all - 0.12, (agree, total, ref_all)
+        assert strict_ok / strict >= ref_strict - 0.06, (strict_ok, strict, ref_strict)
+        assert worst <= 1.5 * ref_gap, (mode, worst, ref_gap)
 
 
 def test_vivit_b_dense_config1():
@@ -298,6 +312,7 @@ def _vitdet_run(golden_dir, fixture, grid, policy_cls, policy_kw, cast, stream_f
         for t in range(want.shape[0]):
             y = bb(xs[t].to(DEV))[:, ::stride].cpu()
             worst.append(float((y - want[t]).abs().max()))
+    print(f"\n[{fixture}] max |out - reference| per frame: {[f'{w:.2e}' for w in worst]} (tolerance {tol:.0e})")
     assert max(worst) <= tol, worst
     return g, bb
 
@@ -311,19 +326,58 @@ def test_vitdet_672_topk(golden_dir):
                 16, 1e-3)
 
 
-def test_vitdet_1024_threshold(golden_dir):
-    """BASELINE config 5: ViTDet-B backbone 1024^2 (N=4096, windows padded 64->70), threshold policy with
-    data-dependent r per gate (409 / 0 / 409 here) kept on the device, global blocks bf16 A.v cast."""
+@pytest.mark.parametrize("thr,fixture", [(1.0, "vitdet_1024.npz"), (0.2, "vitdet_1024_thr0.2.npz"), (5.0, "vitdet_1024_thr5.npz")])
+def test_vitdet_1024_threshold(golden_dir, thr, fixture):
+    """BASELINE config 5: ViTDet-B backbone 1024^2 (N=4096, windows padded 64->70), threshold policy with data-dependent r
+    per gate kept on the device, global blocks bf16 A.v cast -- at all three thresholds of
+    configs/evaluate/vitdet_vid/threshold_1024.yml:5, free-running against the reference's golden output slices (1e-3),
+    EVERY gate's count and the last block's index list."""
     from eventful_transformer import _native
-    g, bb = _vitdet_run(golden_dir, "vitdet_1024.npz", 64, "TokenNormThreshold", dict(threshold=1.0), "bfloat16",
-                        lambda steps, seed: O.make_threshold_stream(64 * 64, 768, steps, seed + 2), 64, 2e-3)
-    # the last block's three gate counts are still in scratch: compare with the reference's counts
+    from eventful_transformer import blocks as evt_blocks
+    counts = []
+    evt_blocks.INDEX_TAP = lambda _blk, tag, idx, count: counts.append(count[:1].clone())
+    try:
+        g, bb = _vitdet_run(golden_dir, fixture, 64, "TokenNormThreshold", dict(threshold=thr), "bfloat16",
+                            lambda steps, seed: O.make_threshold_stream(64 * 64, 768, steps, seed + 2), 64, 1e-3)
+    finally:
+        evt_blocks.INDEX_TAP = None
+    assert float(g["threshold"]) == thr
+    got_all = np.asarray([int(c.cpu()[0]) for c in counts]).reshape(-1, 12, 3)   # (gated frames, blocks, gates)
+    assert np.array_equal(got_all, g["counts"]), (got_all, g["counts"])
+    print(f"    gate counts (qkv, projection, mlp) of the last block: {got_all[-1, -1].tolist()}; range {got_all.min()}..{got_all.max()}")
+    # the last block's index list is still in scratch
     dev0 = torch.device(DEV, 0)
-    want = g["counts"][-1, -1]
-    got = [int(_native.scratch(f"cnt_{n}", (1,), torch.int32, dev0).cpu()[0]) for n in ("qkv", "projection", "mlp")]
-    assert got == want.tolist(), (got, want)
-    idx = _native.scratch("idx_mlp", (1, 4096), torch.int32, dev0).cpu()[0, : got[2]].numpy()
+    n_mlp = int(got_all[-1, -1, 2])
+    idx = _native.scratch("idx_mlp", (1, 4096), torch.int32, dev0).cpu()[0, :n_mlp].numpy()
     assert np.array_equal(idx.astype(np.int64), g[f"idx_1_11_mlp_index"].reshape(-1).astype(np.int64))
+
+
+def test_forward_hooks_see_tensors(golden_dir):
+    """Block chaining (blocks.PendingSum) is backbone-internal: a forward hook on a block -- the reference's users inspect
+    block outputs that way -- receives a plain tensor, and hooking does not change the backbone's output."""
+    from eventful_transformer import policies
+    sd = H.backbone_params(3, 64, 4, 5, 37)
+    from eventful_transformer.backbones import ViTBackbone
+    cfg = dict(dim=64, heads=4, mlp_ratio=4)
+    outs = []
+    for hooked in (False, True):
+        bb = ViTBackbone(block_config=cfg, depth=3, position_encoding_size=(6, 6), input_size=(6, 6), block_class="EventfulBlock",
+                         has_class_token=True)
+        bb.load_state_dict(sd, strict=True)
+        bb = bb.eval().to(DEV)
+        H.set_policies(bb, policies.TokenNormTopK, k=12)
+        seen = []
+        if hooked:
+            bb.blocks[1].register_forward_hook(lambda m, i, o: seen.append((type(i[0]), type(o))))
+            bb.blocks.register_forward_hook(lambda m, i, o: seen.append(("container", type(o))))
+        xs = O.make_token_stream(2, 37, 64, 3, 12, seed=6, small=0.02)
+        with torch.inference_mode():
+            ys = [bb(xs[t].to(DEV)).cpu() for t in range(3)]
+        outs.append(ys)
+        if hooked:
+            assert len(seen) == 6 and all(t is torch.Tensor for pair in seen for t in pair if t != "container"), seen
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_pooled_block_batch_is_per_clip():
