@@ -10,10 +10,11 @@
 // in LDS for the softmax (rows never leave the CU), V^T chunks reuse the K region for P.V.  Scores, probabilities and
 // the per-head values are never written to HBM unless the caller asks for the states.
 //
-// Arithmetic is that of the unfused kernels (K4 / K5 / K6): fp32-input MFMA for S (exact fp32 products), expf,
+// Arithmetic is that of the unfused kernels (K4 / K5 / K6): S on the fp32-input MFMA (exact fp32 products) or, with qk_split,
+// on the bf16 hi/lo split MFMA like evt_qk's split mode (three bf16 MFMAs per product, 16x the rate); expf,
 // probabilities and values rounded to the store type T, P.V on the T-input MFMA (fp32: 32x32x2; bf16 / fp16: 32x32x16),
 // result rounded to T.
-#include "evt_common.h"
+#include "evt_linear.h"   // split4 (fp32 -> bf16 hi / lo), bf16x8_t
 
 #ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/attn_prof.py --dense)
 __device__ unsigned long long evt_prof_dense_buf[8];
@@ -24,7 +25,6 @@ __device__ unsigned long long evt_prof_dense_buf[8];
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int AR = 32;     // query rows per workgroup
@@ -40,6 +40,14 @@ struct DenseArgs {
   int G, H, N, D, gh, gw, qw;
   float scale;
 };
+
+// SPLIT: S = (q / scale) k^T and the rel-pos terms on v_mfma_f32_16x16x32_bf16 with q, k and the rel-pos tables as bf16
+// hi + lo (three MFMAs per product, ~1e-5 relative -- the arithmetic of evt_qk / evt_softmax_av_gated / evt_attention_stream in
+// split mode) instead of exact fp32 products on v_mfma_f32_16x16x4_f32 at 1/16 of the rate.  In-kernel phase timing of the
+// ViTDet window launch (9 windows x 12 heads, 196 tokens, scripts/attn_prof.py --dense window) before: rel-pos dots 40 % of a
+// workgroup's life (per-table-row VALU dots with DPP reductions), q.k^T 17 %.  With SPLIT the rel-pos terms are ONE more
+// score product: the tile's q rows against the (<= 4 gh + qw gw) table rows it can meet as "virtual keys", table
+// fragments loaded straight from L2, each product written to the row's (ky | kx) slot when the table row is that row's.
 
 // P.V over keys [0, len) of the staged chunk (len % 16 == 0): a = P row of this lane, b = V^T row of this lane.
 template <typename T> struct PvSweep;
@@ -85,8 +93,11 @@ __host__ __device__ inline int dense_tile_floats(int N) {                       
 }
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
+// Three workgroups per CU (the 49 KB of LDS allow it): at most 168 registers per lane INCLUDING the 16 AGPRs of the P.V
+// accumulator -- at 154 + 16 the kernel ran two, and the 756 workgroups of a 672^2 frame took two rounds (48.7 us; 504
+// workgroups: 28.7 us).
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256, 3) void attn_dense_kernel(const DenseArgs a) {
   constexpr int TPF = 4 / (int)sizeof(T);       // T elements per float slot
   constexpr int VP = KC + 16 / (int)sizeof(T);  // V^T pitch in T elements (16-byte pad)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -185,8 +196,126 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
   }
   __syncthreads();
   DN_TICK(0);   // q rows + K chunk 0 staged
-  if (KC < a.N) load_k(KC, kr);   // K chunk 1 flies during the rel-pos dots and the first MFMA sweep
-  if (rel) {
+  // ---- q MFMA fragments -> registers, scaled: q / self.scale (blocks.py:514); a power-of-two scale makes the
+  //      reciprocal multiply exact.  Exact mode, 16x16x4 tiles: lane = (row l15 of a 16-row half, k group kg of 16 channels).
+  //      SPLIT, 16x16x32 bf16 tiles: k-block m holds channels 32 m + 8 kg .. + 8 as bf16 hi and lo.
+  const int l15 = lane & 15, kg = lane >> 4;
+  const float inv_scale = 1.0f / a.scale;
+  const bool pow2 = (inv_scale * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+  float4 qf[2][4];
+  bf16x8_t qh[2][2], ql[2][2];
+  {
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int ch = SPLIT ? 32 * (m >> 1) + 8 * kg + 4 * (m & 1) : kg * 16 + 4 * m;
+        float4 q = *reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QP + ch);
+        if (pow2) { q.x *= inv_scale; q.y *= inv_scale; q.z *= inv_scale; q.w *= inv_scale; }
+        else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
+        qf[hr][m] = q;
+      }
+    if (SPLIT) {
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          bf16x4_t h0, l0, h1, l1;
+          split4(qf[hr][2 * m], &h0, &l0);
+          split4(qf[hr][2 * m + 1], &h1, &l1);
+          qh[hr][m] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          ql[hr][m] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+  }
+  // (q / scale) . b for the 16 "keys" whose channel pieces (4 x float4 in this lane's fragment layout) are in kf
+  auto scores16 = [&](const float4* kf, f32x4_acc* acc) __attribute__((always_inline)) {
+    acc[0] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+    if (!SPLIT) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, kf[m].x, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, kf[m].y, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, kf[m].z, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, kf[m].w, acc[hr], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        bf16x4_t h0, l0, h1, l1;
+        split4(kf[2 * m], &h0, &l0);
+        split4(kf[2 * m + 1], &h1, &l1);
+        const bf16x8_t kh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), kl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr) {
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[hr][m], kh, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kl, acc[hr], 0, 0, 0);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kh, acc[hr], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto frag_chan = [&](int m) __attribute__((always_inline)) { return SPLIT ? 32 * (m >> 1) + 8 * kg + 4 * (m & 1) : kg * 16 + 4 * m; };
+  if (KC < a.N) load_k(KC, kr);   // K chunk 1 flies during the rel-pos terms and the first MFMA sweep
+  if (rel && SPLIT && pow2) {
+    // rel-pos terms (utils.py:159-168: UNSCALED q . table row) as one more score product: "virtual keys" = the table rows
+    // rel_y[y][ky] of the <= 4 query-grid rows y this tile touches, then all rel_x[x][kx].  q / scale is a power-of-two
+    // multiple of q, so scale * ((q / scale) . t) is the same fp32 value as q . t computed this way.  Wave w owns the
+    // 16-row groups w, w + 4, ...; lane (l15, kg) loads its table row's channel pieces straight from L2.
+    const int i_hi = min(i0 + AR, a.N) - 1;
+    const int y_lo = i0 / a.qw, ny = i_hi / a.qw - y_lo + 1;
+    const int ycnt = ny * a.gh, vtot = ycnt + a.qw * a.gw;
+    const float* ytab = a.rel_y + (int64_t)y_lo * a.gh * DH;
+    const float inv_gh = 1.0f / (float)a.gh, inv_gw_ = 1.0f / (float)a.gw, inv_qw = 1.0f / (float)a.qw;
+    int ry_[2][4], rx_[2][4];   // grid coordinates of the lane's 8 rows (row 16 hr + 4 kg + r), -1 past the group
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * hr + 4 * kg + r;
+        const int yi = fast_div(i, inv_qw);
+        ry_[hr][r] = i < a.N ? yi : -1;
+        rx_[hr][r] = i < a.N ? i - yi * a.qw : -1;
+      }
+    auto load_t = [&](int vg, float4* tf) __attribute__((always_inline)) {
+      const int v = min(vg * 16 + l15, vtot - 1);
+      const float* row = v < ycnt ? ytab + (int64_t)v * DH : a.rel_x + (int64_t)(v - ycnt) * DH;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) tf[m] = *reinterpret_cast<const float4*>(row + frag_chan(m));
+    };
+    auto consume_t = [&](int vg, const float4* tf) __attribute__((always_inline)) {
+      f32x4_acc acc[2];
+      scores16(tf, acc);
+      const int v = vg * 16 + l15;
+      if (v < vtot) {
+        const bool isy = v < ycnt;
+        const int x = isy ? v : v - ycnt;
+        const int sel = isy ? fast_div(x, inv_gh) : fast_div(x, inv_gw_);          // table's grid row offset / grid column
+        const int e = isy ? x - sel * a.gh : a.gh + x - sel * a.gw;                // slot in the row's (ky | kx) list
+#pragma unroll
+        for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool mine = isy ? (ry_[hr][r] == y_lo + sel) : (rx_[hr][r] == sel);
+            if (mine) relv[(16 * hr + 4 * kg + r) * nrel + e] = acc[hr][r] * a.scale;
+          }
+      }
+    };
+    const int ngrp = (vtot + 15) / 16;
+    float4 tA[4], tB[4];
+    if (wave < ngrp) load_t(wave, tA);
+    for (int vg = wave; vg < ngrp; vg += 8) {
+      if (vg + 4 < ngrp) load_t(vg + 4, tB);
+      consume_t(vg, tA);
+      if (vg + 4 < ngrp) {
+        if (vg + 8 < ngrp) load_t(vg + 8, tA);
+        consume_t(vg + 4, tB);
+      }
+    }
+  } else if (rel) {
     // rel-pos terms of the 32 rows (utils.py:159-168), per TABLE ROW: (yi, ky) for the <= 32/qw + 2 query grid rows
     // the tile touches, then (xi, kx) for every xi.  A 16-lane DPP row owns one 256-byte table row (one coalesced
     // 16-byte load per lane, fetched once per workgroup) and dots it with the raw q rows that use it -- those with
@@ -237,23 +366,6 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
       }
     }
   }
-  // ---- q MFMA fragments -> registers, scaled: q / self.scale (blocks.py:514); a power-of-two scale makes the
-  //      reciprocal multiply exact.  16x16x4 tiles: lane = (row l15 of a 16-row half, k group kg of 16 channels).
-  const int l15 = lane & 15, kg = lane >> 4;
-  float4 qf[2][4];
-  {
-    const float inv = 1.0f / a.scale;
-    const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
-#pragma unroll
-    for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float4 q = *reinterpret_cast<const float4*>(Qs + (hr * 16 + l15) * QP + kg * 16 + 4 * m);
-        if (pow2) { q.x *= inv; q.y *= inv; q.z *= inv; q.w *= inv; }
-        else { q.x /= a.scale; q.y /= a.scale; q.z /= a.scale; q.w /= a.scale; }
-        qf[hr][m] = q;
-      }
-  }
   __syncthreads();   // rel-pos dots and fragment reads are done: the q tile's storage becomes the score tile
   DN_TICK(1);   // rel-pos dots, q fragments
 
@@ -268,19 +380,12 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
     else load_v(0, vr);                                        // last K chunk: V chunk 0 flies from here through the softmax
     const int n0 = c0 + wave * 16;
     if (n0 < a.N) {  // wave-uniform
-      f32x4_acc acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      const float* kb = Ks + (wave * 16 + l15) * QP + kg * 16;
+      f32x4_acc acc[2];
+      const float* kb = Ks + (wave * 16 + l15) * QP;
+      float4 kf[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float4 fb = *reinterpret_cast<const float4*>(kb + 4 * m);
-#pragma unroll
-        for (int hr = 0; hr < 2; ++hr) {
-          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].x, fb.x, acc[hr], 0, 0, 0);
-          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].y, fb.y, acc[hr], 0, 0, 0);
-          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].z, fb.z, acc[hr], 0, 0, 0);
-          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][m].w, fb.w, acc[hr], 0, 0, 0);
-        }
-      }
+      for (int m = 0; m < 4; ++m) kf[m] = *reinterpret_cast<const float4*>(kb + frag_chan(m));
+      scores16(kf, acc);
       const int j = n0 + l15;
       if (j < a.N) {
 #pragma unroll
@@ -418,12 +523,17 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(const DenseArgs a) {
 }
 
 template <typename T>
-int launch_dense(const DenseArgs& a, void* stream) {
+int launch_dense(const DenseArgs& a, int split, void* stream) {
   const size_t lds = ((size_t)KC * QP + (size_t)dense_tile_floats(a.N) + (size_t)AR * (a.gh + a.gw) + a.N) * sizeof(float);
   const dim3 grid((a.N + AR - 1) / AR, a.G * a.H);
   if (grid.y == 0) return EVT_OK;
-  EVT_ALLOW_LDS(attn_dense_kernel<T>, lds);
-  hipLaunchKernelGGL(attn_dense_kernel<T>, grid, dim3(256), lds, evt_stream(stream), a);
+  if (split) {
+    EVT_ALLOW_LDS((attn_dense_kernel<T, true>), lds);
+    hipLaunchKernelGGL((attn_dense_kernel<T, true>), grid, dim3(256), lds, evt_stream(stream), a);
+  } else {
+    EVT_ALLOW_LDS((attn_dense_kernel<T, false>), lds);
+    hipLaunchKernelGGL((attn_dense_kernel<T, false>), grid, dim3(256), lds, evt_stream(stream), a);
+  }
   return evt_check_launch("evt_attention_dense");
 }
 
@@ -450,8 +560,16 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
   DenseArgs a{d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row, d->out_f32, d->product, d->a_state, d->pv,
               d->tok_map ? d->groups_per_clip : 1, d->tok_map ? d->clip_rows : d->N, d->G, d->H, d->N, d->D,
               d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale};
-  EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, stream); });
+  EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, d->qk_split, stream); });
   return EVT_OK;
+}
+
+// Diagnostic: resident workgroups per CU the runtime reports for the fp32-store K8 kernel with `lds` bytes of dynamic LDS.
+extern "C" __attribute__((visibility("default"))) int evt_debug_dense_occupancy(int split, int lds) {
+  int n = -1;
+  if (split) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_dense_kernel<float, true>, 256, (size_t)lds);
+  else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_dense_kernel<float, false>, 256, (size_t)lds);
+  return n;
 }
 
 #ifdef EVT_PROF

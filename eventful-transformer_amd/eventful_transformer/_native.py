@@ -100,6 +100,7 @@ class AttnDenseDesc(Structure):
         ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("clip_rows", c_int32), ("pad_row", c_void_p),
         ("out_f32", c_void_p), ("product", c_void_p), ("a_state", c_void_p), ("pv", c_void_p),
         ("G", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("scale", c_float), ("store", c_int32),
+        ("qk_split", c_int32),
     ]
 
 
@@ -478,10 +479,11 @@ def attention_dense_fits(N, D, H):
 
 
 def attention_dense(qkv, G, H, N, D, scale, store, out_f32=None, rel_y=None, rel_x=None, gh=0, gw=0, qw=0, tok_map=None,
-                    groups_per_clip=1, clip_rows=0, pad_row=None, product=None, a_state=None, pv=None):
+                    groups_per_clip=1, clip_rows=0, pad_row=None, product=None, a_state=None, pv=None, qk_split=None):
     """K8: q.k^T + rel-pos + softmax + A.v of whole groups in one launch (scores never reach HBM)."""
     d = AttnDenseDesc(_p(qkv), _p(rel_y), _p(rel_x), gh, gw, qw, _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
-                      _p(out_f32), _p(product), _p(a_state), _p(pv), G, H, N, D, float(scale), store)
+                      _p(out_f32), _p(product), _p(a_state), _p(pv), G, H, N, D, float(scale), store,
+                      int(QK_SPLIT if qk_split is None else qk_split))
     es = 4 if store == EVT_F32 else 2
     work = G * (12.0 * N * D + 4.0 * N * D) + (G * H * N * N * (4.0 + es) + G * N * D * es if product is not None else 0.0)
     if product is not None:   # only the state-producing (global-block) form is part of the "attn" family

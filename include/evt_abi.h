@@ -35,7 +35,7 @@ extern "C" {
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
-                                 5: evt_attention_stream */
+                                 5: evt_attention_stream, evt_attn_dense_desc.qk_split */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -427,6 +427,8 @@ typedef struct evt_attn_dense_desc {
   int32_t G, H, N, D;                     /* G groups of N tokens                                 */
   float scale;
   int32_t store;
+  int32_t qk_split;                       /* ABI 5: 1 = q, k and the rel-pos tables as bf16 hi + lo on the matrix cores (3 bf16  */
+                                          /* MFMAs per product, ~1e-5 relative, like evt_qk split); 0 = exact fp32 products      */
 } evt_attn_dense_desc;
 
 EVT_API int evt_attention_dense(const evt_attn_dense_desc* d, void* stream);
