@@ -531,7 +531,7 @@ def test_fused_attention_in_kernel_qk(cast, N, k, rel, qk_split):
         bd, idxd = buf.to(DEV), idx.int().to(DEV)
         relkw = dict(rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=gh, gw=gw) if rel else {}
         if t == 0:
-            n.attention_dense(bd, B, H, N, D, scale, store, out_f32=out, a_state=ap, pv=pv, qw=gw, **relkw)
+            n.attention_dense(bd, B, H, N, D, scale, store, out_f32=out, a_state=ap, pv=pv, qw=gw, qk_split=qk_split, **relkw)
             n.v_gate(bd, None, None, B, N, D, 0, vp, None, None, store, False)
         else:
             cap = k if (t != 2 or k == N) else k + 5
