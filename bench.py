@@ -860,6 +860,92 @@ def self_check_vitdet(w, frames=3):
             "ok": bool(worst <= tol and sets_equal == sets_total)}
 
 
+def wrapper_legs(device):
+    """End-to-end timing of the model wrappers around the backbone (parity: tests/test_gpu_models.py):
+    `FactorizedViViT` (uint8 clip -> class probabilities: tubelet embedding, 16 gated spatial steps x 2 temporal views, temporal
+    model, classifier; protocol of scripts/time/vivit_epic_kitchens.py:23-45) and ViTDet's pre-backbone (preprocessing + patch
+    embedding) and post-backbone (SimplePyramid) around the 672^2 backbone (scripts/time/vitdet_vid.py:33-45)."""
+    from eventful_transformer import policies
+    from models.vitdet import ViTDet
+    from models.vivit import FactorizedViViT
+
+    def seeded(module, seed, std=0.02):
+        rs = np.random.RandomState(seed)
+        sd = {}
+        for name, p_ in sorted(module.state_dict().items()):
+            v = (rs.standard_normal(tuple(p_.shape)) * std).astype(np.float32)
+            if "layer_norm.weight" in name or (name.endswith(".weight") and p_.ndim == 1):
+                v = (1.0 + rs.standard_normal(tuple(p_.shape)) * 0.05).astype(np.float32)
+            sd[name] = torch.from_numpy(v)
+        return sd
+
+    out = {}
+    cfg = dict(classes=400, input_shape=[32, 3, 224, 224], normalize_mean=0.45, normalize_std=0.225, spatial_views=1,
+               temporal_stride=2, temporal_views=2, tubelet_shape=[2, 16, 16],
+               spatial_config=dict(depth=12, position_encoding_size=[14, 14], block_config=dict(dim=768, heads=12, mlp_ratio=4),
+                                   block_class="EventfulBlock"),
+               temporal_config=dict(depth=4, position_encoding_size=[16], block_config=dict(dim=768, heads=12, mlp_ratio=4)))
+    model = FactorizedViViT(**cfg)
+    model.load_state_dict(seeded(model, 5), strict=True)
+    model = model.eval().to(device)
+    set_policies(model, lambda: policies.TokenNormTopK(k=128))
+    g = torch.Generator(device=device).manual_seed(11)
+    clips = torch.randint(0, 256, (8, 80, 3, 224, 224), dtype=torch.uint8, device=device, generator=g)   # 8 videos of 80 frames
+    with torch.inference_mode():
+        model(clips[:1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(clips.shape[0]):
+            probs = model(clips[i:i + 1])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        model(clips)   # the 8 videos as ONE batch (16 view streams of per-clip state)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(clips)
+        torch.cuda.synchronize()
+        el8 = time.perf_counter() - t0
+    out["vivit_e2e"] = {"clips_s": round(clips.shape[0] / el, 2), "ms_per_clip": round(el / clips.shape[0] * 1e3, 2),
+                        "clips_s_batch8": round(clips.shape[0] / el8, 2),
+                        "config": "FactorizedViViT-B, uint8 (1,80,3,224,224) video -> 400 class probabilities, 2 temporal views x 16 "
+                                  "spatial steps (top-k 128, fp32), batch 1 per call (eager launches: host-bound)",
+                        "probs_sum": round(float(probs.sum()), 5)}
+    del model, clips
+    bcfg = dict(block_config=dict(dim=DIM, heads=HEADS, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14)),
+                depth=DEPTH, position_encoding_size=(14, 14), block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
+                window_indices=VITDET_WINDOWED)
+    det = ViTDet(bcfg, (3, 672, 672), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], 256, (16, 16), [4.0, 2.0, 1.0, 0.5])
+    det.load_state_dict(seeded(det, 6), strict=True)
+    det = det.eval().to(device)
+    set_policies(det, lambda: policies.TokenNormTopK(k=256))
+    frames = torch.randint(0, 256, (6, 1, 3, 672, 672), dtype=torch.uint8, device=device, generator=g)
+    pre, bb, post = [], [], []
+    with torch.inference_mode():
+        for rep in range(2):
+            det.reset()
+            pre, bb, post = [], [], []
+            for t in range(frames.shape[0]):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                images, x = det.pre_backbone(frames[t])
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                x = det.backbone(x)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                det.post_backbone(images, x)
+                torch.cuda.synchronize(); t3 = time.perf_counter()
+                pre.append(t1 - t0); bb.append(t2 - t1); post.append(t3 - t2)
+    nf = slice(1, None)
+    out["vitdet_e2e_672"] = {"pre_backbone_ms": round(sum(pre[nf]) / len(pre[nf]) * 1e3, 3),
+                             "backbone_ms_eager": round(sum(bb[nf]) / len(bb[nf]) * 1e3, 3),
+                             "post_backbone_ms": round(sum(post[nf]) / len(post[nf]) * 1e3, 3),
+                             "config": "ViTDet-B 672^2 up to the pyramid (p2..p6), uint8 frame in, one stream, top-k 256, non-first frames, "
+                                       "eager launches (scripts/time/vitdet_vid.py:33-45 split)"}
+    del det, frames
+    from eventful_transformer import _native
+    _native.clear_scratch()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -989,6 +1075,11 @@ def main():
                 except Exception as exc:   # a leg must not take the headline line down
                     legs[name] = {"error": f"{type(exc).__name__}: {exc}"}
                 log(f"other workload {name}: {legs[name]}")
+            try:
+                legs.update(wrapper_legs(device))
+            except Exception as exc:
+                legs["wrappers"] = {"error": f"{type(exc).__name__}: {exc}"}
+            log(f"wrappers: {({k_: legs[k_] for k_ in legs if k_.endswith('e2e') or 'e2e' in k_})}")
             line["other_workloads"] = legs
     if rank == 0:
         print(json.dumps(line), flush=True)
