@@ -818,6 +818,47 @@ def vitdet_latency(w):
         out[f"latency_ms_non_first_{tag}"] = round(sum(nf) / len(nf) * 1e3, 3)
         if tag == "graphs":
             runner.release()
+    out.update(vitdet_pipelined(w))
+    return out
+
+
+def vitdet_pipelined(w, lanes=(2, 4), groups=6):
+    """Throughput of ONE video stream with P consecutive frames in flight (graphs.FrameGraphs.run_pipelined: P lanes in one HIP
+    graph, block i of frame t+1 behind block i+1 of frame t).  The stream is the workload's clip walked back and forth
+    (consecutive frames stay neighbours); per-frame latency is NOT improved by this, frames/s of the stream is.  Outputs are
+    compared bit for bit with frame-by-frame graph replay of the same sequence."""
+    from eventful_transformer.graphs import FrameGraphs
+
+    model, clips = w["model"], w["data"][0]
+    T = clips.shape[0]
+    walk = list(range(1, T)) + list(range(T - 2, 0, -1))
+    out = {}
+    with torch.inference_mode():
+        for P in lanes:
+            n = P * (groups + 2)
+            seq = [walk[i % len(walk)] for i in range(n)]
+            serial = FrameGraphs(model.net)
+            serial.reset()
+            serial(clips[0])
+            for t in seq:
+                want = serial(clips[t])
+            want = want.clone()
+            serial.release()
+            runner = FrameGraphs(model.net)
+            runner.reset()
+            runner(clips[0])
+            stacks = [torch.stack([clips[t] for t in seq[g * P:(g + 1) * P]]) for g in range(groups + 2)]
+            runner.run_pipelined(stacks[0])      # lanes' scratch buffers (eager)
+            runner.run_pipelined(stacks[1])      # capture + first replay
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for g in range(2, groups + 2):
+                ys = runner.run_pipelined(stacks[g])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"pipelined_{P}_ms_per_frame"] = round(dt / (groups * P) * 1e3, 3)
+            out[f"pipelined_{P}_bit_identical"] = bool(torch.equal(ys[-1], want))
+            runner.release()
     return out
 
 

@@ -31,7 +31,7 @@
 // heads: 48 rows = 444 workgroups = one round.
 // The A.v part (LDS tiles of a~ / da~, both products on the matrix cores, state read-modify-write epilogue, per-head
 // partial ||out - ref||^2 for the projection gate) is that of evt_softmax_av_gated; every rounding point of the reference
-// is kept.  Head dim 64, N % 4 == 0, un-pooled keys.
+// is kept.  Head dim 64, un-pooled keys.
 #include "evt_attn_tiles.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -758,7 +758,6 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
   EVT_REQUIRE(d->qkv && d->a_state_t && d->pv, EVT_ERR_BAD_ARG, "evt_attention_stream: null qkv / a_state_t / pv");
   EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->D == d->H * 64, EVT_ERR_BAD_SHAPE,
               "evt_attention_stream: head dim 64 required (B=%d H=%d N=%d D=%d)", d->B, d->H, d->N, d->D);
-  EVT_REQUIRE((d->N & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_attention_stream: N=%d must be a multiple of 4", d->N);
   EVT_REQUIRE(d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_attention_stream: scale must be positive");
   EVT_REQUIRE(d->rel_terms == nullptr || (d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N), EVT_ERR_BAD_SHAPE,
               "evt_attention_stream: rel-pos key grid %dx%d does not match N=%d", d->gh, d->gw, d->N);

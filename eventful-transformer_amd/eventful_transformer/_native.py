@@ -215,10 +215,27 @@ def store_code(dtype):
 # another on one stream, so the hidden/ã/Δã/... scratch never needs to exist per block).
 # --------------------------------------------------------------------------------------------------
 _pool = {}
+_lane = 0   # frames of one stream captured side by side on several HIP streams (graphs.FrameGraphs.run_pipelined) each
+            # get their own set of work buffers: the lane is part of the pool key
+
+
+class lane:
+    """Context manager: scratch buffers requested inside belong to work lane `index`."""
+
+    def __init__(self, index):
+        self.index = index
+
+    def __enter__(self):
+        global _lane
+        self._saved, _lane = _lane, self.index
+
+    def __exit__(self, *exc):
+        global _lane
+        _lane = self._saved
 
 
 def scratch(name, shape, dtype, device):
-    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device())
+    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device(), _lane)
     t = _pool.get(key)
     if t is None:
         t = torch.empty(tuple(shape), dtype=dtype, device=device)
@@ -481,9 +498,12 @@ def fused_qk_fits(N, Nk, D, H, kcap):
 STREAM_QK = os.environ.get("EVT_STREAM_QK", "1") != "0"   # global blocks with N > 256: in-kernel scores (evt_attention_stream)
 
 
+STREAM_MIN_N = int(os.environ.get("EVT_STREAM_MIN_N", "257"))
+
+
 def attention_stream_fits(N, D, H):
-    """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest), N % 4 == 0."""
-    return STREAM_QK and FUSED_QK and D == 64 * H and N > 256 and N % 4 == 0
+    """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest)."""
+    return STREAM_QK and FUSED_QK and D == 64 * H and N >= STREAM_MIN_N
 
 
 def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_terms=None, gh=0, gw=0, idx=None, count=None,

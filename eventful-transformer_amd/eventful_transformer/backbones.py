@@ -28,6 +28,9 @@ class ViTBackbone(ExtendedModule):
             else:
                 config["window_size"] = None
             self.blocks.append(getattr(blocks, name)(input_size=input_size, **config))
+        # graphs.FrameGraphs.run_pipelined sets this while it captures several frames of one stream side by side: an
+        # object whose before_block(i, n) / after_block(i, n) order block i of a frame behind the previous frame's blocks
+        self.block_sync = None
 
     def forward(self, x):
         x = self.position_encoding(x)
@@ -37,15 +40,21 @@ class ViTBackbone(ExtendedModule):
         # a block boundary is only chained when neither side (nor the container, nor torch's global registry) carries a
         # forward / pre-forward hook -- hooked blocks take and return plain tensors, and a hooked `blocks` container is
         # invoked as the nn.Sequential it is.
-        if not CHAIN_BLOCKS or _hooked(self.blocks):
+        sync = self.block_sync
+        if (not CHAIN_BLOCKS or _hooked(self.blocks)) and sync is None:
             return self.blocks(x)
+        chain = CHAIN_BLOCKS and not _hooked(self.blocks)
         mods = list(self.blocks)
         for i, blk in enumerate(mods):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if nxt is not None and _chains(blk) and _chains(nxt):
+            if sync is not None:
+                sync.before_block(i, len(mods))
+            if chain and nxt is not None and _chains(blk) and _chains(nxt):
                 x = blk(x, _defer_output=True)
             else:
                 x = blk(x)
+            if sync is not None:
+                sync.after_block(i, len(mods))
         return x.materialize() if isinstance(x, blocks.PendingSum) else x
 
 

@@ -19,6 +19,16 @@ frame 0 eager (fills the scratch pool, splits the weights) then captured and rep
 captured; everything after is replay only.  The numbers are bit-identical to the eager path (same kernels,
 same order, same buffers).  Weights are read at capture time (the bf16 planes of the split-precision GEMM are
 built then): call `release()` after loading new weights.
+
+Frame pipelining (`run_pipelined`): block i of frame t+1 only needs block i of frame t (its temporal state) and block
+i-1 of frame t+1 (its input), so consecutive frames of ONE stream overlap like a wavefront.  With every launch of a
+one-stream frame latency-bound (150-190 dependent launches of 5-80 us that each fill a fraction of the chip), P frames
+are captured side by side on P HIP streams ("lanes", each with its own scratch buffers) in one graph, ordered by
+per-block events: lane j enters block i once lane j-1 has left block i+1 (one block further than the state dependency:
+a chained block hands its MLP token buffer to the next block's first row pass unevaluated, and the next frame must not
+scatter into that buffer before it has been read).  Same kernels on the same state in the same per-block order: the
+outputs are bit-identical to frame-by-frame replay; the latency of a frame is unchanged, the throughput of the stream
+approaches P x.
 """
 import torch
 
@@ -41,6 +51,8 @@ class FrameGraphs:
         self._x = None           # static input
         self._t = 0
         self._inc_warm = False
+        self._pipe = None        # (graph, static inputs, static outputs, side streams) of `run_pipelined`
+        self._pipe_warm = 0
 
     def reset(self):
         """Start a new clip.  Before the first-frame graph exists this resets the model; afterwards the graph
@@ -51,9 +63,10 @@ class FrameGraphs:
 
     def release(self):
         """Drop the graphs (and their private memory pools) and reset the model."""
-        self._first = self._inc = self._x = None
+        self._first = self._inc = self._x = self._pipe = None
         self._t = 0
         self._inc_warm = False
+        self._pipe_warm = 0
         self.model.reset()
 
     def _capture(self):
@@ -100,3 +113,76 @@ class FrameGraphs:
             graph.replay()
         self._t += 1
         return y
+
+
+    # ---------------------------------------------------------------------------------------------
+    def _backbones(self):
+        from eventful_transformer.backbones import ViTBackbone
+
+        return [m for m in self.model.modules() if isinstance(m, ViTBackbone)]
+
+    def _capture_pipelined(self, xs):
+        P = xs.shape[0]
+        bbs = self._backbones()
+        if len(bbs) != 1:
+            raise RuntimeError("FrameGraphs.run_pipelined: the model must contain exactly one ViTBackbone")
+        bb = bbs[0]
+        side = [torch.cuda.Stream(device=xs.device) for _ in range(P - 1)]
+        done = [[torch.cuda.Event() for _ in bb.blocks] for _ in range(P)]
+        graph = torch.cuda.CUDAGraph()
+        ys = []
+        try:
+            with torch.cuda.graph(graph):
+                main = torch.cuda.current_stream()
+                for s in side:                      # fork before any work is issued
+                    s.wait_stream(main)
+                for j in range(P):
+                    st = main if j == 0 else side[j - 1]
+                    bb.block_sync = _LaneSync(j, st, done)
+                    with torch.cuda.stream(st), _native.lane(j):
+                        ys.append(self._fwd(xs[j]))
+                for s in side:                      # join
+                    main.wait_stream(s)
+        finally:
+            bb.block_sync = None
+        return graph, xs, ys, side
+
+    @torch.inference_mode()
+    def run_pipelined(self, xs):
+        """xs: (P, ...) = the next P frames of the stream (not the first frame of a clip).  Returns the list of their P
+        outputs -- static tensors, overwritten by the next call.  The first call per lane count runs the frames one by one
+        (each lane's scratch buffers come into being outside the capture), the second captures, later ones replay."""
+        if self._t == 0:
+            raise RuntimeError("FrameGraphs.run_pipelined: the first frame of a clip goes through __call__")
+        P = xs.shape[0]
+        if self._pipe is not None and (self._pipe[1].shape != xs.shape or self._pipe[1].dtype != xs.dtype):
+            raise RuntimeError("FrameGraphs.run_pipelined: frame stack differs from the captured one; call release()")
+        if self._pipe is None and self._pipe_warm != P:
+            ys = []
+            for j in range(P):
+                with _native.lane(j):
+                    ys.append(self._fwd(xs[j].contiguous()).clone())
+            self._pipe_warm = P
+            self._t += P
+            return ys
+        if self._pipe is None:
+            self._pipe = self._capture_pipelined(torch.empty_like(xs, memory_format=torch.contiguous_format))
+        graph, sx, ys, _ = self._pipe
+        sx.copy_(xs)
+        graph.replay()
+        self._t += P
+        return ys
+
+
+class _LaneSync:
+    """Event ordering of one lane of `run_pipelined` (called by ViTBackbone.forward around every block)."""
+
+    def __init__(self, lane, stream, done):
+        self.lane, self.stream, self.done = lane, stream, done
+
+    def before_block(self, i, n):
+        if self.lane > 0:
+            self.stream.wait_event(self.done[self.lane - 1][min(i + 1, n - 1)])
+
+    def after_block(self, i, n):
+        self.done[self.lane][i].record(self.stream)

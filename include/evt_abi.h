@@ -391,7 +391,7 @@ EVT_API int evt_rel_terms(const float* qkv, const float* rel_y, const float* rel
  *            pv += round(a~ . dv~); pv += round(da~ . v_old)  (modules.py:285-295); out = pv, heads merged.
  *
  * a_state_t is the gate reference TRANSPOSED, (B,H,Nkeys,Nrows): the 32 rows a workgroup owns of a selected column
- * are contiguous.  Head dim 64, N % 4 == 0, un-pooled keys (Nk == N).  v_delta_t / v_old_t, norm_ref / norm_parts,
+ * are contiguous.  Head dim 64, un-pooled keys (Nk == N).  v_delta_t / v_old_t, norm_ref / norm_parts,
  * out_f32 == NULL: as in evt_softmax_av_desc.  rel_terms: evt_rel_terms output or NULL (no relative position).
  * ------------------------------------------------------------------------------------------ */
 typedef struct evt_attn_stream_desc {

@@ -469,6 +469,46 @@ def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed, resized):
         graphed(clips[0][0][:1])
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
+@pytest.mark.parametrize("policy,kw", [("TokenNormTopK", dict(k=30)), ("TokenNormThreshold", dict(threshold=0.8))])
+def test_pipelined_frames_are_bit_identical(policy, kw, lanes):
+    """graphs.FrameGraphs.run_pipelined: `lanes` consecutive frames of one stream captured side by side on `lanes` HIP streams
+    (block i of frame t+1 behind block i+1 of frame t) must give bit for bit what frame-by-frame execution gives, on a
+    backbone with windowed and global blocks, rel-pos terms and chained (PendingSum) block boundaries."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+    from eventful_transformer.graphs import FrameGraphs
+
+    def make():
+        torch.manual_seed(3)
+        cfg = dict(dim=128, heads=2, mlp_ratio=2, matmul_2_cast="bfloat16", window_size=(4, 4), relative_embedding_size=(8, 8))
+        bb = ViTBackbone(block_config=cfg, depth=4, position_encoding_size=(8, 8), input_size=(8, 8), block_class="EventfulBlock",
+                         window_indices=(0, 2), windowed_class="EventfulTokenwiseBlock", windowed_overrides=dict(matmul_2_cast=None))
+        for p_ in bb.parameters():
+            torch.nn.init.normal_(p_, std=0.05)
+        bb = bb.eval().to(DEV)
+        H.set_policies(bb, getattr(policies, policy), **kw)
+        return bb
+
+    T = 1 + 4 * lanes
+    clips = [O.make_token_stream(1, 64, 128, T, 20, seed=60 + c, small=0.01).to(DEV) for c in range(2)]
+    eager, piped = make(), FrameGraphs(make())
+    with torch.inference_mode():
+        for clip in clips:
+            eager.reset()
+            piped.reset()
+            want = [eager(clip[t]).clone() for t in range(T)]
+            got = [piped(clip[0]).clone()]
+            for t in range(1, T, lanes):
+                got += [y.clone() for y in piped.run_pipelined(clip[t:t + lanes])]
+            for t in range(T):
+                assert torch.equal(got[t], want[t]), (t, float((got[t] - want[t]).abs().max()))
+    assert piped._pipe is not None
+    with pytest.raises(RuntimeError, match="first frame"):
+        piped.reset()
+        piped.run_pipelined(clips[0][1:1 + lanes])
+
+
 def test_vivit_sized_backbone_reruns_are_bit_identical():
     """I7 at the benchmark's shapes (N = 197, D = 768, 12 heads, bf16 A.v cast, k = 128; 2 blocks, 3 clips x 4 frames):
     every kernel on the path -- K8 with state outputs on the first frame, split-precision K3/K4, the fused K5+K6,
