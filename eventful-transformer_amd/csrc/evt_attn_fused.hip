@@ -226,10 +226,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   };
   if (QK && NREG > 0) {
     // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  Wave w owns keys
-    // 16w .. 16w+15 of every 64-key chunk.  Both operands go STRAIGHT from the token buffer into MFMA fragments: lane
-    // (l15, kg) reads, of q row l15 / key l15, the channels its fragment holds (16 lanes x 4 kg cover whole 128-byte
-    // lines of 16 rows), so there is no LDS staging and no barrier until the tile is complete; the next chunk's
-    // fragments are requested before the current chunk's MFMAs.
+    // 16w .. 16w+15 of every 64-key chunk; lane (l15, kg) holds, of q row l15 / key l15, the channels `chan` of its
+    // fragment pieces ("Operand path" below); one workgroup barrier (the q rows), none per chunk.
     const int64_t rs = 3 * (int64_t)a.D;
     const float* clip = a.qkv + (int64_t)b * a.N * rs;
     const int l15 = lane & 15, kg = lane >> 4;
@@ -251,41 +249,80 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     // does not care which channel meets which MFMA step as long as q and k agree): 16 contiguous channels 16kg + 4p.
     // QK == 2 (16x16x32 bf16 tiles): k-block m = p >> 1 holds channels 32m + 8kg .. +8, pieces 2m, 2m + 1.
     auto chan = [&](int p_) __attribute__((always_inline)) { return QK == 1 ? 16 * kg + 4 * p_ : 32 * (p_ >> 1) + 8 * kg + 4 * (p_ & 1); };
-    float4 qf[2][4];
+    // Operand path.  A lane's fragment pieces are 16 bytes of ONE row (q row / key l15), neighbouring lanes are rows 9 KB
+    // apart: read straight from the token buffer, a wave's dwordx4 load is 64 separate 16-byte requests and the texture
+    // addresser works through them one by one.  Ablation builds at B = 256 (406 us): dropping 8 of a wave's 16 key loads
+    // -27 us, 6 of its 8 q loads (every wave read all 32 q rows) -23 us; the same scattered loads were what bound the
+    // statistics pass of evt_attention_stream.  So both operands now enter COALESCED -- 16 consecutive lanes read one
+    // row's 256 bytes -- and are re-read as fragments from LDS: the q rows once per workgroup, each wave's 16 keys of a
+    // chunk through a staging block of its own (no workgroup barrier; the next chunk's rows are in flight in registers
+    // meanwhile).  The staging blocks live in the A / V tiles, which are idle until the chunk loop.
+    constexpr int KP = 68;   // fp32 row pitch: 16 rows x 4 dwords of a fragment read cover the 64 banks once
+    static_assert((size_t)(FR + 4 * 16) * KP * sizeof(float) <= (size_t)(2 * FR + 2 * 64) * P * sizeof(T), "operand staging fits the A / V tiles");
+    float* qst = reinterpret_cast<float*>(smem_raw);            // [FR][KP] q rows / scale
+    float* kst = qst + FR * KP + wave * 16 * KP;                // [16][KP] this wave's keys of the current chunk
+    float4 qg[2];
 #pragma unroll
-    for (int hr = 0; hr < 2; ++hr) {
-      const int i = i0 + hr * 16 + l15;
-      const float* qp = clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64;
-#pragma unroll
-      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qp + chan(p_));
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u, row = e >> 4, i = i0 + row;
+      qg[u] = *reinterpret_cast<const float4*>(clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64 + 4 * (e & 15));
     }
-    auto load_kf = [&](int c0, float4* kf) __attribute__((always_inline)) {
-      const int j = c0 + wave * 16 + l15;
-      const float* kp = clip + (int64_t)(j < a.N ? j : a.N - 1) * rs + a.D + h * 64;
-#pragma unroll
-      for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
-    };
-    // Two fragment register sets, used alternately (a copy `kf = kn` at the end of an iteration made hipcc wait for the
-    // prefetch it had just issued: four serialised L2 round trips per workgroup).  The score-independent requests of the
-    // chunk loop and the epilogue (`prefetch`: 16 two-byte gathers of the old a~ values among them) go out BEHIND the q rows
-    // and the first two key chunks: vmcnt retires in order, so in front of them every q.k^T wait was also a wait for the
-    // slowest gather.  In-kernel phase timing (scripts/attn_prof.py): 18.8k of a workgroup's 41k ticks were spent here.
-    float4 kA[4], kB[4];
-    load_kf(0, kA);
-    if (QKC < a.N) load_kf(QKC, kB);
+    // (named native vectors, not a float4 array handed to a lambda: hipcc kept that array in scratch memory)
+    typedef float kvec __attribute__((ext_vector_type(4)));
+    kvec kr0, kr1, kr2, kr3;
+    const int krow = lane >> 4, kcol = 4 * (lane & 15);
+    const float* kbase = clip + a.D + h * 64 + kcol;
+#define EVT_LOAD_KRAW(c0_)                                                                                     \
+    do {   /* the wave's 16 key rows of chunk c0_, 4 rows per load */                                          \
+      const int j0_ = (c0_) + wave * 16 + krow;                                                                \
+      kr0 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ < a.N ? j0_ : a.N - 1) * rs);                 \
+      kr1 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 4 < a.N ? j0_ + 4 : a.N - 1) * rs);         \
+      kr2 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 8 < a.N ? j0_ + 8 : a.N - 1) * rs);         \
+      kr3 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 12 < a.N ? j0_ + 12 : a.N - 1) * rs);       \
+    } while (0)
+    // ONE raw register set (the next chunk's rows, in flight while the current chunk is multiplied) + one fragment set: a
+    // second raw set made hipcc load piece by piece with a wait each (three workgroups per CU: 164 registers).  The
+    // score-independent requests of the chunk loop and the epilogue (`prefetch`: 16 two-byte gathers of the old a~ values
+    // among them) go out BEHIND the q rows and the first key chunk: vmcnt retires in order, so in front of them every
+    // q.k^T wait was also a wait for the slowest gather.
+    EVT_LOAD_KRAW(0);
     asm volatile("" ::: "memory");
     prefetch();
     asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u;
+      *reinterpret_cast<float4*>(qst + (e >> 4) * KP + 4 * (e & 15)) = scaled(qg[u]);
+    }
+    __syncthreads();
+    float4 qf[2][4];
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qst + (hr * 16 + l15) * KP + chan(p_));
     bf16x8_t qh[2][2], ql[2][2];
+    if (QK == 2) {
 #pragma unroll
-    for (int hr = 0; hr < 2; ++hr) {
-#pragma unroll
-      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = scaled(qf[hr][p_]);
-      if (QK == 2) {
+      for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
         for (int m = 0; m < 2; ++m) split8(qf[hr][2 * m], qf[hr][2 * m + 1], &qh[hr][m], &ql[hr][m]);
-      }
     }
+    // raw rows -> the wave's staging block -> this lane's fragment pieces (wave-private: only the wave's own LDS traffic is waited for)
+    float4 kf[4];
+    float* kst_w = kst + krow * KP + kcol;
+    const float* kst_r = kst + l15 * KP;
+#define EVT_STAGE_K()                                                                                          \
+    do {                                                                                                       \
+      *reinterpret_cast<kvec*>(kst_w) = kr0;                                                                   \
+      *reinterpret_cast<kvec*>(kst_w + 4 * KP) = kr1;                                                          \
+      *reinterpret_cast<kvec*>(kst_w + 8 * KP) = kr2;                                                          \
+      *reinterpret_cast<kvec*>(kst_w + 12 * KP) = kr3;                                                         \
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                                                      \
+      __builtin_amdgcn_wave_barrier();                                                                         \
+      _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kst_r + chan(p_)); \
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                                                      \
+      __builtin_amdgcn_wave_barrier();                                                                         \
+    } while (0)
     auto qk_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
       const int n0 = c0 + wave * 16;
       if (n0 < a.N) {  // wave-uniform
@@ -325,12 +362,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     // N <= 256 (entry-point check): at most four chunks, written out -- in a loop the same wait instruction would serve the
     // first chunk (many younger requests in flight) and the later ones (none), and hipcc has to assume none.
     static_assert(QKC == 64, "four chunks of 64 keys cover N <= 256");
-    qk_chunk(0, kA);
-    if (2 * QKC < a.N) load_kf(2 * QKC, kA);
-    if (QKC < a.N) qk_chunk(QKC, kB);
-    if (3 * QKC < a.N) load_kf(3 * QKC, kB);
-    if (2 * QKC < a.N) qk_chunk(2 * QKC, kA);
-    if (3 * QKC < a.N) qk_chunk(3 * QKC, kB);
+    // a chunk's row loads and their staging sit in ONE basic block (nested conditions, N <= 256 = four chunks): a load
+    // whose use is in a later conditional block is waited for with vmcnt(0) where it is issued
+    EVT_STAGE_K();
+    if (QKC < a.N) {
+      EVT_LOAD_KRAW(QKC);
+      qk_chunk(0, kf);
+      EVT_STAGE_K();
+      if (2 * QKC < a.N) {
+        EVT_LOAD_KRAW(2 * QKC);
+        qk_chunk(QKC, kf);
+        EVT_STAGE_K();
+        if (3 * QKC < a.N) {
+          EVT_LOAD_KRAW(3 * QKC);
+          qk_chunk(2 * QKC, kf);
+          EVT_STAGE_K();
+          qk_chunk(3 * QKC, kf);
+        } else {
+          qk_chunk(2 * QKC, kf);
+        }
+      } else {
+        qk_chunk(QKC, kf);
+      }
+    } else {
+      qk_chunk(0, kf);
+    }
+#undef EVT_LOAD_KRAW
+#undef EVT_STAGE_K
     __syncthreads();
     ATT_TICK(0);   // prefetch issue + q.k^T
   }

@@ -43,6 +43,7 @@ struct StreamArgs {
   void* a_state_t; const int32_t* idx; const int32_t* count;
   const void* v_delta_t; const void* v_old_t; const void* v_state; void* pv; float* out_f32;
   const float* norm_ref; float* norm_parts;
+  void* k_split;
   int B, H, N, D, kcap, gh, gw;
   float scale;
 };
@@ -104,6 +105,42 @@ template <> struct Sweep16<float> {
     return acc;
   }
 };
+
+// Key rows of the frame as bf16 hi / lo MFMA fragments in FRAGMENT-MAJOR order, once per launch (QK == 2).
+// Why.  Ablation builds of the statistics pass at 1024^2 (N = 4096; whole launch 231 us): without the (max, exp, sum)
+// chain 233 us, without the score MFMAs 228 us, without the rel-pos LDS reads 231 us, WITHOUT THE KEY LOADS 176 us; four
+// fragment register sets instead of two (three chunks in flight): 231 us.  The pass is bound by the key loads, and not by
+// their latency: a lane owns one key row of the chunk (the MFMA's A-operand row), so neighbouring lanes read 16-byte
+// pieces 256 bytes apart and the texture addresser works through a wave's dwordx4 load piece by piece (~64 cycles per
+// instruction; 4 per chunk and wave, 8 waves per CU: 2048 of the 1840 cycles a chunk took).  Here every (16-key block, k-block m, hi | lo)
+// is stored as the 64 lanes' 16-byte pieces in lane order: a wave's load instruction reads 1 KB of consecutive bytes.
+// The conversion of a key row, repeated by every row tile before (128 x at 1024^2; ~50 of the pass's 177 VALU
+// instructions per chunk and wave), happens once.  Layout: uint4 index (((bh * NKB + key / 16) * 2 + m) * 2 + hl) * 64 +
+// kg * 16 + key % 16, NKB = ceil(N / 16); keys past N are zero rows.  One thread per (b, key, h, 8 channels).
+__global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * NKB * 16 * H * 8;
+  if (t >= total) return;
+  const int c8 = (int)(t & 7), m = c8 >> 2, kg = c8 & 3;
+  const int64_t u = t >> 3;
+  const int h = (int)(u % H);
+  const int64_t bk = u / H;               // b * (16 NKB) + key
+  const int64_t b = bk / (16 * NKB);
+  const int key = (int)(bk - b * 16 * NKB);
+  bf16x8_t hi = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+  if (key < N) {
+    const float* src = qkv + (b * N + key) * 3 * (int64_t)D + D + h * SDH + c8 * 8;
+    const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+    bf16x4_t h0, l0, h1, l1;
+    split4(x, &h0, &l0);
+    split4(y, &h1, &l1);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  uint4* dst = out + ((((b * H + h) * NKB + (key >> 4)) * 2 + m) * 2) * 64 + kg * 16 + (key & 15);
+  dst[0] = __builtin_bit_cast(uint4, hi);
+  dst[64] = __builtin_bit_cast(uint4, lo);
+}
 
 // QK: 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = q, k as bf16 hi + lo (three v_mfma_f32_16x16x32_bf16 per
 // product, ~1e-5 relative; the arithmetic of evt_qk's split mode).  FIRST: first frame of a clip (see the header).
@@ -167,17 +204,35 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 #pragma unroll
     for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qp + chan(p_));
   }
-  auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps) -> 4 pieces
-    const float* kp = clip + (int64_t)j * rs + a.D + h * SDH;
+  // Key fragments -> 4 pieces.  QK == 1: fp32 channels of key row j from the token buffer.  QK == 2: pieces 2m, 2m + 1 = hi,
+  // lo of k-block m from the fragment-major plane (split_keys_kernel).
+  const int NKB = (a.N + 15) >> 4;
+  const uint4* ksp = reinterpret_cast<const uint4*>(a.k_split) + (int64_t)bh * NKB * 256;
+  auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps): a gather
+    if (QK == 2) {
+      const uint4* kp = ksp + (int64_t)(j >> 4) * 256 + kg * 16 + (j & 15);
 #pragma unroll
-    for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
+      for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
+    } else {
+      const float* kp = clip + (int64_t)j * rs + a.D + h * SDH;
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
+    }
+  };
+  auto load_chunk = [&](int c0, float4* kf) __attribute__((always_inline)) {   // keys c0 + 16 wave + l15 of a streamed chunk (clamped past N)
+    if (QK == 2) {   // the wave's 16-key block: four loads of 1 KB of consecutive bytes
+      const int kb = (c0 >> 4) + wave;
+      const uint4* kp = ksp + (int64_t)(kb < NKB ? kb : NKB - 1) * 256 + lane;
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
+    } else {
+      const int j = c0 + wave * 16 + l15;
+      load_kf(j < a.N ? j : a.N - 1, kf);
+    }
   };
   float4 kA[4], kB[4];
-  {
-    const int j0 = wave * 16 + l15;
-    load_kf(j0 < a.N ? j0 : a.N - 1, kA);
-    load_kf(64 + j0 < a.N ? 64 + j0 : a.N - 1, kB);
-  }
+  load_chunk(0, kA);
+  load_chunk(64, kB);
   if (rel) {
     // the tile's rows are contiguous in rel_terms: a flat copy, 8 loads in flight per thread before the first LDS store
     // (a loop of load -> store pairs is 16-24 serialised round trips: 12 us of a 60 us workgroup)
@@ -233,8 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     } else {
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        bf16x8_t kh, kl;
-        split8(kf[2 * m], kf[2 * m + 1], &kh, &kl);
+        const bf16x8_t kh = __builtin_bit_cast(bf16x8_t, kf[2 * m]), kl = __builtin_bit_cast(bf16x8_t, kf[2 * m + 1]);
 #pragma unroll
         for (int hr = 0; hr < NHR; ++hr) {
           sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[hr][m], sacc[hr], 0, 0, 0);
@@ -292,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
   for (int c0 = 0; c0 < a.N; c0 += 128) {
     stats(c0, kA);
-    { const int j = c0 + 128 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
+    load_chunk(c0 + 128, kA);
     if (c0 + 64 < a.N) stats(c0 + 64, kB);
-    { const int j = c0 + 192 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+    load_chunk(c0 + 192, kB);
   }
   bool rok[NHR];   // query row 16 hr + l15 of the tile exists
 #pragma unroll
@@ -442,8 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 
   if (FIRST) {
     const T* vst = reinterpret_cast<const T*>(a.v_state) + (int64_t)b * a.N * a.D + h * SDH;
-    { const int j = wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
-    { const int j = 64 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+    load_chunk(0, kA);
+    load_chunk(64, kB);
     auto first_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
       // the chunk's 64 value rows (16 channels per thread), requested ahead of the score MFMAs
       const int vkey = tid >> 2, vc0 = (tid & 3) * 16, vj = c0 + vkey;
@@ -489,9 +543,9 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     };
     for (int c0 = 0; c0 < a.N; c0 += 128) {
       first_chunk(c0, kA);
-      { const int j = c0 + 128 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kA); }
+      load_chunk(c0 + 128, kA);
       if (c0 + 64 < a.N) first_chunk(c0 + 64, kB);
-      { const int j = c0 + 192 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kB); }
+      load_chunk(c0 + 192, kB);
     }
     STR_TICK(3);   // pass B (first frame: all keys)
     // ---- epilogue: out = state = round(acc(keys 0..31 of each chunk) + acc(keys 32..63)) ------------------------
@@ -707,6 +761,12 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   const size_t lds = stream_lds_bytes<T, NHR>(a.gh + a.gw);
   const int tiles_x = (a.N + FRT - 1) / FRT, total = tiles_x * a.B * a.H;
   EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
+  if (QK == 2) {
+    const int nkb = (a.N + 15) / 16;
+    const int64_t units = (int64_t)a.B * nkb * 16 * a.H * 8;
+    hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, a.qkv, reinterpret_cast<uint4*>(a.k_split),
+                       a.B, a.H, a.N, a.D, nkb);
+  }
   hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
 }
 
@@ -770,10 +830,12 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
     EVT_REQUIRE(d->out_f32 != nullptr || d->store != EVT_F32, EVT_ERR_BAD_ARG,
                 "evt_attention_stream: out_f32 may only be omitted with a 16-bit store type (the output then IS the pv state)");
   }
+  EVT_REQUIRE(!d->qk_split || d->k_split != nullptr, EVT_ERR_BAD_ARG,
+              "evt_attention_stream: qk_split needs the k_split workspace (B * H * ceil(N / 16) * 4096 bytes)");
   if (d->B == 0) return EVT_OK;
   const bool rel = d->rel_terms != nullptr;
   StreamArgs a{d->qkv, d->rel_terms, d->a_state_t, d->idx, d->count, d->v_delta_t, d->v_old_t, d->v_state, d->pv, d->out_f32,
-               d->norm_ref, d->norm_parts, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale};
+               d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale};
   hipStream_t s = evt_stream(stream);
   EVT_DISPATCH_STORE(d->store, T, {
     if (d->first) launch_stream<T, true>(a, d->qk_split, s);

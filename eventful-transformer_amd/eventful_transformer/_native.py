@@ -114,7 +114,7 @@ class AttnStreamDesc(Structure):
         ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p),
         ("v_state", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("store", c_int32), ("scale", c_float),
-        ("qk_split", c_int32), ("first", c_int32),
+        ("qk_split", c_int32), ("first", c_int32), ("k_split", c_void_p),
     ]
 
 
@@ -510,9 +510,12 @@ def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_te
                      kcap=0, v_delta_t=None, v_old_t=None, v_state=None, out_f32=None, norm_ref=None, norm_parts=None,
                      qk_split=None):
     """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N)."""
+    split = int(QK_SPLIT if qk_split is None else qk_split)
+    # split arithmetic: the frame's key rows as bf16 hi / lo fragments, written by the call's pre-kernel (4 KB per 16 keys and head)
+    ksp = scratch("k_split", (B, H, (N + 15) // 16, 2048), torch.bfloat16, qkv.device) if split else None
     d = AttnStreamDesc(_p(qkv), _p(rel_terms), gh, gw, _p(a_state_t), _p(idx), _p(count), kcap, _p(v_delta_t), _p(v_old_t),
                        _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts), B, H, N, D, store, float(scale),
-                       int(QK_SPLIT if qk_split is None else qk_split), int(first))
+                       split, int(first), _p(ksp))
     # algorithmic bytes: q, k read once per clip (8ND), rel terms, gate-reference columns read + rewritten (first frame:
     # written whole), v pieces, A.v state read-modify-write (first frame: v state read, state written), fp32 output
     es = 4 if store == EVT_F32 else 2

@@ -409,6 +409,8 @@ typedef struct evt_attn_stream_desc {
   float scale;                            /* q / scale (blocks.py:514)                                       */
   int32_t qk_split;                       /* 1 = q, k as bf16 hi + lo (3 bf16 MFMAs per product), 0 = exact fp32 MFMA */
   int32_t first;                          /* 1 = first frame of a clip                                       */
+  void* k_split;                          /* workspace, B * H * ceil(N/16) * 4096 bytes, required with qk_split: the frame's
+                                             key rows as bf16 hi / lo MFMA fragments (written by a pre-kernel of this call) */
 } evt_attn_stream_desc;
 
 EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
