@@ -779,6 +779,8 @@ def other_workload_leg(name, device, budget_s=12.0, cpu=True, **kw):
             leg.update(vitdet_latency(w))
             leg["check"] = self_check_vitdet(w)
         else:
+            if graphs and w["resident"] == 1 and w["k"] > 0:
+                leg.update(vivit_pipelined(w))
             leg["check"] = self_check_vivit(w["model"], w["data"][0], w["sd"], w["cast"], w["k"], max_frames=6)
         if cpu and time.perf_counter() - t_start < 3 * budget_s:
             if w["kind"] == "vivit":
@@ -790,6 +792,46 @@ def other_workload_leg(name, device, budget_s=12.0, cpu=True, **kw):
         return leg
     finally:
         release_workload(w)
+
+
+def vivit_pipelined(w, lanes=(3, 5), reps=6):
+    """ONE ViViT clip stream (B = 1) with P frames of the clip in flight (graphs.FrameGraphs.run_pipelined): the first frame of
+    each clip by the first-frame graph, its remaining frames in groups of P.  Outputs compared bit for bit with frame-by-frame
+    replay of the same clip."""
+    from eventful_transformer.graphs import FrameGraphs
+
+    model, clip = w["model"], w["data"][0]
+    T = clip.shape[0]
+    out = {}
+    with torch.inference_mode():
+        serial = FrameGraphs(model.net)
+        serial.reset()
+        want = torch.stack([serial(clip[t]).clone() for t in range(T)], dim=1)
+        serial.release()
+        for P in lanes:
+            if (T - 1) % P:
+                continue
+            runner = FrameGraphs(model.net)
+
+            def run():
+                runner.reset()
+                ys = [runner(clip[0]).clone()]
+                for t in range(1, T, P):
+                    ys += [y.clone() for y in runner.run_pipelined(clip[t:t + P])]
+                return torch.stack(ys, dim=1)
+
+            run()
+            run()      # lanes' scratch buffers, capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                got = run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[f"pipelined_{P}_frames_s"] = round(reps * T / dt, 1)
+            out[f"pipelined_{P}_bit_identical"] = bool(torch.equal(got, want))
+            runner.release()
+    return out
 
 
 def vitdet_latency(w):
