@@ -331,20 +331,41 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   float rm[NHR], rsum[NHR];
 #pragma unroll
   for (int hr = 0; hr < NHR; ++hr) { rm[hr] = -1.0e30f; rsum[hr] = 0.f; }
-  auto stats = [&](int c0, const float4* kf) __attribute__((always_inline)) {
+  // The pass is VALU-bound once the key loads are coalesced (scripts/isa_loops.py: 127 VALU per chunk and wave), so the
+  // per-key bookkeeping is kept out of it: the (grid row, grid column) of the lane's first key advance by one chunk's
+  // 64 keys per call instead of a float division per key, and only the chunks that can reach past N mask their scores.
+  const int cdy = rel ? 64 / a.gw : 0, cdx = rel ? 64 - cdy * a.gw : 0;   // a chunk = cdy grid rows + cdx columns
+  int ky0 = 0, kx0 = 0;                                                    // of key 16 wave + 4 kg of the current chunk
+  if (rel) { const int j0 = wave * 16 + 4 * kg; ky0 = fast_div(j0, inv_gw); kx0 = j0 - ky0 * a.gw; }
+  auto stats = [&](int c0, const float4* kf, const bool mask) __attribute__((always_inline)) {
     f32x4_acc sacc[NHR];
     scores(kf, sacc);
     const int jb = c0 + wave * 16 + 4 * kg;
-    int js[4];
+    if (rel) {
+      int oy[4], ox[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) js[r] = jb + r < a.N ? jb + r : a.N - 1;
-    with_rel(sacc, js);
+      for (int r = 0; r < 4; ++r) {
+        const int kx = kx0 + r;
+        const bool wrap = kx >= a.gw;
+        oy[r] = min(ky0 + (wrap ? 1 : 0), a.gh - 1);   // (keys past N: any valid slot, their scores are masked)
+        ox[r] = a.gh + (wrap ? kx - a.gw : kx);
+      }
+#pragma unroll
+      for (int hr = 0; hr < NHR; ++hr) {
+        const float* rv = relv + (16 * hr + l15) * RP;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[hr][r] = (sacc[hr][r] + rv[oy[r]]) + rv[ox[r]];
+      }
+      kx0 += cdx;
+      ky0 += cdy;
+      if (kx0 >= a.gw) { kx0 -= a.gw; ++ky0; }
+    }
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
       // 4 scores of ONE row: one rescale of the running sum per group, one exponential per score
       float x[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[r] = jb + r < a.N ? sacc[hr][r] : -INFINITY;
+      for (int r = 0; r < 4; ++r) x[r] = (!mask || jb + r < a.N) ? sacc[hr][r] : -INFINITY;
       const float nm = fmaxf(rm[hr], fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));   // finite: rm starts at -1e30
       const float part = (fast_exp(x[0] - nm) + fast_exp(x[1] - nm)) + (fast_exp(x[2] - nm) + fast_exp(x[3] - nm));
       rsum[hr] = fmaf(rsum[hr], fast_exp(rm[hr] - nm), part);
@@ -353,11 +374,16 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   };
   // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
-  for (int c0 = 0; c0 < a.N; c0 += 128) {
-    stats(c0, kA);
-    load_chunk(c0 + 128, kA);
-    if (c0 + 64 < a.N) stats(c0 + 64, kB);
-    load_chunk(c0 + 192, kB);
+  {
+    int c0 = 0;
+    for (; c0 + 128 <= a.N; c0 += 128) {   // whole chunk pairs: no masks
+      stats(c0, kA, false);
+      load_chunk(c0 + 128, kA);
+      stats(c0 + 64, kB, false);
+      load_chunk(c0 + 192, kB);
+    }
+    if (c0 < a.N) stats(c0, kA, true);          // the last (partial) pair: its fragments were requested above / in the prologue
+    if (c0 + 64 < a.N) stats(c0 + 64, kB, true);
   }
   bool rok[NHR];   // query row 16 hr + l15 of the tile exists
 #pragma unroll

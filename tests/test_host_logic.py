@@ -201,3 +201,14 @@ def test_graft_entry_build_hook():
     from eventful_transformer import _native
 
     assert _native.load().evt_version() == _native.ABI_VERSION
+
+
+def test_big_tile_choice_respects_the_4gb_weight_plane_bound():
+    """The persistent 256-row GEMM addresses the hl32 weight planes with 32-bit byte offsets: a weight matrix whose planes reach
+    4 GB (Nout * pitch(K) * 2 >= 2^32) must fall back to the 128x128 kernel (evt_gated_linear_big_tile == 0), while the same
+    launch at ViT-B's size picks a 256-row tile.  Shape-only query: no GPU needed."""
+    from eventful_transformer import _native
+    B, kcap, N = 256, 128, 197
+    assert _native.gated_linear_big_tile(768, True, N, 2304, True, N, False, B, kcap, 768, 2304) != 0
+    big_k, big_n = 65536, 32768          # 32768 rows x 65536 x 4 bytes of hl32 lines = 8 GB
+    assert _native.gated_linear_big_tile(big_k, True, N, big_n, True, N, False, B, kcap, big_k, big_n) == 0
