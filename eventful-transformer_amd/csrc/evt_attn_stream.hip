@@ -117,25 +117,27 @@ template <> struct Sweep16<float> {
 // The conversion of a key row, repeated by every row tile before (128 x at 1024^2; ~50 of the pass's 177 VALU
 // instructions per chunk and wave), happens once.  Layout: uint4 index (((bh * NKB + key / 16) * 2 + m) * 2 + hl) * 64 +
 // kg * 16 + key % 16, NKB = ceil(N / 16); keys past N are zero rows.  One thread per (b, key, h, 8 channels).
-// One workgroup per (clip, 16-key block): the block's key rows are read as whole 3 KB token-row slices (coalesced), converted,
-// placed at their fragment positions in LDS (48 KB for 12 heads) and written out as 4 KB of consecutive bytes per head -- the
-// direct version (one thread per 8 channels, two scattered 16-byte stores each) took 7.2 / 11.2 us at 672^2 / 1024^2.
+// One workgroup per (clip, 16-key block, group of 4 heads): the block's key rows are read as 1 KB token-row slices
+// (coalesced), converted, placed at their fragment positions in LDS and written out as 4 KB of consecutive bytes per head
+// (one thread per 8 channels with two scattered 16-byte stores each: 11.2 us at 1024^2; one workgroup for all 12 heads of a
+// block: 111 workgroups at 672^2, 7.5 us).
+constexpr int SKH = 4;   // heads per workgroup
 __global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
-  uint4* tile = reinterpret_cast<uint4*>(sk_smem);   // [H][256] uint4: head h's 4 KB block in its final order
+  __shared__ __attribute__((aligned(16))) uint4 tile[SKH * 256];   // [head][256]: a head's 4 KB block in its final order
   const int b = blockIdx.x / NKB, kb = blockIdx.x - b * NKB;
-  const int units = 16 * H * 8;                      // (key i, head h, 8-channel group c8), c8 fastest: 32 consecutive bytes each
+  const int h0 = blockIdx.y * SKH, nh = min(SKH, H - h0);
+  const int units = 16 * nh * 8;                     // (key i, head, 8-channel group c8), c8 fastest: 32 consecutive bytes each
   for (int u = threadIdx.x; u < units; u += 256) {
-    const int c8 = u & 7, hh = (u >> 3) % H, i = (u >> 3) / H, key = kb * 16 + i;
+    const int c8 = u & 7, hh = (u >> 3) % nh, i = (u >> 3) / nh, key = kb * 16 + i;
     bf16x8_t hi = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
     if (key < N) {
-      const float* src = qkv + ((int64_t)b * N + key) * 3 * (int64_t)D + D + hh * SDH + c8 * 8;
+      const float* src = qkv + ((int64_t)b * N + key) * 3 * (int64_t)D + D + (h0 + hh) * SDH + c8 * 8;
       const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
-      bf16x4_t h0, l0, h1, l1;
-      split4(x, &h0, &l0);
-      split4(y, &h1, &l1);
-      hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      bf16x4_t hx, lx, hy, ly;
+      split4(x, &hx, &lx);
+      split4(y, &hy, &ly);
+      hi = __builtin_shufflevector(hx, hy, 0, 1, 2, 3, 4, 5, 6, 7);
+      lo = __builtin_shufflevector(lx, ly, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     // final position p = hh * 256 + (2 m + hl) * 64 + kg * 16 + i; in LDS the low four bits are rotated by the piece's
     // (c8 + 8 hh): a wave's lanes share i and differ in (c8, hh), un-rotated they would all hit the same four banks
@@ -145,9 +147,9 @@ __global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict
     dst[64] = __builtin_bit_cast(uint4, lo);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < H * 256; e += 256) {
+  for (int e = threadIdx.x; e < nh * 256; e += 256) {
     const int hh = e >> 8, g = e >> 4, c8 = ((g >> 3) & 1) * 4 + (g & 3);
-    out[(((int64_t)b * H + hh) * NKB + kb) * 256 + (e & 255)] = tile[(e & ~15) | ((e + c8 + 8 * hh) & 15)];
+    out[(((int64_t)b * H + h0 + hh) * NKB + kb) * 256 + (e & 255)] = tile[(e & ~15) | ((e + c8 + 8 * hh) & 15)];
   }
 }
 
@@ -798,10 +800,8 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
   if (QK == 2) {
     const int nkb = (a.N + 15) / 16;
-    const size_t sk_lds = (size_t)a.H * 4096;
-    EVT_ALLOW_LDS(split_keys_kernel, sk_lds);
-    hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb)), dim3(256), sk_lds, s, a.qkv, reinterpret_cast<uint4*>(a.k_split),
-                       a.B, a.H, a.N, a.D, nkb);
+    hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb), (unsigned)((a.H + SKH - 1) / SKH)), dim3(256), 0, s, a.qkv,
+                       reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, nkb);
   }
   hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
 }

@@ -149,7 +149,7 @@ def _bind(lib):
         "evt_pool_kv": [P, I, I, I, I, I, I, P, P],
         "evt_pool_index": [P, P, I, I, I, I, I, I, I, I, P, P, P],
         "evt_softmax_av_gated": [POINTER(SoftmaxAvDesc), P],
-        "evt_rel_terms": [P, P, P, I, I, I, I, I, I, I, P, P],
+        "evt_rel_terms": [P, P, P, I, I, I, I, I, I, I, I, P, P],
         "evt_attention_dense": [POINTER(AttnDenseDesc), P],
         "evt_attention_stream": [POINTER(AttnStreamDesc), P],
         "evt_av": [POINTER(AvDesc), P],
@@ -467,10 +467,12 @@ def pool_index(idx, count, B, kcap, qw, p0, p1, kw, Nk, kcap_k, idx_k, count_k):
                                  _stream()))
 
 
-def rel_terms(qkv, rel_y, rel_x, B, H, N, D, gh, gw, qw, out):
+def rel_terms(qkv, rel_y, rel_x, B, H, N, D, gh, gw, qw, out, split=None):
     """Decomposed rel-pos terms of every query token (utils.py:159-168): out (B,H,N,gh+gw), read by the fused attention
-    kernel instead of recomputing them per 32-row workgroup."""
-    _check(load().evt_rel_terms(_p(qkv), _p(rel_y), _p(rel_x), B, H, N, D, gh, gw, qw, _p(out), _stream()))
+    kernels instead of recomputing them per 32-row workgroup.  split (default: the scores' arithmetic, EVT_QK_SPLIT): bf16
+    hi/lo MFMA products vs fp32 FMA chains."""
+    _check(load().evt_rel_terms(_p(qkv), _p(rel_y), _p(rel_x), B, H, N, D, gh, gw, qw,
+                                int(QK_SPLIT if split is None else split), _p(out), _stream()))
 
 
 def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv, out_f32, B, H, N, D, store,

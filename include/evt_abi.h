@@ -372,9 +372,11 @@ EVT_API int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream);
  * `add_decomposed_rel_pos`): terms[b,h,i,e] = q[b,i,h,:] . rel_y[i / qw, e, :] for e < gh and
  * q[b,i,h,:] . rel_x[i % qw, e - gh, :] for gh <= e < gh + gw.  One workgroup per (clip, head, query-grid row or
  * column): its rel_y / rel_x slice and its q rows are read once (a 32-row attention workgroup computing the same
- * terms for itself re-reads 32 x (gh + gw) table rows of 256 bytes).  Head dim 64, N = qh * qw. */
+ * terms for itself re-reads 32 x (gh + gw) table rows of 256 bytes).  Head dim 64, N = qh * qw.
+ * split (ABI 5): 1 = on the matrix cores with q and the tables as bf16 hi + lo (three bf16 MFMAs per product, ~1e-5
+ * relative: the arithmetic of split-mode scores), 0 = fp32 FMA chains. */
 EVT_API int evt_rel_terms(const float* qkv, const float* rel_y, const float* rel_x, int32_t B, int32_t H, int32_t N,
-                          int32_t D, int32_t gh, int32_t gw, int32_t qw, float* terms, void* stream);
+                          int32_t D, int32_t gh, int32_t gw, int32_t qw, int32_t split, float* terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K5+K6 for LARGE token counts, scores computed in the kernel (ABI 5; ViTDet global blocks, N = 1764 / 4096):
