@@ -15,13 +15,17 @@ frames = sel / 36.0
 if frames < 1:   # the selections are embedded in the gated linears: count the global blocks' rel-pos launches (4 per frame)
     frames = sum(1 for k in ks if "rel_terms_kernel" in k[2]) / 4.0
 tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
+durs = collections.defaultdict(list)
 prev = ks[0][0]
 for s, e, n, g, w in ks:
     t = tot[short(n)]
     t[0] += 1; t[1] += (e - s) / 1e3; t[2] += min(max(0, s - prev), 50_000) / 1e3
+    durs[short(n)].append((e - s) / 1e3)
     prev = max(prev, e)
 busy = sum(v[1] for v in tot.values()); gaps = sum(v[2] for v in tot.values())
 print(f"{len(ks)} kernels, ~{frames:.1f} gated frames; per frame: busy {busy / frames:.1f} us, gaps {gaps / frames:.1f} us")
-print(f"{'kernel':70s} {'n/frame':>8s} {'us/frame':>9s} {'avg us':>8s} {'gap/frame':>9s}")
+print(f"{'kernel':70s} {'n/frame':>8s} {'us/frame':>9s} {'avg us':>8s} {'gap/frame':>9s}  p10 / p50 / p90 us")
 for n, (c, d, gp) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
-    print(f"{n:70s} {c / frames:8.1f} {d / frames:9.1f} {d / c:8.1f} {gp / frames:9.1f}")
+    v = sorted(durs[n])
+    pct = lambda q: v[min(len(v) - 1, int(q * len(v)))]   # a kernel launched in several roles (shapes) shows up as a spread
+    print(f"{n:70s} {c / frames:8.1f} {d / frames:9.1f} {d / c:8.1f} {gp / frames:9.1f}  {pct(0.1):5.1f} / {pct(0.5):5.1f} / {pct(0.9):5.1f}")
