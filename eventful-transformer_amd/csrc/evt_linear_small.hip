@@ -43,7 +43,7 @@ typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
 // workgroup that owns a clip's first row in column tile 0 writes the index list (+ count, complement list) to HBM for the
 // later kernels of the block.
 template <int ACT, int BM, int BN, bool PARTIAL, int NW, bool LOOPED, bool SEL>
-__global__ __launch_bounds__(64 * NW) void gated_linear_small_kernel(const LinArgs g, int tiles_n, int ksplit, int gm) {
+__global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_kernel(const LinArgs g, int tiles_n, int ksplit, int gm) {
   constexpr int MI = BM / 32, NJ = BN / 32, SMALL_THREADS = 64 * NW;
   constexpr int AJ = BM / 8, WJ = BN / 8;                 // 16-byte pieces per lane per k-tile: 8 rows x 8 chunks per wave instruction
   constexpr int WSTAGE = 2 * BM * 32 + 2 * BN * 32;       // bf16 elements of one wave's stage: A hi, A lo, W hi, W lo
@@ -67,25 +67,34 @@ __global__ __launch_bounds__(64 * NW) void gated_linear_small_kernel(const LinAr
   const int split = PARTIAL ? (int)blockIdx.z : 0;
   const int M = g.B * g.kcap;
   // XCD-aware tile order (workgroup w runs on XCD w % 8): all row tiles of a column tile run on ONE XCD, so a weight tile
-  // is fetched into one private L2 instead of one per row tile.  Column tile bn belongs to XCD bn % 8; the grid is padded
-  // to 8 x ceil(tiles_n / 8) x gm and the surplus workgroups leave.  gm = row tiles launched: all of them, or -- one
+  // is fetched into one private L2 (two for a tile that straddles a run boundary) instead of one per row tile; the grid is
+  // padded to a multiple of 8 and the surplus workgroups leave.  gm = row tiles launched: all of them, or -- one
   // stream under the threshold policy, kcap = N rows of which count[0] are live -- enough for 512 rows, each workgroup
   // walking row tiles bm, bm + gm, ... below the device-side count (a grid over all kcap / BM row tiles would start
   // thousands of 512-thread workgroups only to retire them).
+  // (The (column tile, row tile) pairs in column-major order are dealt to the XCDs in eight CONTIGUOUS, equally long runs:
+  // "column tile bn on XCD bn % 8" gave XCDs 0-3 five column tiles and XCDs 4-7 four at Nout = 2304 -- 35 workgroups on a
+  // 32-CU XCD with 7 row tiles, i.e. a second round for three of them: QKV at M = 409 took 22.5 us against 12.7 at M = 256.)
   const int x8 = blockIdx.x & 7, s8 = blockIdx.x >> 3;
-  const int bn = (s8 / gm) * 8 + x8;
-  if (bn >= tiles_n) return;
-  const int n0 = bn * BN;
+  const int total = tiles_n * gm, q8 = total >> 3, r8 = total & 7;
+  if (s8 >= q8 + (x8 < r8 ? 1 : 0)) return;
+  const int t8 = x8 * q8 + min(x8, r8) + s8;
+  const int bn = t8 / gm, bm_first = t8 - bn * gm;
   int sel_cnt = 0;
   if (SEL && LOOPED) {   // one stream: the selection once, in front of the row-tile loop; idx_l stays valid throughout
-    const bool writer = bn == 0 && split == 0 && (s8 % gm) == 0;
+    const bool writer = bn == 0 && split == 0 && bm_first == 0;
     sel_cnt = evt_select_block<SMALL_THREADS>(g.sel_norms, g.sel_parts, g.sel_N, g.sel_k, g.sel_thr, g.sel_mode, g.kcap, sel_smem, idx_l,
                                               writer ? g.sel_idx : nullptr, writer ? g.sel_count : nullptr, writer ? g.sel_rest : nullptr);
     __syncthreads();
   }
   const int rows_live = LOOPED ? min(M, SEL ? sel_cnt : g.count[0]) : M;
-  for (int bm = s8 % gm; bm * BM < rows_live; bm += gm) {
+  const int n0_inv = bn * BN;
+  for (int bm = bm_first; bm * BM < rows_live; bm += gm) {
   const int m0 = bm * BM;
+  // (LOOPED: the column offset and the lane index are made opaque per iteration -- hoisted out of the row-tile loop, everything
+  // derived from them stays live across the epilogue, and the 64x64 variant needed 256 VGPR + 116 AGPR: one wave per SIMD)
+  int n0 = n0_inv, lane_v = lane;
+  if (LOOPED) { asm volatile("" : "+s"(n0)); asm volatile("" : "+v"(lane_v)); }
 
   // k range of this workgroup (whole 32-k tiles), then of this wave
   const int nk_all = g.K / 32, kps = (nk_all + ksplit - 1) / ksplit;
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void gated_linear_small_kernel(const LinAr
   // ---- staging assignment: lane -> row (lane >> 3) + 8 j, 16-byte chunk lane & 7 of the row's 128-byte k-tile.  One wave
   // instruction reads 8 whole 128-byte lines.  (Row-per-lane loads straight into MFMA fragments -- 32 lines per
   // instruction, each touched by four instructions -- made the launch L1-tag-bound: 21 us for QKV at M = 256.)
-  const int sr = lane >> 3, sc = lane & 7;
+  const int sr = lane_v >> 3, sc = lane_v & 7;
   const int64_t wpitch = hl32_pitch(g.K);
   // 32-bit byte offsets from the (scalar) base pointers: the 64x64 tile sits at the register limit of two waves per SIMD
   // (the launcher guarantees activations and weight planes below 2 GB)
@@ -297,7 +306,7 @@ void launch_small_inst(const LinArgs& a, hipStream_t s, int ksplit, int tiles_n,
   const size_t stages = (size_t)NW * (2 * BM * 32 + 2 * BN * 32) * 2;
   const size_t front = SEL ? std::max(stages, (size_t)evt_select_smem_words(a.sel_N) * 4) : stages;
   const size_t lds = front + (size_t)BM * sizeof(int64_t) + (SEL ? (size_t)a.kcap * sizeof(int32_t) : 0);
-  const dim3 grid(8 * ((tiles_n + 7) / 8) * gm, 1, ksplit);
+  const dim3 grid(8 * ((tiles_n * gm + 7) / 8), 1, ksplit);
   if (ksplit > 1) {
     EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), lds);
     hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), grid, dim3(64 * NW), lds, s, a, tiles_n, ksplit, gm);
@@ -353,6 +362,10 @@ int evt_launch_split_small(const LinArgs& a, hipStream_t s) {
   int bm = 64, ks = 1;
   auto wgs = [&](int b) { return ((live + b - 1) / b) * ((a.Nout + b - 1) / b); };
   if (wgs(64) < 128) bm = 32;
+  // One stream under a device-side count: the row-tile loop costs the 64x64 variant its occupancy (256 VGPR + 116 AGPR with four
+  // waves = 4 waves per CU; with eight waves it spills) -- at count = 409 of 4096 rows QKV 28.4 us / MLP-1 28.3 us against
+  // 20.4 / 22.2 us on 32x32 tiles (146 + 16 registers, three workgroups per CU).
+  if (counted_ && a.B == 1) bm = 32;
   static const int force_tile = getenv("EVT_SMALL_TILE") ? atoi(getenv("EVT_SMALL_TILE")) : 0;
   static const int force_ks = getenv("EVT_SMALL_KS") ? atoi(getenv("EVT_SMALL_KS")) : 0;
   if (force_tile == 32 || force_tile == 64) bm = force_tile;
