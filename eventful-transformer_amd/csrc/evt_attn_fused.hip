@@ -521,37 +521,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       const float* rv = relv + r * nrel;
       const float* prow = prod + (int64_t)i * a.Nk;
       float mx = -INFINITY, sum = 0.f;
-      if (false) {
-        for (int j0 = 0; j0 < a.Nk; j0 += 2048) {
-          float4 x4[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = j0 + (lane + 64 * u) * 4;
-            x4[u] = (j < a.Nk) ? *reinterpret_cast<const float4*>(prow + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-          }
-          if (rel) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int j = j0 + (lane + 64 * u) * 4;
-              if (j < a.Nk) {
-                float* xe = reinterpret_cast<float*>(&x4[u]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const int ky = fast_div(j + q, inv_gw); xe[q] = (xe[q] + rv[ky]) + rv[a.gh + j + q - ky * a.gw]; }
-              }
-            }
-          }
-          float cm = -INFINITY;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) cm = fmaxf(cm, fmaxf(fmaxf(x4[u].x, x4[u].y), fmaxf(x4[u].z, x4[u].w)));
-          const float nm = fmaxf(mx, cm);
-          float part = 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            part += (fast_exp(x4[u].x - nm) + fast_exp(x4[u].y - nm)) + (fast_exp(x4[u].z - nm) + fast_exp(x4[u].w - nm));
-          sum = (nm == -INFINITY) ? 0.f : sum * fast_exp(mx - nm) + part;
-          mx = nm;
-        }
-      } else
       for (int j0 = 0; j0 < a.Nk; j0 += 512) {
         float x[8];
 #pragma unroll

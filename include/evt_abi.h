@@ -35,8 +35,9 @@ extern "C" {
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
-                                 5: evt_attention_stream, evt_attn_dense_desc.qk_split, embedded selection (sel_* fields of
-                                    evt_linear_desc / evt_mlp_desc, evt_gated_linear_embeds_select) */
+                                 5: evt_attention_stream (+ its k_split workspace), evt_attn_dense_desc.qk_split, the `split`
+                                    argument of evt_rel_terms, embedded selection (sel_* fields of evt_linear_desc /
+                                    evt_mlp_desc, evt_gated_linear_embeds_select) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# generic round-3 GPU job: $1 = output tag, rest = what to do (see case below)
+# GPU job steps for the one-stream (ViTDet) work: $1 = output tag, rest = what to do (see case below)
 set -u
 TAG=$1; shift
 OUT=gpurun_out/$TAG
