@@ -233,10 +233,12 @@ def test_gated_linear(B, N, K, Nout, k, act, gemm_mode):
     assert torch.allclose(out.cpu(), yd.float(), atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("M,K,Nout,act", [(256, 3072, 768, 0), (256, 768, 3072, 1), (196, 768, 2304, 0), (50, 1024, 1024, 0)])
+@pytest.mark.parametrize("M,K,Nout,act", [(256, 3072, 768, 0), (256, 768, 3072, 1), (196, 768, 2304, 0), (50, 1024, 1024, 0),
+                                          (409, 768, 2304, 0), (409, 768, 3072, 1), (1000, 3072, 768, 0)])
 def test_splitk_small_launch(M, K, Nout, act):
-    """Few-tile launches take the split-K path (fixed-order partial sums): same accuracy, bit-reproducible,
-    scatter / count / fused p refresh unchanged."""
+    """Few-tile launches (one video stream: the small-row-count kernel with its in-CU K split, or split-K over workgroups with
+    fixed-order partial sums): same accuracy, bit-reproducible, scatter / count / fused p refresh unchanged.  M = 409 and
+    1000: (column, row) tile counts that do not divide by the 8 XCD runs of the tile order."""
     n = native()
     if n.GEMM_MODE != "split":
         pytest.skip("split-K belongs to the split-precision kernel")
@@ -272,7 +274,7 @@ def test_splitk_small_launch(M, K, Nout, act):
     assert err < 2e-5, float(err)
 
 
-@pytest.mark.parametrize("counts", [[100], [1000], [0], [130, 5, 1024]])
+@pytest.mark.parametrize("counts", [[100], [1000], [0], [130, 5, 1024], [409], [1]])
 def test_splitk_dynamic_counts(counts):
     """Threshold-policy launches (kcap = N, per-clip counts on the device): the split-K factor is picked by the
     workgroups from the counts -- few live tiles -> split + finish kernel, many -> single pass under the same
