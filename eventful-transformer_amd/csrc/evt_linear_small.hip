@@ -75,11 +75,24 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
   // (The (column tile, row tile) pairs in column-major order are dealt to the XCDs in eight CONTIGUOUS, equally long runs:
   // "column tile bn on XCD bn % 8" gave XCDs 0-3 five column tiles and XCDs 4-7 four at Nout = 2304 -- 35 workgroups on a
   // 32-CU XCD with 7 row tiles, i.e. a second round for three of them: QKV at M = 409 took 22.5 us against 12.7 at M = 256.)
-  const int x8 = blockIdx.x & 7, s8 = blockIdx.x >> 3;
-  const int total = tiles_n * gm, q8 = total >> 3, r8 = total & 7;
-  if (s8 >= q8 + (x8 < r8 ? 1 : 0)) return;
-  const int t8 = x8 * q8 + min(x8, r8) + s8;
-  const int bn = t8 / gm, bm_first = t8 - bn * gm;
+  // Under a device-side count (LOOPED) the launch does not know how many of its gm row tiles are live: row-major order
+  // instead, column tile bn on XCD bn % 8 (the column count padded to a multiple of 8) -- the live row tiles are dispatched
+  // first and every XCD gets the same share of each; the dead ones retire behind them (with 13 of 16 row tiles live, the
+  // column-major runs cost QKV 18.5 us against 15.9 us for a launch of exactly 13).
+  int bn, bm_first;
+  if (LOOPED) {
+    const int tn8 = (tiles_n + 7) & ~7;
+    bm_first = (int)blockIdx.x / tn8;
+    bn = (int)blockIdx.x - bm_first * tn8;
+    if (bn >= tiles_n) return;
+  } else {
+    const int x8 = blockIdx.x & 7, s8 = blockIdx.x >> 3;
+    const int total = tiles_n * gm, q8 = total >> 3, r8 = total & 7;
+    if (s8 >= q8 + (x8 < r8 ? 1 : 0)) return;
+    const int t8 = x8 * q8 + min(x8, r8) + s8;
+    bn = t8 / gm;
+    bm_first = t8 - bn * gm;
+  }
   int sel_cnt = 0;
   if (SEL && LOOPED) {   // one stream: the selection once, in front of the row-tile loop; idx_l stays valid throughout
     const bool writer = bn == 0 && split == 0 && bm_first == 0;
@@ -306,7 +319,7 @@ void launch_small_inst(const LinArgs& a, hipStream_t s, int ksplit, int tiles_n,
   const size_t stages = (size_t)NW * (2 * BM * 32 + 2 * BN * 32) * 2;
   const size_t front = SEL ? std::max(stages, (size_t)evt_select_smem_words(a.sel_N) * 4) : stages;
   const size_t lds = front + (size_t)BM * sizeof(int64_t) + (SEL ? (size_t)a.kcap * sizeof(int32_t) : 0);
-  const dim3 grid(8 * ((tiles_n * gm + 7) / 8), 1, ksplit);
+  const dim3 grid(LOOPED ? ((tiles_n + 7) & ~7) * gm : 8 * ((tiles_n * gm + 7) / 8), 1, ksplit);
   if (ksplit > 1) {
     EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), lds);
     hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), grid, dim3(64 * NW), lds, s, a, tiles_n, ksplit, gm);
@@ -321,7 +334,12 @@ void launch_small_tile(const LinArgs& a, hipStream_t s, int ksplit) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (a.Nout + BN - 1) / BN;
   const bool looped = (a.count != nullptr || (a.sel_norms != nullptr && a.sel_mode == 1)) && a.B == 1;
-  const int gm = looped ? std::min(tiles_m, 512 / BM) : tiles_m;
+  // row tiles launched under a device-side count: enough for 512 rows, but not more (column, row) pairs than CUs when that
+  // still covers 256 rows -- a 9th workgroup on a 32-CU XCD is a second round
+  static const int gm_env = getenv("EVT_SMALL_GM") ? atoi(getenv("EVT_SMALL_GM")) : 0;
+  int gm_l = std::min(tiles_m, 512 / BM);
+  if (gm_env > 0) gm_l = std::min(tiles_m, gm_env);
+  const int gm = looped ? gm_l : tiles_m;
   if (a.sel_norms != nullptr) {
     if (looped) launch_small_inst<ACT, BM, BN, 4, true, true>(a, s, ksplit, tiles_n, gm);
     else launch_small_inst<ACT, BM, BN, 8, false, true>(a, s, ksplit, tiles_n, gm);
