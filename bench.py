@@ -988,8 +988,24 @@ def wrapper_legs(device):
         model(clips)
         torch.cuda.synchronize()
         el8 = time.perf_counter() - t0
+        # batch 1 again with the spatial steps replayed as HIP graphs, frame by frame and with 3 time steps in flight
+        replay = {}
+        for lanes in (1, 3):
+            model.use_frame_graphs(lanes)
+            model(clips[:1])
+            model(clips[1:2])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(clips.shape[0]):
+                probs_g = model(clips[i:i + 1])
+            torch.cuda.synchronize()
+            replay[lanes] = (time.perf_counter() - t0, bool(torch.equal(probs_g, probs)))
+        model.use_frame_graphs(0)
     out["vivit_e2e"] = {"clips_s": round(clips.shape[0] / el, 2), "ms_per_clip": round(el / clips.shape[0] * 1e3, 2),
                         "clips_s_batch8": round(clips.shape[0] / el8, 2),
+                        "clips_s_graph_replay": round(clips.shape[0] / replay[1][0], 2),
+                        "clips_s_graph_replay_3_in_flight": round(clips.shape[0] / replay[3][0], 2),
+                        "graph_replay_bit_identical": replay[1][1] and replay[3][1],
                         "config": "FactorizedViViT-B, uint8 (1,80,3,224,224) video -> 400 class probabilities, 2 temporal views x 16 "
                                   "spatial steps (top-k 128, fp32), batch 1 per call (eager launches: host-bound)",
                         "probs_sum": round(float(probs.sum()), 5)}

@@ -158,6 +158,7 @@ class FactorizedViViT(ExtendedModule):
         self.temporal_model = ViViTSubModel((input_t // tubelet_shape[0],), temporal_config)
         self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0.0 else nn.Identity()
         self.classifier = CountedLinear(in_features=dim, out_features=classes)
+        self._frames, self._frames_in_flight = None, 1   # see use_frame_graphs
 
     def forward(self, x):
         clips = x.shape[0]
@@ -173,10 +174,39 @@ class FactorizedViViT(ExtendedModule):
             return self._forward_view(torch.stack(views, dim=1).flatten(end_dim=1))
         return torch.stack([self._forward_view(v) for v in views], dim=1).flatten(end_dim=1)
 
+    def use_frame_graphs(self, frames_in_flight=1):
+        """MI355X addition (no counterpart in the reference, whose spatial steps run eagerly): replay the spatial sub-model's
+        per-step launches as HIP graphs (eventful_transformer.graphs.FrameGraphs), optionally with `frames_in_flight`
+        consecutive time steps of a view side by side (`run_pipelined`).  Same kernels on the same state: bit-identical
+        probabilities; at batch 1 the eager steps are bound by the host's launch rate.  Pass 0 to go back to eager steps."""
+        from eventful_transformer.graphs import FrameGraphs
+
+        if self._frames is not None:
+            self._frames.release()
+        self._frames = FrameGraphs(self.spatial_model) if frames_in_flight >= 1 else None
+        self._frames_in_flight = max(1, int(frames_in_flight))
+
     def _forward_view(self, x):
         tokens = self.embedding(x.contiguous())  # (views, time, patches, dim)
+        if self._frames is not None:
+            return self._forward_view_graphs(tokens)
         self.spatial_model.reset()
         return torch.stack([self.spatial_model(tokens[:, t]) for t in range(tokens.shape[1])], dim=1)
+
+    def _forward_view_graphs(self, tokens):
+        frames, P, T = self._frames, self._frames_in_flight, tokens.shape[1]
+        steps = tokens.transpose(0, 1).contiguous()          # (time, views, patches, dim)
+        frames.reset()
+        out = [frames(steps[0]).clone()]
+        t = 1
+        while t < T:
+            if P > 1 and t + P <= T:
+                out += [y.clone() for y in frames.run_pipelined(steps[t:t + P])]
+                t += P
+            else:
+                out.append(frames(steps[t]).clone())
+                t += 1
+        return torch.stack(out, dim=1)
 
     def _forward_temporal(self, x, clips):
         x = x.reshape((-1,) + tuple(x.shape[-2:])).contiguous()

@@ -42,6 +42,30 @@ def test_vivit_clip_classification_end_to_end(golden_dir):
     assert e_feat <= 2e-3 and e_logit <= 1e-3 and e_prob <= 1e-5, (e_feat, e_logit, e_prob)
 
 
+def test_vivit_end_to_end_graph_replay_is_bit_identical(golden_dir):
+    """FactorizedViViT.use_frame_graphs: the spatial steps replayed as HIP graphs, frame by frame and with three time steps of a
+    view in flight, give bit for bit the probabilities of the eager steps (same kernels, same state, same per-block order) --
+    over two different clips each, so that capture, first replay and later replays are all compared."""
+    from eventful_transformer import policies
+    from models.vivit import FactorizedViViT
+    g = H.load_npz(os.path.join(golden_dir, "models.npz"))
+    seed, k = int(g["vivit__seed"]), int(g["vivit__k"])
+    model = FactorizedViViT(**H.VIVIT_B_CONFIG)
+    model.load_state_dict(H.seeded_module_params(model, seed), strict=True)
+    model = model.eval().to(DEV)
+    H.set_policies(model, policies.TokenNormTopK, k=k)
+    clips = [H.synthetic_video(seed + 1 + c).to(DEV) for c in range(3)]
+    with torch.inference_mode():
+        want = [model(c).clone() for c in clips]
+        for lanes in (1, 3):
+            model.use_frame_graphs(lanes)
+            got = [model(c).clone() for c in clips]
+            for w_, g_ in zip(want, got):
+                assert torch.equal(w_, g_), (lanes, float((w_ - g_).abs().max()))
+        model.use_frame_graphs(0)
+        assert torch.equal(model(clips[0]), want[0])
+
+
 def test_vitdet_pre_backbone_and_pyramid(golden_dir):
     """models/vitdet.py of this package vs the reference's ViTDetPreprocessing + LinearEmbedding (patch GEMM) and
     SimplePyramid (transposed convs as four scatter-GEMMs, 1x1 / 3x3 convs as GEMMs, LayerNorm row passes)."""
