@@ -1032,10 +1032,41 @@ def wrapper_legs(device):
                 det.post_backbone(images, x)
                 torch.cuda.synchronize(); t3 = time.perf_counter()
                 pre.append(t1 - t0); bb.append(t2 - t1); post.append(t3 - t2)
+    # the whole frame (uint8 image -> pyramid features) as ONE HIP graph per frame, and with 4 frames of the stream in flight
+    from eventful_transformer.graphs import FrameGraphs
+    whole = {}
+    with torch.inference_mode():
+        det.reset()
+        want = {k_: v.clone() for k_, v in det(frames[0]).items()}
+        want = {k_: v.clone() for k_, v in det(frames[1]).items()}
+        runner = FrameGraphs(det)
+        for rep in range(3):
+            runner.reset()
+            runner(frames[0])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            got = runner(frames[1])
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for t in range(2, frames.shape[0]):
+                runner(frames[t])
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            if rep == 0:
+                whole["bit_identical"] = all(bool(torch.equal(got[k_], want[k_])) for k_ in want)
+        whole["ms"] = (t2 - t1) / (frames.shape[0] - 2) * 1e3
+        seq = torch.stack([frames[1 + (i % (frames.shape[0] - 1))] for i in range(16)])
+        runner.reset(); runner(frames[0])
+        runner.run_pipelined(seq[0:4]); runner.run_pipelined(seq[4:8])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        runner.run_pipelined(seq[8:12]); runner.run_pipelined(seq[12:16])
+        torch.cuda.synchronize()
+        whole["ms_pipelined_4"] = (time.perf_counter() - t0) / 8 * 1e3
+        runner.release()
     nf = slice(1, None)
     out["vitdet_e2e_672"] = {"pre_backbone_ms": round(sum(pre[nf]) / len(pre[nf]) * 1e3, 3),
                              "backbone_ms_eager": round(sum(bb[nf]) / len(bb[nf]) * 1e3, 3),
                              "post_backbone_ms": round(sum(post[nf]) / len(post[nf]) * 1e3, 3),
+                             "frame_ms_graph_replay": round(whole["ms"], 3),
+                             "frame_ms_graph_replay_4_in_flight": round(whole["ms_pipelined_4"], 3),
+                             "graph_replay_bit_identical": whole["bit_identical"],
                              "config": "ViTDet-B 672^2 up to the pyramid (p2..p6), uint8 frame in, one stream, top-k 256, non-first frames, "
                                        "eager launches (scripts/time/vitdet_vid.py:33-45 split)"}
     del det, frames

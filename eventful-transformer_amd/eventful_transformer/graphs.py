@@ -161,7 +161,7 @@ class FrameGraphs:
             ys = []
             for j in range(P):
                 with _native.lane(j):
-                    ys.append(self._fwd(xs[j].contiguous()).clone())
+                    ys.append(_clone_out(self._fwd(xs[j].contiguous())))
             self._pipe_warm = P
             self._t += P
             return ys
@@ -172,6 +172,17 @@ class FrameGraphs:
         graph.replay()
         self._t += P
         return ys
+
+
+def _clone_out(y):
+    """Copy of a forward's output: a tensor, or a dict / list / tuple of outputs (model wrappers return feature dicts)."""
+    if isinstance(y, torch.Tensor):
+        return y.clone()
+    if isinstance(y, dict):
+        return {k: _clone_out(v) for k, v in y.items()}
+    if isinstance(y, (list, tuple)):
+        return type(y)(_clone_out(v) for v in y)
+    return y
 
 
 class _LaneSync:

@@ -89,12 +89,20 @@ class ViTDetPreprocessing(nn.Module):
         self.input_shape = tuple(input_shape)
         self.normalize_mean = normalize_mean
         self.normalize_std = normalize_std
+        self._stats = {}   # (dtype, device) -> (mean, std) on the device: built once, outside any HIP-graph capture
+
+    def _mean_std(self, x):
+        key = (x.dtype, x.device)
+        if key not in self._stats:
+            mean = torch.as_tensor(self.normalize_mean, dtype=x.dtype, device=x.device)
+            std = torch.as_tensor(self.normalize_std, dtype=x.dtype, device=x.device)
+            if mean.ndim:
+                mean, std = mean.view(-1, 1, 1), std.view(-1, 1, 1)
+            self._stats[key] = (mean, std)
+        return self._stats[key]
 
     def forward(self, x):
-        mean = torch.as_tensor(self.normalize_mean, dtype=x.dtype, device=x.device)
-        std = torch.as_tensor(self.normalize_std, dtype=x.dtype, device=x.device)
-        if mean.ndim:
-            mean, std = mean.view(-1, 1, 1), std.view(-1, 1, 1)
+        mean, std = self._mean_std(x)
         x = (x * 255.0 - mean) / std
         h, w = self.input_shape[-2:]
         return F.pad(x, (0, w - x.shape[-1], 0, h - x.shape[-2]))
