@@ -51,6 +51,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured copy ceiling)
 VITDET_WINDOWED = (0, 1, 3, 4, 6, 7, 9, 10)   # configs/models/vitdet_b_coco.yml:13
+# Random-init weights: normal(0, 0.02), except the query / key rows of every `qkv` layer in the ViViT workloads and in vitdet1024,
+# which are drawn at 0.06 -- with 0.02 the attention is near-uniform and the projection gate's delta norms are near-tied (median top-k
+# margin 1.7e-4), so its index sets could not be compared with the reference at any meaningful margin (oracle.sharpen_qk; same
+# shapes and launches, the timing does not depend on it).
+QK_STD = 0.06
 
 WORKLOADS = {
     #              kind      block class      frames  k     cast        grid
@@ -84,9 +89,22 @@ def launch_ranks(n, argv, backend_env=None):
 # ------------------------------------------------------------------------------------------------------
 # parameters and synthetic inputs
 # ------------------------------------------------------------------------------------------------------
-def seeded_state_dict(seed=77, std=0.02):
+def _sharpen_qk(sd, prefix, qk_std, std):
+    for i in range(DEPTH):
+        for nm in ("qkv.weight", "qkv.bias"):
+            w = sd[f"{prefix}blocks.{i}.{nm}"].clone()
+            w[: 2 * DIM] *= qk_std / std
+            sd[f"{prefix}blocks.{i}.{nm}"] = w
+    return sd
+
+
+def seeded_state_dict(seed=77, std=0.02, qk_std=QK_STD):
     """ViViT-B spatial sub-model parameters under the reference's state_dict names (ViViTSubModel,
     vivit.py:272-291).  Version-stable generator (numpy RandomState), as in the parity tests."""
+    return _sharpen_qk(_seeded_state_dict(seed, std), "backbone.", qk_std, std)
+
+
+def _seeded_state_dict(seed, std):
     rs = np.random.RandomState(seed)
 
     def n(*shape, s=std):
@@ -137,8 +155,13 @@ def vitdet_state_dict_shapes():
     return sd
 
 
-def vitdet_state_dict(seed=91, std=0.02):
+def vitdet_state_dict(seed=91, std=0.02, qk_std=None):
     """ViTDet-B backbone parameters (vitdet_b_coco.yml: 12 blocks, rel-pos tables 64x64 global / 14x14 windowed)."""
+    sd = _vitdet_state_dict(seed, std)
+    return sd if qk_std is None else _sharpen_qk(sd, "", qk_std, std)
+
+
+def _vitdet_state_dict(seed, std):
     rs = np.random.RandomState(seed)
 
     def n(*shape, s=std):
@@ -175,16 +198,19 @@ def synthetic_clips(batch, frames, k, seed, device, tokens=TOKENS):
     return torch.stack(out)
 
 
-def threshold_stream(frames, seed, device, tokens, frac=0.1, big=0.5, small=1e-3):
-    """(T, 1, tokens, D): each frame ~10 % of the tokens move by N(0, 0.5^2), the rest by N(0, 1e-3^2)."""
+def threshold_stream(frames, seed, device, tokens, lo=1e-4, hi=1.0, frac=(0.02, 0.15)):
+    """(T, 1, tokens, D) with CONTINUOUS perturbation magnitudes (the device-side twin of oracle.make_varied_threshold_stream):
+    each frame a fraction f ~ U(frac) of the tokens moves by N(0, s^2) with a per-token log-uniform s in [lo, hi], the rest jitter
+    by N(0, lo^2) -- every gate's selected-token count depends on the data, the frame and the threshold."""
     g = torch.Generator(device=device).manual_seed(seed)
     cur = torch.randn(1, tokens, DIM, generator=g, device=device)
     out = [cur]
     for _ in range(1, frames):
-        cur = cur + small * torch.randn(1, tokens, DIM, generator=g, device=device)
-        pick = torch.rand(1, tokens, generator=g, device=device).argsort(dim=1)[:, : int(frac * tokens)]
-        bump = big * torch.randn(1, pick.shape[1], DIM, generator=g, device=device)
-        cur = cur.scatter_add(1, pick.unsqueeze(-1).expand(-1, -1, DIM), bump)
+        f = frac[0] + (frac[1] - frac[0]) * float(torch.rand(1, generator=g, device=device))
+        moving = torch.rand(tokens, generator=g, device=device) < f
+        scale = torch.exp(np.log(lo) + (np.log(hi) - np.log(lo)) * torch.rand(tokens, generator=g, device=device))
+        scale = torch.where(moving, scale, torch.full_like(scale, lo))
+        cur = cur + scale.view(1, tokens, 1) * torch.randn(1, tokens, DIM, generator=g, device=device)
         out.append(cur)
     return torch.stack(out)
 
@@ -539,13 +565,17 @@ def self_check_vivit(model, clips, sd, cast, k, max_frames=None):
     # relative) of A.v state elements, which persist in the state; over 12 blocks x T frames the class embedding
     # moves by ~1e-2 (the reference's own fp32-vs-bf16 gap on this model is 6.6e-2).
     tol = 1e-3 if cast is None else 2e-2
+    # fp32 mode over a whole clip: the projection gates (a third of all gates) must be part of the claim, not skipped as near-ties
+    proj_needed = 60 if (cast is None and k > 0 and T >= 12) else 0
+    proj_ok = per_gate["projection"]["checked"] >= proj_needed
     return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol,
             "gates_checked": checked, "index_sets_equal": bool(checked == equal_on_margin),
+            "projection_gates_checked_min": proj_needed,
             "gates_total": total, "agreement_rate_all_margins": round(equal_all / total, 4) if total else None,
             "margin_bar": bar, "per_gate": per_gate,
             "mode": "CPU oracle replays clip 0 of the timed batch with the HIP index sets forced into its gates; its own "
                     "top-k must pick the same set wherever its margin >= bar",
-            "ok": bool(worst <= tol and checked == equal_on_margin)}
+            "ok": bool(worst <= tol and checked == equal_on_margin and proj_ok)}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -566,10 +596,54 @@ def broadcast_weights(sd, extra, device, rank):
             off += n
 
 
-def max_over_ranks(seconds, device):
-    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+def max_over_ranks(seconds, device, *more):
+    """MAX over ranks of the elapsed time (and of any further per-rank numbers, in the same single all-reduce)."""
+    t = torch.tensor([seconds, *more], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return float(t[0].item()) if not more else [float(v) for v in t.tolist()]
+
+
+# Every torch.distributed entry point that moves data or synchronises ranks is wrapped with a call counter, so that a run can
+# PROVE its timed region contains no collective (SURVEY.md section 8e: clips shard with no data-path exchange; the only
+# collectives are the weight broadcast before and the max-reduce after).  `timed_region` snapshots the counter right after the
+# opening barrier and right before the closing one; the count is max-reduced with the elapsed time and printed.
+_COLLECTIVE_NAMES = ("all_reduce", "broadcast", "barrier", "all_gather", "all_gather_into_tensor", "all_gather_object", "reduce",
+                     "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "gather", "scatter", "send", "recv",
+                     "isend", "irecv", "broadcast_object_list", "batch_isend_irecv")
+_collective_calls = [0]
+
+
+def install_collective_counter():
+    if getattr(dist, "_evt_counted", False):
+        return
+    for name in _COLLECTIVE_NAMES:
+        fn = getattr(dist, name, None)
+        if fn is None:
+            continue
+
+        def counted(*a, _fn=fn, **kw):
+            _collective_calls[0] += 1
+            return _fn(*a, **kw)
+        setattr(dist, name, counted)
+    dist._evt_counted = True
+
+
+def timed_region(step, steps, world, device_sync):
+    """barrier + device sync, EXACTLY `steps` steps, barrier + device sync -> (elapsed seconds of this rank, number of
+    torch.distributed calls issued between the two barriers)."""
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    sync_all()
+    c0 = _collective_calls[0]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    inside = _collective_calls[0] - c0
+    sync_all()
+    return time.perf_counter() - t0, inside
 
 
 def clips_for_rank(total_clips, world, rank):
@@ -646,7 +720,8 @@ def build_workload(name, device, world, rank, clips=256, total_clips=None, frame
     if kind == "vivit":
         sd = seeded_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes().items()}
     else:
-        sd = vitdet_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()}
+        sd = (vitdet_state_dict(qk_std=QK_STD if name == "vitdet1024" else None) if rank == 0
+              else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()})
     if world > 1:
         broadcast_weights(sd, {}, device, rank)
     if kind == "vivit":
@@ -678,11 +753,6 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
         model.use_graphs()
         events_on = False
 
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def step():
         out = None
         for clips in data:
@@ -696,19 +766,15 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
         torch.cuda.synchronize()
         events = [] if events_on else None
         _native.set_kernel_events(timed_kernel, events)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
+        elapsed, inside = timed_region(step, steps, world, torch.cuda.synchronize)
         _native.set_kernel_events(timed_kernel, None)
     if world > 1:
-        elapsed = max_over_ranks(elapsed, device)
+        elapsed, inside = max_over_ranks(elapsed, device, inside)
+    w["collectives_in_timed_region"] = int(inside)
     roofline = None
     if events:
         ms = sum(ev[0].elapsed_time(ev[1]) for ev in events)
-        work = sum(ev[2] for ev in events)
+        work = sum(_native.event_work(ev) for ev in events)   # after the timed region: live selected-row counts are read back here
         launches = sum(ev[3] for ev in events)
         if timed_kernel == "gemm":
             achieved = work / (ms * 1e-3) / 1e12
@@ -736,8 +802,9 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
             roofline = {"bound": "hbm", "kernel": "attn_stream_kernel / softmax_av_gated_kernel (global-block attention)",
                         "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
-                        "algorithmic_bytes": "q, k read once + rel-pos terms + gate-reference columns read and rewritten + v pieces "
-                                             "+ A.v state RMW + fp32 output per launch (the N^2 score state is no longer kept)",
+                        "algorithmic_bytes": "q, k read once + rel-pos terms + gate-reference columns of the LIVE selected keys read and "
+                                             "rewritten + their v pieces + A.v state RMW + fp32 output per launch (no N^2 score state; the "
+                                             "threshold policy's device-side counts are read back after the timed region)",
                         "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                         "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
     return elapsed, roofline
@@ -904,9 +971,34 @@ def vitdet_pipelined(w, lanes=(2, 4), groups=6):
     return out
 
 
+class _ReplayThreshold:
+    """Oracle-side policy for the self-check under the threshold policy: hands the oracle the index list the HIP run selected
+    (both sides then refresh the same tokens), records the oracle's own selection and, for the tokens the two disagree on, how
+    close their norm is to the threshold (relative); `margin` = the closest any token comes."""
+
+    def __init__(self, threshold):
+        self.threshold = threshold
+        self.forced = self.own = None
+        self.margin = self.worst_flip = None
+
+    def __call__(self, e, dim=-1):
+        n = torch.linalg.vector_norm(e, ord=2, dim=dim).reshape(-1)
+        rel = (n.double() - self.threshold).abs() / self.threshold
+        own = n.gt(self.threshold)
+        mine = torch.zeros_like(own)
+        mine[self.forced.reshape(-1)] = True
+        self.own = own.nonzero().reshape(-1)
+        self.margin = float(rel.min())
+        diff = own != mine
+        self.worst_flip = float(rel[diff].max()) if bool(diff.any()) else 0.0
+        return self.forced
+
+
 def self_check_vitdet(w, frames=3):
-    """Stream 0 of a ViTDet workload, first `frames` frames, HIP vs the CPU oracle: the backbone output (every 64th token)
-    and every gate's selected-token count per frame (top-k: the index sets themselves)."""
+    """Stream 0 of a ViTDet workload, first `frames` frames, HIP vs the CPU oracle: the backbone output (every 64th token) and
+    every gate's index set.  The oracle replays the stream with the HIP index sets forced into its gates (a near-tie decided the
+    other way cannot fork the two states) and records its own selection: top-k sets must be equal wherever the oracle's margin
+    is >= 1e-3; threshold sets must be equal except for tokens whose norm is within 1e-3 (relative) of the threshold."""
     from eventful_transformer import blocks as evt_blocks
 
     model, clips = w["model"], w["data"][0][:frames, :1]
@@ -922,25 +1014,44 @@ def self_check_vitdet(w, frames=3):
         evt_blocks.INDEX_TAP = None
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     bb, oblocks = vitdet_oracle_model(w["sd"], w["cast"], w["policy"], w["grid"])
-    worst, sets_equal, sets_total = 0.0, 0, 0
+    topk = w["policy"][0] == "topk"
+    gates = ("qkv_gate", "projection_gate", "mlp_gate")
+    for ob in oblocks:
+        for gname in ob.GATES:
+            ob.policy[gname] = _ReplayTopK(w["policy"][1]) if topk else _ReplayThreshold(w["policy"][1])
+    worst, sets_equal, sets_ok, sets_total, counts, closest = 0.0, 0, 0, 0, [], 1.0
+    bar = 1e-3
     x_cpu = clips.cpu()
     with torch.inference_mode():
         for t in range(frames):
+            if t > 0:
+                for bi, ob in enumerate(oblocks):
+                    for gi, gname in enumerate(gates):
+                        idx, count = taps[((t - 1) * DEPTH + bi) * 3 + gi]
+                        n = int(count[0]) if count is not None else idx.numel()
+                        counts.append(n)
+                        ob.policy[gname].forced = idx[:n].cpu().long().view(1, n)
             ref = bb.forward(x_cpu[t].clone())
             worst = max(worst, float((outs[t] - ref[0, ::64]).abs().max()))
             if t == 0:
                 continue
-            for bi, ob in enumerate(oblocks):
-                for gi, gname in enumerate(("qkv_index", "projection_index", "mlp_index")):
-                    idx, count = taps[((t - 1) * DEPTH + bi) * 3 + gi]
-                    want = ob.trace[gname].reshape(-1).sort()[0]
-                    n = int(count[0]) if count is not None else idx.numel()
+            for ob in oblocks:
+                for gname in gates:
+                    pol = ob.policy[gname]
+                    same = bool(torch.equal(pol.forced.reshape(-1), pol.own.reshape(-1)))
                     sets_total += 1
-                    sets_equal += bool(n == want.numel() and torch.equal(idx[:n].cpu().long(), want))
-    tol = 1e-3 if w["cast"] is None else 2e-3
-    return {"frames": frames, "max_abs_err": round(worst, 6), "tolerance": tol, "index_sets_equal": sets_equal,
-            "index_sets_total": sets_total, "mode": "free-running vs the CPU oracle (output tokens 0, 64, 128, ...; every gate's index set)",
-            "ok": bool(worst <= tol and sets_equal == sets_total)}
+                    sets_equal += same
+                    closest = min(closest, pol.margin)
+                    sets_ok += same or (pol.margin < bar if topk else pol.worst_flip < bar)
+    tol = 1e-3
+    out = {"frames": frames, "max_abs_err": round(worst, 6), "tolerance": tol, "index_sets_equal": sets_equal,
+           "index_sets_total": sets_total, "index_sets_ok": sets_ok, "margin_bar": bar, "closest_margin": float(f"{closest:.3g}"),
+           "mode": "CPU oracle replays the stream with the HIP index sets forced into its gates (output tokens 0, 64, 128, ...; every "
+                   "gate's set against the oracle's own selection; a differing set is accepted only if the oracle's margin is below the bar)",
+           "ok": bool(worst <= tol and sets_ok == sets_total)}
+    if not topk:
+        out["selected_counts_min_max_distinct"] = [min(counts), max(counts), len(set(counts))]
+    return out
 
 
 def wrapper_legs(device):
@@ -975,6 +1086,7 @@ def wrapper_legs(device):
     g = torch.Generator(device=device).manual_seed(11)
     clips = torch.randint(0, 256, (8, 80, 3, 224, 224), dtype=torch.uint8, device=device, generator=g)   # 8 videos of 80 frames
     with torch.inference_mode():
+        model.use_frame_graphs(0)   # eager steps first (the default mode replays graphs at batch 1, timed below)
         model(clips[:1])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -1000,14 +1112,24 @@ def wrapper_legs(device):
                 probs_g = model(clips[i:i + 1])
             torch.cuda.synchronize()
             replay[lanes] = (time.perf_counter() - t0, bool(torch.equal(probs_g, probs)))
+        model.use_frame_graphs(None)   # the default: automatic
+        model(clips[:1]); model(clips[1:2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(clips.shape[0]):
+            probs_g = model(clips[i:i + 1])
+        torch.cuda.synchronize()
+        replay["default"] = (time.perf_counter() - t0, bool(torch.equal(probs_g, probs)))
         model.use_frame_graphs(0)
-    out["vivit_e2e"] = {"clips_s": round(clips.shape[0] / el, 2), "ms_per_clip": round(el / clips.shape[0] * 1e3, 2),
+    out["vivit_e2e"] = {"clips_s": round(clips.shape[0] / replay["default"][0], 2),
+                        "clips_s_eager": round(clips.shape[0] / el, 2), "ms_per_clip_eager": round(el / clips.shape[0] * 1e3, 2),
                         "clips_s_batch8": round(clips.shape[0] / el8, 2),
                         "clips_s_graph_replay": round(clips.shape[0] / replay[1][0], 2),
                         "clips_s_graph_replay_3_in_flight": round(clips.shape[0] / replay[3][0], 2),
-                        "graph_replay_bit_identical": replay[1][1] and replay[3][1],
+                        "graph_replay_bit_identical": replay[1][1] and replay[3][1] and replay["default"][1],
                         "config": "FactorizedViViT-B, uint8 (1,80,3,224,224) video -> 400 class probabilities, 2 temporal views x 16 "
-                                  "spatial steps (top-k 128, fp32), batch 1 per call (eager launches: host-bound)",
+                                  "spatial steps (top-k 128, fp32), batch 1 per call; clips_s = the wrapper's default mode (HIP-graph replay "
+                                  "of the spatial steps, 3 in flight, at <= 2 view streams); clips_s_eager: eager launches (host-bound)",
                         "probs_sum": round(float(probs.sum()), 5)}
     del model, clips
     bcfg = dict(block_config=dict(dim=DIM, heads=HEADS, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14)),
@@ -1106,6 +1228,7 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
+    install_collective_counter()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -1151,6 +1274,7 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": w["scaling"], "vs_baseline": None,
+            "collectives_in_timed_region": w["collectives_in_timed_region"],   # max over ranks; 0 = clips shard with no exchange
             "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
                       (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
             "data": "synthetic", "per_gpu": round(value / world, 2),
@@ -1255,13 +1379,13 @@ def dry_run(args, world, rank):
     if total == 0:
         total = world * args.clips
     mine = batches_for_rank(total, world, rank, args.clips)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def step():
         for b in mine:
             time.sleep(0.001 * len(b))
-    elapsed = time.perf_counter() - t0
+    elapsed, inside = timed_region(step, args.steps, world, lambda: None)   # the same bracket as the real run
     if world > 1:
-        elapsed = max_over_ranks(elapsed, dev)
+        elapsed, inside = max_over_ranks(elapsed, dev, inside)
         counts, batches, covers = [None] * world, [None] * world, [None] * world
         dist.all_gather_object(counts, sum(len(b) for b in mine))
         dist.all_gather_object(batches, [len(b) for b in mine])
@@ -1275,6 +1399,7 @@ def dry_run(args, world, rank):
                           "disjoint_cover": sorted(c for cv in covers for c in cv) == list(range(total)),
                           "config": {"clips_per_step": total, "resident_clips_per_gpu": args.clips},
                           "weights_from_rank0": bool(float(sd["w"][0]) == 1.0),
+                          "collectives_in_timed_region": int(inside), "collectives_total": _collective_calls[0],
                           "ms_per_step": round(elapsed / args.steps * 1e3, 3)}), flush=True)
     if world > 1:
         dist.destroy_process_group()

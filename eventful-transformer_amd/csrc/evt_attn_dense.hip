@@ -564,14 +564,6 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
   return EVT_OK;
 }
 
-// Diagnostic: resident workgroups per CU the runtime reports for the fp32-store K8 kernel with `lds` bytes of dynamic LDS.
-extern "C" __attribute__((visibility("default"))) int evt_debug_dense_occupancy(int split, int lds) {
-  int n = -1;
-  if (split) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_dense_kernel<float, true>, 256, (size_t)lds);
-  else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_dense_kernel<float, false>, 256, (size_t)lds);
-  return n;
-}
-
 #ifdef EVT_PROF
 extern "C" __attribute__((visibility("default"))) int evt_debug_prof_dense(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(evt_prof_dense_buf), sizeof(unsigned long long) * 8);

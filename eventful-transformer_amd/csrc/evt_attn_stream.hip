@@ -806,17 +806,6 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
 }
 
-int stream_cu_count() {
-  static int cus[EVT_MAX_DEVICES] = {0};
-  const int dev = evt_current_device();
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev] = n;
-  }
-  return cus[dev];
-}
-
 // Tile height: the launch runs in ceil(workgroups / slots) rounds of (almost) equal length, slots = CUs x workgroups per
 // CU (two by registers; fewer when LDS says so), and a workgroup of NHR row groups costs ~(1 + NHR) units (the key
 // fragments are split once per workgroup, everything else is per row group).  EVT_STREAM_NHR forces 2 or 3.
@@ -824,7 +813,7 @@ template <typename T>
 int stream_pick_nhr(const StreamArgs& a) {
   static const int forced = getenv("EVT_STREAM_NHR") ? atoi(getenv("EVT_STREAM_NHR")) : 0;
   if (forced >= 2 && forced <= 3) return forced;
-  const int cus = stream_cu_count(), nrel = a.gh + a.gw;
+  const int cus = evt_cu_count(), nrel = a.gh + a.gw;
   const size_t lds[2] = {stream_lds_bytes<T, 2>(nrel), stream_lds_bytes<T, 3>(nrel)};
   int best = 2;
   int64_t best_cost = -1;
@@ -849,6 +838,16 @@ void launch_stream(const StreamArgs& a, int qk_split, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int64_t evt_attention_stream_lds_bytes(int32_t store, int32_t gh, int32_t gw) {
+  const int nrel = (gh > 0 && gw > 0) ? gh + gw : 0;
+  switch (store) {
+    case EVT_F32: return (int64_t)stream_lds_bytes<float, 2>(nrel);
+    case EVT_BF16: return (int64_t)stream_lds_bytes<bf16_t, 2>(nrel);
+    case EVT_F16: return (int64_t)stream_lds_bytes<f16_t, 2>(nrel);
+    default: return -1;
+  }
+}
+
 extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream) {
   EVT_REQUIRE(d != nullptr, EVT_ERR_BAD_ARG, "evt_attention_stream: null descriptor");
   EVT_REQUIRE(d->qkv && d->a_state_t && d->pv, EVT_ERR_BAD_ARG, "evt_attention_stream: null qkv / a_state_t / pv");
@@ -870,6 +869,12 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
               "evt_attention_stream: qk_split needs the k_split workspace (B * H * ceil(N / 16) * 4096 bytes)");
   if (d->B == 0) return EVT_OK;
   const bool rel = d->rel_terms != nullptr;
+  {
+    const int64_t need = evt_attention_stream_lds_bytes(d->store, rel ? d->gh : 0, rel ? d->gw : 0);
+    EVT_REQUIRE(need > 0 && need <= EVT_LDS_PER_CU, EVT_ERR_BAD_SHAPE,
+                "evt_attention_stream: a 32-row tile with a %dx%d rel-pos key grid needs %lld bytes of LDS (CU: %d); use evt_qk + "
+                "evt_softmax_av_gated for this shape", d->gh, d->gw, (long long)need, EVT_LDS_PER_CU);
+  }
   StreamArgs a{d->qkv, d->rel_terms, d->a_state_t, d->idx, d->count, d->v_delta_t, d->v_old_t, d->v_state, d->pv, d->out_f32,
                d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale};
   hipStream_t s = evt_stream(stream);

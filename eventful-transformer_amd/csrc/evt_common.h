@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/evt_abi.h"
 
@@ -15,6 +16,9 @@
 char* evt_err_buf();
 int evt_fail(int code, const char* fmt, ...);
 int evt_check_launch(const char* what);
+// A host-side preparation step of the launch that follows failed (e.g. raising a kernel's dynamic-LDS limit): the note is
+// thread-local and evt_check_launch reports it together with the launch error it explains.
+void evt_note_launch_problem(const char* fmt, ...);
 
 #define EVT_REQUIRE(cond, code, ...) \
   do {                               \
@@ -25,20 +29,42 @@ static inline hipStream_t evt_stream(void* s) { return reinterpret_cast<hipStrea
 
 // Per-DEVICE host caches (one process may drive several GPUs; hipFuncSetAttribute applies to the current device only).
 constexpr int EVT_MAX_DEVICES = 64;
-static inline int evt_current_device() {
+static inline int evt_current_device() {   // -1: outside the per-device tables (never aliased onto another device's slot)
   int dev = 0;
-  (void)hipGetDevice(&dev);
-  return dev >= 0 && dev < EVT_MAX_DEVICES ? dev : 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  return dev >= 0 && dev < EVT_MAX_DEVICES ? dev : -1;
 }
+// Compute units of the current device (cached per device; 256 if the runtime does not say).
+static inline int evt_cu_count() {
+  static std::atomic<int> cus[EVT_MAX_DEVICES];
+  int dev = evt_current_device();
+  if (dev >= 0 && cus[dev].load(std::memory_order_relaxed) > 0) return cus[dev].load(std::memory_order_relaxed);
+  int real = 0, n = 0;
+  if (hipGetDevice(&real) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, real) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0) cus[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+constexpr int EVT_LDS_PER_CU = 160 * 1024;   // gfx950
+
 // Raises a kernel's dynamic-LDS limit to `bytes` when that exceeds what this call site has already set on the current
 // device (one static table per call site = per kernel instantiation): no runtime call on the launch path afterwards.
+// The table only remembers a size the runtime ACCEPTED (a refused raise is retried by the next call and its reason is kept for
+// evt_check_launch); entries are atomics, so host threads driving the library concurrently race at worst to the same call.
+// Devices beyond the table are not cached: every launch there makes the runtime call.
 #define EVT_ALLOW_LDS(kernel, bytes)                                                                            \
   do {                                                                                                           \
-    static int evt_lds_set_[EVT_MAX_DEVICES] = {0};                                                              \
+    static std::atomic<int> evt_lds_set_[EVT_MAX_DEVICES];                                                       \
     const int evt_dev_ = evt_current_device();                                                                   \
-    if ((int)(bytes) > 64 * 1024 && evt_lds_set_[evt_dev_] < (int)(bytes)) {                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-      evt_lds_set_[evt_dev_] = (int)(bytes);                                                                     \
+    const int evt_want_ = (int)(bytes);                                                                          \
+    if (evt_want_ > 64 * 1024 && (evt_dev_ < 0 || evt_lds_set_[evt_dev_].load(std::memory_order_relaxed) < evt_want_)) { \
+      hipError_t evt_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, evt_want_); \
+      if (evt_e_ != hipSuccess) {                                                                                \
+        (void)hipGetLastError();                                                                                 \
+        evt_note_launch_problem("hipFuncSetAttribute(%s, dynamic LDS %d bytes) failed: %s", #kernel, evt_want_, hipGetErrorString(evt_e_)); \
+      } else if (evt_dev_ >= 0) {                                                                                \
+        int evt_old_ = evt_lds_set_[evt_dev_].load(std::memory_order_relaxed);                                   \
+        while (evt_old_ < evt_want_ && !evt_lds_set_[evt_dev_].compare_exchange_weak(evt_old_, evt_want_)) {}    \
+      }                                                                                                          \
     }                                                                                                            \
   } while (0)
 

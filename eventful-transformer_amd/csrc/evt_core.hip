@@ -13,9 +13,25 @@ int evt_fail(int code, const char* fmt, ...) {
   return code;
 }
 
+static thread_local char g_note[256] = "";
+
+void evt_note_launch_problem(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_note, sizeof(g_note), fmt, ap);
+  va_end(ap);
+}
+
 int evt_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return evt_fail(EVT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  if (e != hipSuccess) {
+    char note[256];
+    snprintf(note, sizeof(note), "%s", g_note);
+    g_note[0] = 0;
+    return note[0] ? evt_fail(EVT_ERR_HIP, "%s: %s (%s)", what, hipGetErrorString(e), note)
+                   : evt_fail(EVT_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  }
+  g_note[0] = 0;
   return EVT_OK;
 }
 

@@ -500,17 +500,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
 #endif
 }
 
-int cu_count() {   // per device: one process may drive several GPUs
-  static int cus[EVT_MAX_DEVICES] = {0};
-  const int dev = evt_current_device();
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev] = n;
-  }
-  return cus[dev];
-}
-
 template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
 void launch_big_one(const LinArgs& a, hipStream_t s, dim3 grid, int tiles_n, int tiles_total) {
   constexpr size_t lds_bytes = (size_t)2 * (2 * TBM * 32 + 2 * TBN * 32 + 32 + ((FMT & 1) ? 32 : 0)) * 2 + (size_t)2 * TBM * 4 + (size_t)2 * TBN * 4;
@@ -523,7 +512,7 @@ template <int TBM, int TBN, int WM, int WN, int DEPTH>
 void launch_big_cfg(const LinArgs& a, hipStream_t s) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
-  const dim3 grid(std::min(tiles_m * tiles_n, cu_count()));   // persistent: one workgroup per CU
+  const dim3 grid(std::min(tiles_m * tiles_n, evt_cu_count()));   // persistent: one workgroup per CU
   const int tt = tiles_m * tiles_n;
   // formats in use: fp32 -> fp32 (any activation), fp32 -> hl32 with GELU (first half of the MLP), hl32 -> fp32 (second half)
   if (a.a_bf16) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 4>(a, s, grid, tiles_n, tt);
@@ -553,7 +542,7 @@ int evt_big_choice(const LinArgs& a) {
   // divide Nout (no wasted edge columns) and whose last round is at least 85 % full; measured at M = 32768 (B = 256 clips):
   // 256x256 for Nout = 2304 / 3072 (343 / 474 us vs 380 / 531 for the 128x128 kernel), 256x192 for Nout = 768 (126 / 418 vs
   // 134 / 443 us; 256x256 would leave a quarter of the CUs idle in its second round).
-  const int cus = cu_count(), M = a.B * a.kcap;
+  const int cus = evt_cu_count(), M = a.B * a.kcap;
   const int tiles_m = (M + 255) / 256;
   auto fills = [&](int tbn) {
     if (a.Nout % tbn != 0) return false;

@@ -20,12 +20,12 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 5   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 6   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense", "evt_attention_stream",
+    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes",
 )
 
 
@@ -130,6 +130,8 @@ def _bind(lib):
     lib.evt_gated_linear_workspace_bytes.restype = c_int64
     lib.evt_split_weights_bytes.argtypes = [c_int64, c_int64]
     lib.evt_split_weights_bytes.restype = c_int64
+    lib.evt_attention_stream_lds_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.evt_attention_stream_lds_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
@@ -188,8 +190,26 @@ def _check(rc):
         raise RuntimeError(f"libevt_hip: {msg} (status {rc})")
 
 
+_lane_stream = {}   # (device, work lane) -> (stream handle, stream) that last launched there
+
+
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream's handle.  Work buffers (`scratch`) are shared by everything that runs in one work lane of a
+    device, which is only sound while that work is ordered on ONE stream: a launch from a second stream while the first still
+    has work in flight raises instead of silently sharing index lists and hidden buffers.  Drive two streams (or threads) with
+    `with _native.lane(i):` around each one's calls."""
+    st = torch.cuda.current_stream()
+    h = st.cuda_stream
+    key = (st.device_index, _lane)
+    last = _lane_stream.get(key)
+    if last is None or last[0] != h:
+        if last is not None and not torch.cuda.is_current_stream_capturing() and not last[1].query():
+            raise RuntimeError(
+                f"eventful_transformer: HIP stream {h:#x} launches into work lane {_lane} of device {st.device_index} while "
+                f"stream {last[0]:#x} still has work in flight there; the lane's scratch buffers (index lists, hidden rows, ...) "
+                "would be shared.  Synchronise the streams, or give each its own lane: `with _native.lane(i): model(x)`.")
+        _lane_stream[key] = (h, st)
+    return c_void_p(h)
 
 
 def require_hip(*tensors):
@@ -212,7 +232,9 @@ def store_code(dtype):
 
 # --------------------------------------------------------------------------------------------------
 # scratch pool: fixed-address work buffers shared by all blocks on a device (blocks run one after
-# another on one stream, so the hidden/ã/Δã/... scratch never needs to exist per block).
+# another on one stream, so the hidden/ã/Δã/... scratch never needs to exist per block).  The pool is keyed by
+# (name, shape, dtype, device, work lane) -- NOT by stream or model: two same-shaped models share buffers, which is
+# correct while one stream orders them (`_stream` enforces that) and is what `lane` is for otherwise.
 # --------------------------------------------------------------------------------------------------
 _pool = {}
 _lane = 0   # frames of one stream captured side by side on several HIP streams (graphs.FrameGraphs.run_pipelined) each
@@ -299,15 +321,27 @@ def set_kernel_events(family, sink):
         _EVENTS[family] = sink
 
 
-def _timed(family, work, fn, launches=1):
+def _timed(family, work, fn, launches=1, count=None, per_row=0.0):
+    """work: algorithmic FLOP / bytes of the launch.  count (device int32 (B,), threshold policy): the launch touches
+    `per_row` more work for every LIVE selected row -- the capacity of the index list says nothing about it -- so the entry's
+    work becomes a callable that reads a copy of the counts (taken before the start event) once the timed region is over."""
     sink = _EVENTS.get(family)
     if sink is None:
         return fn()
+    if count is not None:
+        live = count.clone()
+        base = work
+        work = lambda: base + per_row * float(live.sum().item())   # noqa: E731
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
     sink.append((s, e, work, launches))
+
+
+def event_work(entry):
+    """Algorithmic work of one set_kernel_events entry (evaluates the live-count form; call after the timed region)."""
+    return entry[2]() if callable(entry[2]) else entry[2]
 
 
 def gemm_kernel_name():
@@ -488,8 +522,10 @@ def softmax_av_gated(product, a_state, idx, count, kcap, v_delta_t, v_old_t, pv,
     # A.v state read-modify-write, fp32 output
     es, nk = (4 if store == EVT_F32 else 2), (N if Nk is None else Nk)
     state_read = 4.0 * H * N * nk if product is not None else 8.0 * N * D   # QK mode reads q and k instead of the state
-    work = B * (state_read + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D + 4.0 * N * D)
-    _timed("attn", work, lambda: _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream())))
+    per_row = 2.0 * es * H * N + 2.0 * es * D          # per selected key: its gate-reference column read + rewritten, v delta / old
+    fixed = B * (state_read + 2.0 * es * N * D + (4.0 * N * D if out_f32 is not None else 0.0))
+    _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0),
+           lambda: _check(load().evt_softmax_av_gated(ctypes.byref(d), _stream())), count=count, per_row=per_row)
 
 
 def fused_qk_fits(N, Nk, D, H, kcap):
@@ -503,9 +539,16 @@ STREAM_QK = os.environ.get("EVT_STREAM_QK", "1") != "0"   # global blocks with N
 STREAM_MIN_N = int(os.environ.get("EVT_STREAM_MIN_N", "257"))
 
 
-def attention_stream_fits(N, D, H):
-    """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest)."""
-    return STREAM_QK and FUSED_QK and D == 64 * H and N >= STREAM_MIN_N
+LDS_PER_CU = 160 * 1024
+
+
+def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
+    """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest), and a 32-row tile with
+    the rel-pos terms of a gh x gw key grid inside a CU's LDS (evt_attention_stream_lds_bytes; larger grids take the
+    evt_qk + evt_softmax_av_gated path)."""
+    if not (STREAM_QK and FUSED_QK and D == 64 * H and N >= STREAM_MIN_N):
+        return False
+    return 0 < load().evt_attention_stream_lds_bytes(store, gh, gw) <= LDS_PER_CU
 
 
 def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_terms=None, gh=0, gw=0, idx=None, count=None,
@@ -520,14 +563,16 @@ def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_te
                        split, int(first), _p(ksp))
     # algorithmic bytes: q, k read once per clip (8ND), rel terms, gate-reference columns read + rewritten (first frame:
     # written whole), v pieces, A.v state read-modify-write (first frame: v state read, state written), fp32 output
+    # The gated form is priced by the LIVE selected-key count (threshold policy: `count` on the device, capacity N), never by kcap.
     es = 4 if store == EVT_F32 else 2
     rel_b = 4.0 * H * N * (gh + gw) if rel_terms is not None else 0.0
+    call = lambda: _check(load().evt_attention_stream(ctypes.byref(d), _stream()))   # noqa: E731
     if first:
-        work = B * (8.0 * N * D + rel_b + 1.0 * es * H * N * N + 2.0 * es * N * D + 4.0 * N * D)
+        _timed("attn", B * (8.0 * N * D + rel_b + 1.0 * es * H * N * N + 2.0 * es * N * D + 4.0 * N * D), call)
     else:
-        work = B * (8.0 * N * D + rel_b + 2.0 * es * H * N * kcap + 2.0 * es * kcap * D + 2.0 * es * N * D +
-                    (4.0 * N * D if out_f32 is not None else 0.0))
-    _timed("attn", work, lambda: _check(load().evt_attention_stream(ctypes.byref(d), _stream())))
+        per_row = 2.0 * es * H * N + 2.0 * es * D
+        fixed = B * (8.0 * N * D + rel_b + 2.0 * es * N * D + (4.0 * N * D if out_f32 is not None else 0.0))
+        _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0), call, count=count, per_row=per_row)
 
 
 def attention_dense_fits(N, D, H):

@@ -405,8 +405,8 @@ class EventfulTokenwiseBlock(Block):
         """Runs the gate's policy on the norms already produced by the row pass (parts > 0: on the per-head partial
         sums of squares produced by the fused attention epilogue).
 
-        embed_for = (K, Nout) of the gated linear that consumes the list: when that launch is a small one (a few hundred
-        rows: one video stream), the selection is NOT launched here -- the returned `select` dict rides on the gated linear,
+        embed_for = (K, Nout, ldo, scattered, o_rows) of the gated linear that consumes the list: when that launch is a small one
+        (a few hundred rows: one video stream), the selection is NOT launched here -- the returned `select` dict rides on the gated linear,
         whose workgroups run it themselves while their first weight tiles are in flight (evt_abi.h, sel_* fields).
         Returns (idx, count, cap, select or None)."""
         policy = gate.policy
@@ -417,8 +417,9 @@ class EventfulTokenwiseBlock(Block):
             # the qkv gate of blocks with a q.k^T state also wants the complement list (K4 skips re-written rows)
             rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
             self._rest = rest if tag == "qkv" else self._rest
-            if embed_for is not None and cap > 0 and _native.embeds_select(self.dim, N, embed_for[1], embed_for[2], embed_for[3],
-                                                                           count is not None, B, cap, embed_for[0], embed_for[1], N):
+            if embed_for is not None and cap > 0 and _native.embeds_select(
+                    lda=self.dim, a_rows=N, ldo=embed_for[2], scattered=embed_for[3], o_rows=embed_for[4], counted=count is not None,
+                    B=B, kcap=cap, K=embed_for[0], Nout=embed_for[1], N=N):
                 mode, k, thr = policy.select_params(N)
                 return idx, count, cap, dict(norms=norms, parts=parts, N=N, k=k, mode=mode, thr=thr, idx=idx, count=count, rest=rest)
             policy.select_into(norms, B, N, idx, count, rest, parts=parts)
@@ -717,8 +718,10 @@ class EventfulBlock(EventfulMatmul1Block):
             product = self._scores(qkv, idx, count, cap, B, N)[0]
             self._ats_idx_k = None if idx is None else idx.long()
             return self._ats_attention(product, qkv, B, N, eventful=True) + (None,)
-        if self.pool_size is None and _native.attention_stream_fits(N, D, H):
-            return self._attention_stream(qkv, idx, count, cap, B, N)
+        if self.pool_size is None:
+            _, _, gh_, gw_, _ = self._rel_tables()
+            if _native.attention_stream_fits(N, D, H, store, gh_, gw_):
+                return self._attention_stream(qkv, idx, count, cap, B, N)
         if acc.first and idx is None and self.matmul_accumulator_1.first:
             a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
             pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)

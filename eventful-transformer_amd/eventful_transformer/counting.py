@@ -3,18 +3,16 @@
 `CountedLinear` is on the gated-token path: its forward runs the MFMA gated-linear kernel (K3) in
 dense mode.  Inside the blocks the fused path calls the same kernel with the gate's index list and
 books the same counters, so `total_counts()` is identical whichever way a linear is reached.
-`CountedMatmul` / `CountedAdd` / `CountedEinsum` / `CountedBias` / `CountedConv` exist for API
+`CountedMatmul` / `CountedAdd` / `CountedEinsum` exist for API
 parity (sub-modules of `MatmulBuffer`, `RelativePositionEmbedding`, ...); inside the fused blocks
-their arithmetic is part of kernels K4-K6 and only their counters are touched.
+their arithmetic is part of kernels K4-K6 and only their counters are touched.  (The reference's `CountedBias` /
+`CountedConv` are dead code there -- nothing instantiates them -- and are not mirrored.)
 """
-from math import prod
-
 import torch
 import torch.nn as nn
-import torch.nn.functional as func
 
 from eventful_transformer import _native
-from eventful_transformer.base import ExtendedModule, numeric_tuple
+from eventful_transformer.base import ExtendedModule
 
 
 class CountedAdd(ExtendedModule):
@@ -28,48 +26,6 @@ class CountedAdd(ExtendedModule):
             out = a + b
         if self.count_mode:
             self.counts["add_flops"] += out.numel()
-        return out
-
-
-class CountedBias(ExtendedModule):
-    """Learned per-feature bias over `spatial_dims` trailing axes (counting.py:25-48)."""
-
-    def __init__(self, features, spatial_dims=0, device=None, dtype=None):
-        super().__init__()
-        self.features = features
-        self.spatial_dims = spatial_dims
-        self.bias = nn.Parameter(torch.zeros(features, device=device, dtype=dtype))
-
-    def forward(self, x):
-        out = x + self.bias.view((self.features,) + (1,) * self.spatial_dims)
-        if self.count_mode:
-            self.counts["bias_flops"] += out.numel()
-        return out
-
-
-class CountedConv(ExtendedModule):
-    """Bias-free N-d convolution with MAC counting (counting.py:51-110).  Off the gated path."""
-
-    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
-                 groups=1, device=None, dtype=None):
-        super().__init__()
-        self.spatial_dims = spatial_dims
-        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
-        self.kernel_size = numeric_tuple(kernel_size, length=spatial_dims)
-        self.stride = numeric_tuple(stride, length=spatial_dims)
-        self.padding = numeric_tuple(padding, length=spatial_dims) if isinstance(padding, int) else padding
-        self.dilation = numeric_tuple(dilation, length=spatial_dims)
-        self.conv_function = getattr(func, f"conv{spatial_dims}d")
-        self.weight = nn.Parameter(
-            torch.zeros((out_channels, in_channels // groups) + self.kernel_size, device=device, dtype=dtype)
-        )
-
-    def forward(self, x):
-        out = self.conv_function(x, self.weight, stride=self.stride, padding=self.padding, dilation=self.dilation,
-                                 groups=self.groups)
-        if self.count_mode:
-            fan_in = (self.in_channels // self.groups) * prod(self.kernel_size)
-            self.counts[f"conv{self.spatial_dims}d_flops"] += out.numel() * fan_in
         return out
 
 

@@ -75,15 +75,20 @@ class FrameGraphs:
             y = self._fwd(self._x)
         return graph, y
 
-    @torch.inference_mode()
-    def __call__(self, x):
+    def _check_frame(self, x, what):
+        """Shared by __call__ and run_pipelined: no MAC counting (it reads counters back to the host, which cannot be captured),
+        and the frame must look like the captured one (shape, dtype, device)."""
         if getattr(self.model, "count_mode", False):
             raise RuntimeError("FrameGraphs: operation counting reads counters back to the host; use the eager model")
+        if self._x is not None and (x.shape != self._x.shape or x.dtype != self._x.dtype or x.device != self._x.device):
+            raise RuntimeError(f"FrameGraphs{what}: frame {tuple(x.shape)} {x.dtype} on {x.device} differs from the captured "
+                               f"{tuple(self._x.shape)} {self._x.dtype} on {self._x.device}; call release() to re-capture")
+
+    @torch.inference_mode()
+    def __call__(self, x):
+        self._check_frame(x, "")
         if self._x is None:
             self._x = torch.empty_like(x, memory_format=torch.contiguous_format)
-        elif x.shape != self._x.shape or x.dtype != self._x.dtype or x.device != self._x.device:
-            raise RuntimeError(f"FrameGraphs: frame {tuple(x.shape)} {x.dtype} differs from the captured "
-                               f"{tuple(self._x.shape)} {self._x.dtype}; call release() to re-capture")
         self._x.copy_(x)
         if self._t == 0:
             if self._first is None:
@@ -150,12 +155,17 @@ class FrameGraphs:
     @torch.inference_mode()
     def run_pipelined(self, xs):
         """xs: (P, ...) = the next P frames of the stream (not the first frame of a clip).  Returns the list of their P
-        outputs -- static tensors, overwritten by the next call.  The first call per lane count runs the frames one by one
-        (each lane's scratch buffers come into being outside the capture), the second captures, later ones replay."""
-        if self._t == 0:
+        outputs.  From the second call on these are STATIC tensors that the next call overwrites (clone to keep); the first call
+        per lane count runs the frames one by one (each lane's scratch buffers come into being outside the capture) and returns
+        copies, the second captures, later ones replay.  The clip must have been started through this object (`reset()` then
+        `__call__` for its first frame): the temporal state the lanes update is the model's."""
+        if self._t == 0 or self._x is None:
             raise RuntimeError("FrameGraphs.run_pipelined: the first frame of a clip goes through __call__")
+        if xs.ndim < 2:
+            raise RuntimeError("FrameGraphs.run_pipelined: expected a stack (P, ...) of frames")
+        self._check_frame(xs[0], ".run_pipelined")
         P = xs.shape[0]
-        if self._pipe is not None and (self._pipe[1].shape != xs.shape or self._pipe[1].dtype != xs.dtype):
+        if self._pipe is not None and (self._pipe[1].shape != xs.shape or self._pipe[1].dtype != xs.dtype or self._pipe[1].device != xs.device):
             raise RuntimeError("FrameGraphs.run_pipelined: frame stack differs from the captured one; call release()")
         if self._pipe is None and self._pipe_warm != P:
             ys = []

@@ -158,7 +158,7 @@ class FactorizedViViT(ExtendedModule):
         self.temporal_model = ViViTSubModel((input_t // tubelet_shape[0],), temporal_config)
         self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0.0 else nn.Identity()
         self.classifier = CountedLinear(in_features=dim, out_features=classes)
-        self._frames, self._frames_in_flight = None, 1   # see use_frame_graphs
+        self._frames, self._frames_in_flight = {}, None   # see use_frame_graphs (None: automatic)
 
     def forward(self, x):
         clips = x.shape[0]
@@ -174,28 +174,59 @@ class FactorizedViViT(ExtendedModule):
             return self._forward_view(torch.stack(views, dim=1).flatten(end_dim=1))
         return torch.stack([self._forward_view(v) for v in views], dim=1).flatten(end_dim=1)
 
-    def use_frame_graphs(self, frames_in_flight=1):
+    AUTO_GRAPH_VIEWS = 2        # automatic mode: view batches up to this size replay HIP graphs (eager steps are host-bound there)
+    AUTO_FRAMES_IN_FLIGHT = 3
+    MAX_FRAME_GRAPHS = 2        # captured shapes kept (each holds its own copy of the per-clip state)
+
+    def use_frame_graphs(self, frames_in_flight=None):
         """MI355X addition (no counterpart in the reference, whose spatial steps run eagerly): replay the spatial sub-model's
         per-step launches as HIP graphs (eventful_transformer.graphs.FrameGraphs), optionally with `frames_in_flight`
         consecutive time steps of a view side by side (`run_pipelined`).  Same kernels on the same state: bit-identical
-        probabilities; at batch 1 the eager steps are bound by the host's launch rate.  Pass 0 to go back to eager steps."""
-        from eventful_transformer.graphs import FrameGraphs
+        probabilities; at batch 1 the eager steps are bound by the host's launch rate.
+          None (default): automatic -- graphs with 3 steps in flight when a call carries at most 2 view streams, eager steps for
+                          larger batches, while counting MACs, in training mode or when forward hooks are registered;
+          0: always eager steps;   n >= 1: always graphs, n steps in flight.
+        One FrameGraphs is captured per (views, patches, dim, dtype, device) of the step input -- the stacked-views and per-view
+        paths and a smaller final batch each get their own -- and the two most recently used are kept."""
+        for frames in self._frames.values():
+            frames.release()
+        self._frames = {}
+        self._frames_in_flight = None if frames_in_flight is None else max(0, int(frames_in_flight))
 
-        if self._frames is not None:
-            self._frames.release()
-        self._frames = FrameGraphs(self.spatial_model) if frames_in_flight >= 1 else None
-        self._frames_in_flight = max(1, int(frames_in_flight))
+    def _graph_mode(self, tokens):
+        """Steps in flight for this call's graph replay, or 0 for eager steps."""
+        if self._frames_in_flight is not None:
+            return self._frames_in_flight
+        if tokens.shape[0] > self.AUTO_GRAPH_VIEWS or self.training or getattr(self, "count_mode", False) or not tokens.is_cuda:
+            return 0
+        if any(m._forward_hooks or m._forward_pre_hooks for m in self.spatial_model.modules()):
+            return 0      # hooks would only run while capturing
+        return self.AUTO_FRAMES_IN_FLIGHT
 
     def _forward_view(self, x):
         tokens = self.embedding(x.contiguous())  # (views, time, patches, dim)
-        if self._frames is not None:
-            return self._forward_view_graphs(tokens)
+        P = self._graph_mode(tokens)
+        if P >= 1:
+            return self._forward_view_graphs(tokens, P)
         self.spatial_model.reset()
         return torch.stack([self.spatial_model(tokens[:, t]) for t in range(tokens.shape[1])], dim=1)
 
-    def _forward_view_graphs(self, tokens):
-        frames, P, T = self._frames, self._frames_in_flight, tokens.shape[1]
+    def _frame_graphs_for(self, step):
+        from eventful_transformer.graphs import FrameGraphs
+
+        key = (tuple(step.shape), step.dtype, step.device)
+        frames = self._frames.pop(key, None)
+        if frames is None:
+            while len(self._frames) >= self.MAX_FRAME_GRAPHS:
+                self._frames.pop(next(iter(self._frames))).release()
+            frames = FrameGraphs(self.spatial_model)
+        self._frames[key] = frames      # most recently used last
+        return frames
+
+    def _forward_view_graphs(self, tokens, P):
+        T = tokens.shape[1]
         steps = tokens.transpose(0, 1).contiguous()          # (time, views, patches, dim)
+        frames = self._frame_graphs_for(steps[0])
         frames.reset()
         out = [frames(steps[0]).clone()]
         t = 1

@@ -31,13 +31,15 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 5   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+#define EVT_ABI_VERSION 6   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
                                  5: evt_attention_stream (+ its k_split workspace), evt_attn_dense_desc.qk_split, the `split`
                                     argument of evt_rel_terms, embedded selection (sel_* fields of evt_linear_desc /
-                                    evt_mlp_desc, evt_gated_linear_embeds_select) */
+                                    evt_mlp_desc, evt_gated_linear_embeds_select);
+                                 6: evt_attention_stream_lds_bytes (shape-only query; evt_attention_stream now answers
+                                    EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -417,6 +419,12 @@ typedef struct evt_attn_stream_desc {
 } evt_attn_stream_desc;
 
 EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
+
+/* LDS bytes of evt_attention_stream's smallest (32-row) tile for a store type and rel-pos key grid (gh = gw = 0: no relative
+ * position); negative for an unknown store type.  Shape-only: callable without a device.  A caller routes a shape whose
+ * answer exceeds the CU's 160 KB to evt_qk + evt_softmax_av_gated (the reference ops are the same, blocks.py:506-523,558-575);
+ * evt_attention_stream itself returns EVT_ERR_BAD_SHAPE for it. */
+EVT_API int64_t evt_attention_stream_lds_bytes(int32_t store, int32_t gh, int32_t gw);
 
 /* ------------------------------------------------------------------------------------------ *
  * K/V token pooling (`pool_size`, blocks.py:303-326, 525-540).

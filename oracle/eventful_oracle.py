@@ -77,12 +77,25 @@ class TopFraction:
 class Threshold:
     """policies.py:6-32 (batch 1 only, ascending indices, data-dependent count)."""
 
-    def __init__(self, threshold):
+    def __init__(self, threshold, save_status=False):
         self.threshold = threshold
+        self.save_status = save_status
+        # save_status: how close the call was -- min over tokens of | ||e|| - threshold | / threshold, and the tokens within
+        # NEAR of the threshold (indices, relative distances): the only ones another summation order may decide differently
+        self.last_margin = None
+        self.last_near = None
+
+    NEAR = 1e-3
 
     def __call__(self, e, dim=-1):
         assert all(s == 1 for s in e.shape[:-2])
-        hit = vector_norm(e, ord=2, dim=dim).gt(self.threshold).nonzero()
+        norms = vector_norm(e, ord=2, dim=dim)
+        if self.save_status:
+            rel = ((norms.double() - self.threshold).abs() / self.threshold).reshape(-1)
+            self.last_margin = float(rel.min())
+            near = (rel < self.NEAR).nonzero().reshape(-1)
+            self.last_near = (near, rel[near])
+        hit = norms.gt(self.threshold).nonzero()
         return hit[..., -1].view((1,) * (e.ndim - 2) + (-1,))
 
 
@@ -595,6 +608,19 @@ def make_block_params(dim, mlp_ratio, seed, std=0.02, rel_sizes=None, head_dim=N
     return p
 
 
+def sharpen_qk(params, dim, qk_std, std=0.02):
+    """Rescales the query and key thirds of a block's `qkv.weight` / `qkv.bias` (rows [0, 2*dim)) from std to qk_std, in place.
+
+    With std-0.02 random weights the attention logits have a standard deviation of ~0.3: near-uniform attention, whose output
+    barely depends on which tokens moved -- the projection gate's delta norms are then near-tied (median top-k margin 1.7e-4,
+    SURVEY.md section 7-1).  qk_std = 0.06 gives logits of std ~2.8 and projection-gate margins with a median >= 1e-3."""
+    for key in ("qkv.weight", "qkv.bias"):
+        w = params[key].clone()
+        w[: 2 * dim] *= qk_std / std
+        params[key] = w
+    return params
+
+
 def make_token_stream(batch, tokens, dim, steps, n_changed, seed, scale=1.0, small=0.0):
     """Synthetic (steps, batch, tokens, dim) token stream (SURVEY.md §8d "Synthetic inputs").
 
@@ -661,5 +687,26 @@ def make_threshold_stream(tokens, dim, steps, seed, frac=0.1, big=0.5, small=1e-
         cur = cur + (rs.standard_normal(cur.shape) * small).astype(np.float32)
         pick = rs.permutation(tokens)[:n_big]
         cur[0, pick] += (rs.standard_normal((n_big, dim)) * big).astype(np.float32)
+        out[t] = cur
+    return torch.from_numpy(out)
+
+
+def make_varied_threshold_stream(tokens, dim, steps, seed, lo=1e-4, hi=1.0, frac=(0.02, 0.15)):
+    """Batch-1 token stream with CONTINUOUS perturbation magnitudes for threshold-policy runs (BASELINE config 5, "variable r
+    per frame"): each step a random fraction f ~ U(frac) of the tokens moves by N(0, s^2) with a per-token log-uniform
+    s in [lo, hi]; the others jitter by N(0, lo^2).  The selected-token count of every gate then depends on the data, on the
+    frame and on the threshold (make_threshold_stream is bimodal: the same ~10 % of tokens at every threshold)."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    out = np.empty((steps, 1, tokens, dim), dtype=np.float32)
+    cur = rs.standard_normal((1, tokens, dim)).astype(np.float32)
+    out[0] = cur
+    for t in range(1, steps):
+        f = rs.uniform(*frac)
+        moving = rs.uniform(size=tokens) < f
+        scale = np.exp(rs.uniform(np.log(lo), np.log(hi), size=tokens))
+        scale[~moving] = lo
+        cur = cur + (rs.standard_normal(cur.shape) * scale[None, :, None]).astype(np.float32)
         out[t] = cur
     return torch.from_numpy(out)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Steps run ON the GPU box through gpurun: $1 = output tag under gpurun_out/, rest = steps.
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_job.sh r04a tests bench'
+set -u
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for what in "$@"; do
+case $what in
+  tests)       # the whole GPU suite; the tests append their measured numbers to the parity summary
+    rm -f gpurun_out/parity_summary.txt
+    EVT_PARITY_SUMMARY=$PWD/$OUT/parity_summary.txt timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest.log 2>&1
+    tail -40 $OUT/pytest.log ;;
+  tests_x)     # stop at the first failure
+    EVT_PARITY_SUMMARY=$PWD/$OUT/parity_summary.txt timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1
+    tail -40 $OUT/pytest.log ;;
+  tests_k=*)   # a subset: tests_k=<pytest -k expression>
+    EVT_PARITY_SUMMARY=$PWD/$OUT/parity_summary.txt timeout 1200 python -m pytest tests -m gpu -q -k "${what#tests_k=}" > $OUT/pytest_k.log 2>&1
+    tail -40 $OUT/pytest_k.log ;;
+  bench)       # the driver's default command
+    timeout 1500 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; tail -5 $OUT/bench.err; cat $OUT/bench.json ;;
+  bench_short) # headline only
+    timeout 900 python bench.py --no-other --no-cpu-baseline 2> $OUT/bench_short.err | tail -1 > $OUT/bench_short.json; cat $OUT/bench_short.json ;;
+  smoke)
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+  kbench)
+    python scripts/kbench.py 2>&1 | tee $OUT/kbench.txt ;;
+  kbench=*)
+    python scripts/kbench.py ${what#kbench=} 2>&1 | tee -a $OUT/kbench.txt ;;
+  osb)
+    python scripts/onestream_bench.py 2>&1 | tee $OUT/osb.txt ;;
+  py=*)        # any script with arguments: py=scripts/x.py,--a,1
+    IFS=',' read -r -a ARGS <<< "${what#py=}"
+    python "${ARGS[@]}" 2>&1 | tee -a $OUT/py.txt ;;
+  *) echo "unknown step $what" ;;
+esac
+done

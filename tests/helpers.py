@@ -1,8 +1,26 @@
 """Shared test helpers: build product (HIP) modules from oracle parameter dicts."""
+import os
+
 import numpy as np
 import torch
 
 import eventful_oracle as O
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The parity tests' measured numbers (agreement rates, worst errors, gate counts) are printed AND appended here, because
+# `pytest -q` swallows stdout: scripts/collect_profiles.sh copies the file into profiles/rNN/parity_summary.txt.
+PARITY_SUMMARY = os.environ.get("EVT_PARITY_SUMMARY", os.path.join(_ROOT, "gpurun_out", "parity_summary.txt"))
+
+
+def report(line):
+    """print + append to the parity summary file (best effort: a read-only tree must not fail a test)."""
+    print(line)
+    try:
+        os.makedirs(os.path.dirname(PARITY_SUMMARY), exist_ok=True)
+        with open(PARITY_SUMMARY, "a") as f:
+            f.write(line.strip("\n") + "\n")
+    except OSError:
+        pass
 
 
 def load_npz(path):
@@ -92,13 +110,15 @@ def small_case_params(name, case, param_seed):
                                head_dim=SMALL["dim"] // SMALL["heads"])
 
 
-def backbone_params(depth, dim, mlp_ratio, seed, tokens, rel_for=None, std=0.02):
+def backbone_params(depth, dim, mlp_ratio, seed, tokens, rel_for=None, std=0.02, qk_std=None):
     """Same generator as oracle/gen_golden.py::backbone_params (numpy RandomState => version-stable)."""
     rs = np.random.RandomState(seed)
     sd = {"position_encoding.encoding": torch.from_numpy((rs.standard_normal((1, tokens, dim)) * std).astype(np.float32))}
     for i in range(depth):
         rel = None if rel_for is None else rel_for(i)
         bp = O.make_block_params(dim, mlp_ratio, seed=seed * 100 + i, std=std, rel_sizes=rel, head_dim=64)
+        if qk_std is not None:
+            O.sharpen_qk(bp, dim, qk_std, std)
         for k, v in bp.items():
             sd[f"blocks.{i}.{k}"] = v
     return sd
@@ -109,10 +129,10 @@ def block_params_of(sd, i):
     return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
 
 
-def vivit_oracle(mode_cast, seed=77, k=128):
-    """ViViT-B spatial oracle + its parameters, as in gen_golden.gen_vivit."""
+def vivit_oracle(mode_cast, seed=77, k=128, qk_std=None):
+    """ViViT-B spatial oracle + its parameters, as in gen_golden.gen_vivit (qk_std: gen_vivit_sharp)."""
     dim, depth, heads, N = 768, 12, 12, 196
-    sd = backbone_params(depth, dim, 4, seed, N + 1)
+    sd = backbone_params(depth, dim, 4, seed, N + 1, qk_std=qk_std)
     rs = np.random.RandomState(seed + 1)
     cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
     ln_w = torch.from_numpy((1 + rs.standard_normal(dim) * 0.05).astype(np.float32))
@@ -127,13 +147,13 @@ def vivit_oracle(mode_cast, seed=77, k=128):
 VITDET_WINDOWED = (0, 1, 3, 4, 6, 7, 9, 10)  # configs/models/vitdet_b_coco.yml:13
 
 
-def vitdet_oracle(grid, policy_factory, cast_global, seed):
+def vitdet_oracle(grid, policy_factory, cast_global, seed, qk_std=None):
     dim, depth, heads = 768, 12, 12
 
     def rel_for(i):
         return (14, 14) if i in VITDET_WINDOWED else (64, 64)
 
-    sd = backbone_params(depth, dim, 4, seed, 14 * 14, rel_for=rel_for)
+    sd = backbone_params(depth, dim, 4, seed, 14 * 14, rel_for=rel_for, qk_std=qk_std)
     blocks = []
     for i in range(depth):
         if i in VITDET_WINDOWED:

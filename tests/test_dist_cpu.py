@@ -105,6 +105,32 @@ def test_eight_rank_dry_run_is_the_strong_scaling_split_of_the_one_rank_run():
     assert one["batches_per_rank"] == [[256] * 8] and eight["batches_per_rank"] == [[256]] * 8
     assert one["disjoint_cover"] and eight["disjoint_cover"]
     assert eight["n_gpus"] == 8 and eight["clips_per_rank"] == [256] * 8 and eight["weights_from_rank0"] is True
+    # no data-path collective.  bench.timed_region counts every torch.distributed call issued between its two
+    # barriers (max over ranks); the collectives that do exist (weight broadcast, the barriers, the max-reduce) are outside.
+    assert eight["collectives_in_timed_region"] == 0 and eight["collectives_total"] >= 4
+    assert one["collectives_in_timed_region"] == 0 and one["collectives_total"] == 0
+
+
+def test_timed_region_counts_collectives():
+    """The counter behind `collectives_in_timed_region` really sees torch.distributed calls made inside the bracket
+    (a one-rank gloo group, a step that -- wrongly -- synchronises the ranks)."""
+    import socket
+
+    import torch.distributed as dist
+
+    import bench
+
+    bench.install_collective_counter()
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        _, inside = bench.timed_region(lambda: dist.barrier(), 3, 1, lambda: None)
+        _, clean = bench.timed_region(lambda: None, 3, 1, lambda: None)
+    finally:
+        dist.destroy_process_group()
+    assert inside == 3 and clean == 0
 
 
 def test_only_rank0_generates_weights():

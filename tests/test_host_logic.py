@@ -24,7 +24,7 @@ def test_abi_header_symbols_are_exported():
         assert hasattr(lib, name), f"{name} declared in include/evt_abi.h but not exported"
     lib.evt_version.restype = ctypes.c_int
     lib.evt_target_arch.restype = ctypes.c_char_p
-    assert lib.evt_version() == _native.ABI_VERSION == 5 and lib.evt_target_arch() == b"gfx950"
+    assert lib.evt_version() == _native.ABI_VERSION == 6 and lib.evt_target_arch() == b"gfx950"
 
 
 def test_abi_argument_errors_without_gpu():
@@ -37,6 +37,13 @@ def test_abi_argument_errors_without_gpu():
     assert rc == -2 and b"multiple of 4" in lib.evt_last_error_string()
     rc = lib.evt_gated_linear(None, None)
     assert rc == -1
+    # shape-only query (ABI 6): ViTDet's 64 x 64 key grid fits a CU's LDS with every store type, an absurd grid does not
+    for store in (_native.EVT_F32, _native.EVT_BF16, _native.EVT_F16):
+        assert 0 < lib.evt_attention_stream_lds_bytes(store, 64, 64) <= _native.LDS_PER_CU
+    assert lib.evt_attention_stream_lds_bytes(_native.EVT_F32, 1000, 1000) > _native.LDS_PER_CU
+    assert lib.evt_attention_stream_lds_bytes(7, 8, 8) < 0
+    assert not _native.attention_stream_fits(1000000, 768, 12, _native.EVT_F32, 1000, 1000)
+    assert _native.attention_stream_fits(4096, 768, 12, _native.EVT_BF16, 64, 64)
 
 
 def test_splitk_workspace_query_is_shape_only():

@@ -84,12 +84,14 @@ def test_invariants_small():
 
 
 @pytest.mark.parametrize("fixture,k,mode,cast", [("vivit_b.npz", 128, "fp32", None), ("vivit_b.npz", 128, "bf16", "bfloat16"),
-                                                 ("vivit_b_k64.npz", 64, "bf16", "bfloat16")])
+                                                 ("vivit_b_k64.npz", 64, "bf16", "bfloat16"),
+                                                 ("vivit_b_sharp.npz", 128, "fp32", None), ("vivit_b_sharp.npz", 128, "bf16", "bfloat16")])
 def test_vivit_b_features(golden_dir, fixture, k, mode, cast):
     """ViViT-B spatial sub-model, free-running oracle vs the reference's golden features / index sets: BASELINE
-    config 2 (k = 128, 6 frames) and config 4's shape (k = 64, T = 32 frames)."""
+    config 2 (k = 128, 6 frames), config 4's shape (k = 64, T = 32 frames) and config 2 with sharp attention (12 frames)."""
     g = H.load_npz(os.path.join(golden_dir, fixture))
-    model, sd, *_ = H.vivit_oracle(cast, seed=int(g[f"{mode}__seed"]), k=k)
+    qk_std = float(g["qk_std"]) if "qk_std" in g.files else None
+    model, sd, *_ = H.vivit_oracle(cast, seed=int(g[f"{mode}__seed"]), k=k, qk_std=qk_std)
     feats = torch.from_numpy(g[f"{mode}__features"])
     idx = g[f"{mode}__idx"]
     xs = O.make_token_stream(1, 196, 768, feats.shape[0], k, seed=int(g[f"{mode}__seed"]) + 2, small=0.01)
@@ -118,18 +120,25 @@ def test_vitdet_672(golden_dir):
 
 
 def test_vitdet_1024_threshold(golden_dir):
+    """Config 5 fixture (variable r: continuous-magnitude stream, sharp attention): the oracle against the reference's outputs,
+    counts and index lists over the first two gated frames (the GPU test walks all of them)."""
     g = H.load_npz(os.path.join(golden_dir, "vitdet_1024.npz"))
     seed, thr = int(g["seed"]), float(g["threshold"])
-    ob, sd = H.vitdet_oracle(64, lambda: O.Threshold(thr), "bfloat16", seed)
+    ob, sd = H.vitdet_oracle(64, lambda: O.Threshold(thr), "bfloat16", seed, qk_std=float(g["qk_std"]))
     want = torch.from_numpy(g["y_slice"])
-    xs = O.make_threshold_stream(64 * 64, 768, want.shape[0], seed + 2)
+    frames = min(3, want.shape[0])
+    xs = O.make_varied_threshold_stream(64 * 64, 768, want.shape[0], int(g["stream_seed"]))
     with torch.inference_mode():
-        for t in range(want.shape[0]):
+        for t in range(frames):
             y = ob.forward(xs[t].clone())[:, ::64]
             assert torch.allclose(y, want[t], atol=ATOL, rtol=0), (t, float((y - want[t]).abs().max()))
             if t > 0:
                 counts = [blk.trace[k].shape[-1] for blk in ob.blocks for k in ("qkv_index", "projection_index", "mlp_index")]
                 assert counts == g["counts"][t - 1].reshape(-1).tolist()
+                for bi, blk in enumerate(ob.blocks):
+                    for k in ("qkv_index", "projection_index", "mlp_index"):
+                        assert np.array_equal(blk.trace[k].reshape(-1).numpy(), g[f"idx_{t}_{bi}_{k}"].reshape(-1).astype(np.int64))
+    assert len(set(g["counts"].reshape(-1).tolist())) > 12, "the fixture's counts must vary per gate and per frame"
 
 
 def _ats_cases():
