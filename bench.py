@@ -51,10 +51,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured copy ceiling)
 VITDET_WINDOWED = (0, 1, 3, 4, 6, 7, 9, 10)   # configs/models/vitdet_b_coco.yml:13
-# Random-init weights: normal(0, 0.02), except the query / key rows of every `qkv` layer in the ViViT workloads and in vitdet1024,
-# which are drawn at 0.06 -- with 0.02 the attention is near-uniform and the projection gate's delta norms are near-tied (median top-k
-# margin 1.7e-4), so its index sets could not be compared with the reference at any meaningful margin (oracle.sharpen_qk; same
-# shapes and launches, the timing does not depend on it).
+# Random-init weights: normal(0, 0.02).  The fp32-mode self-check (`check_fp32`, where north_star's bit-exact gate-index bar
+# holds) draws the query / key rows of every `qkv` layer at 0.06 instead: with 0.02 the attention is near-uniform and the
+# projection gate's delta norms are near-tied (median top-k margin 1.7e-4), so a third of the gates could not be compared with
+# the reference at any meaningful margin (oracle.sharpen_qk; same shapes and launches).  The timed bf16-cast run keeps 0.02: a
+# sharp attention output of magnitude ~1 carries a bf16 rounding step of 2^-9 of its own, and the cast mode's feature
+# tolerance is tied to the reference's measured self-agreement on the 0.02 model (tests/golden/envelope.npz).
 QK_STD = 0.06
 
 WORKLOADS = {
@@ -98,10 +100,11 @@ def _sharpen_qk(sd, prefix, qk_std, std):
     return sd
 
 
-def seeded_state_dict(seed=77, std=0.02, qk_std=QK_STD):
+def seeded_state_dict(seed=77, std=0.02, qk_std=None):
     """ViViT-B spatial sub-model parameters under the reference's state_dict names (ViViTSubModel,
     vivit.py:272-291).  Version-stable generator (numpy RandomState), as in the parity tests."""
-    return _sharpen_qk(_seeded_state_dict(seed, std), "backbone.", qk_std, std)
+    sd = _seeded_state_dict(seed, std)
+    return sd if qk_std is None else _sharpen_qk(sd, "backbone.", qk_std, std)
 
 
 def _seeded_state_dict(seed, std):
@@ -494,7 +497,7 @@ class _ReplayTopK:
         return self.forced
 
 
-def self_check_vivit(model, clips, sd, cast, k, max_frames=None):
+def self_check_vivit(model, clips, sd, cast, k, max_frames=None, qk_std=None):
     """After the timed region: runs the timed model once more on the same resident batch (identical launches) and
     reads back clip 0's class embeddings and -- through the package's diagnostic INDEX_TAP -- clip 0's three gate index
     sets per block per frame.  The CPU oracle then replays clip 0 with THOSE index sets forced into its gates (so a
@@ -566,9 +569,9 @@ def self_check_vivit(model, clips, sd, cast, k, max_frames=None):
     # moves by ~1e-2 (the reference's own fp32-vs-bf16 gap on this model is 6.6e-2).
     tol = 1e-3 if cast is None else 2e-2
     # fp32 mode over a whole clip: the projection gates (a third of all gates) must be part of the claim, not skipped as near-ties
-    proj_needed = 60 if (cast is None and k > 0 and T >= 12) else 0
+    proj_needed = 60 if (cast is None and k > 0 and T >= 12 and qk_std is not None) else 0
     proj_ok = per_gate["projection"]["checked"] >= proj_needed
-    return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol,
+    return {"clip": 0, "frames": T, "max_abs_err": round(worst, 6), "tolerance": tol, "qk_weight_std": qk_std or 0.02,
             "gates_checked": checked, "index_sets_equal": bool(checked == equal_on_margin),
             "projection_gates_checked_min": proj_needed,
             "gates_total": total, "agreement_rate_all_margins": round(equal_all / total, 4) if total else None,
@@ -697,7 +700,7 @@ def log(msg):
 
 
 def build_workload(name, device, world, rank, clips=256, total_clips=None, frames=None, k=None, cast_arg=None, threshold=1.0,
-                   streams=1):
+                   streams=1, qk_std=None):
     """Model + resident synthetic data of one workload on this rank -> dict (model, data, sd, policy, ...)."""
     kind, block_class, wl_frames, wl_k, cast, grid = WORKLOADS[name]
     frames = frames if frames is not None else wl_frames
@@ -718,10 +721,9 @@ def build_workload(name, device, world, rank, clips=256, total_clips=None, frame
     # weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective); the other ranks only
     # allocate the same shapes
     if kind == "vivit":
-        sd = seeded_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes().items()}
+        sd = seeded_state_dict(qk_std=qk_std) if rank == 0 else {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes().items()}
     else:
-        sd = (vitdet_state_dict(qk_std=QK_STD if name == "vitdet1024" else None) if rank == 0
-              else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()})
+        sd = vitdet_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()}
     if world > 1:
         broadcast_weights(sd, {}, device, rank)
     if kind == "vivit":
@@ -1292,9 +1294,9 @@ def main():
             ok = ok and line["check"]["ok"]
             if cast is not None and k > 0:
                 # the same model in the reference's fp32 mode (no A.v cast), 4 clips: where north_star's 1e-3 / bit-exact bar holds
-                w32 = build_workload(args.workload, device, 1, 0, clips=4, total_clips=4, frames=frames, k=k, cast_arg="none")
+                w32 = build_workload(args.workload, device, 1, 0, clips=4, total_clips=4, frames=frames, k=k, cast_arg="none", qk_std=QK_STD)
                 try:
-                    line["check_fp32"] = self_check_vivit(w32["model"], w32["data"][0], w32["sd"], None, k)
+                    line["check_fp32"] = self_check_vivit(w32["model"], w32["data"][0], w32["sd"], None, k, qk_std=QK_STD)
                 finally:
                     release_workload(w32)
                 log(f"self-check (fp32 mode) vs CPU oracle: {line['check_fp32']}")

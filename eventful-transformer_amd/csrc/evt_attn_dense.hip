@@ -14,6 +14,7 @@
 // on the bf16 hi/lo split MFMA like evt_qk's split mode (three bf16 MFMAs per product, 16x the rate); expf,
 // probabilities and values rounded to the store type T, P.V on the T-input MFMA (fp32: 32x32x2; bf16 / fp16: 32x32x16),
 // result rounded to T.
+#include "evt_attn_dense.h"
 #include "evt_linear.h"   // split4 (fp32 -> bf16 hi / lo), bf16x8_t
 
 #ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/attn_prof.py --dense)
@@ -31,15 +32,6 @@ constexpr int AR = 32;     // query rows per workgroup
 constexpr int DH = 64;     // head dim
 constexpr int QP = DH + 4; // fp32 LDS pitch of the q / k tiles
 constexpr int KC = 64;     // keys per staged chunk
-
-struct DenseArgs {
-  const float* qkv; const float* rel_y; const float* rel_x;
-  const int32_t* tok_map; const float* pad_row;
-  float* out_f32; float* product; void* a_state; void* pv;
-  int groups_per_clip, clip_rows;
-  int G, H, N, D, gh, gw, qw;
-  float scale;
-};
 
 // SPLIT: S = (q / scale) k^T and the rel-pos terms on v_mfma_f32_16x16x32_bf16 with q, k and the rel-pos tables as bf16
 // hi + lo (three MFMAs per product, ~1e-5 relative -- the arithmetic of evt_qk / evt_softmax_av_gated / evt_attention_stream in
@@ -560,6 +552,11 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
   DenseArgs a{d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row, d->out_f32, d->product, d->a_state, d->pv,
               d->tok_map ? d->groups_per_clip : 1, d->tok_map ? d->clip_rows : d->N, d->G, d->H, d->N, d->D,
               d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale};
+  // Resident form first (evt_attn_window.hip: the group's K / V staged once per (group, head)); the tiled kernel below keeps
+  // the launches that want state outputs and the shapes whose planes do not fit a CU's LDS.  EVT_DENSE_TILED=1 forces it.
+  static const bool tiled_only = getenv("EVT_DENSE_TILED") != nullptr && atoi(getenv("EVT_DENSE_TILED")) != 0;
+  if (a.G == 0) return EVT_OK;
+  if (!tiled_only && evt_launch_window(a, d->store, d->qk_split, evt_stream(stream))) return evt_check_launch("evt_attention_dense (resident)");
   EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, d->qk_split, stream); });
   return EVT_OK;
 }

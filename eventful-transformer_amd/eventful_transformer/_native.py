@@ -7,6 +7,7 @@ device, the call raises.
 """
 import ctypes
 import os
+import threading
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch
@@ -190,25 +191,24 @@ def _check(rc):
         raise RuntimeError(f"libevt_hip: {msg} (status {rc})")
 
 
-_lane_stream = {}   # (device, work lane) -> (stream handle, stream) that last launched there
+_lane_stream = {}   # (thread, device, work lane) -> (stream handle, stream) that last launched there
 
 
 def _stream():
-    """The current HIP stream's handle.  Work buffers (`scratch`) are shared by everything that runs in one work lane of a
-    device, which is only sound while that work is ordered on ONE stream: a launch from a second stream while the first still
-    has work in flight raises instead of silently sharing index lists and hidden buffers.  Drive two streams (or threads) with
-    `with _native.lane(i):` around each one's calls."""
+    """The current HIP stream's handle.  Work buffers (`scratch`) are shared by everything one host thread runs in one work
+    lane of a device, which is only sound while that work is ordered: when the launching stream CHANGES within a lane, the new
+    stream first waits for everything the previous one has been given (one event, only at the switch), so two streams driven
+    from one thread can never use a lane's index lists or hidden rows at the same time -- they serialise at the switch instead.
+    Run them concurrently with `with _native.lane(i):` around each one's calls.  Inside a graph capture the
+    switch is only recorded: torch synchronises the device before a capture begins, and a captured stream runs nothing."""
     st = torch.cuda.current_stream()
     h = st.cuda_stream
-    key = (st.device_index, _lane)
+    key = (threading.get_ident(), st.device_index, _lane)
     last = _lane_stream.get(key)
     if last is None or last[0] != h:
-        if last is not None and not torch.cuda.is_current_stream_capturing() and not last[1].query():
-            raise RuntimeError(
-                f"eventful_transformer: HIP stream {h:#x} launches into work lane {_lane} of device {st.device_index} while "
-                f"stream {last[0]:#x} still has work in flight there; the lane's scratch buffers (index lists, hidden rows, ...) "
-                "would be shared.  Synchronise the streams, or give each its own lane: `with _native.lane(i): model(x)`.")
-        _lane_stream[key] = (h, st)
+        if last is not None and not torch.cuda.is_current_stream_capturing() and not last[2]:
+            st.wait_stream(last[1])
+        _lane_stream[key] = (h, st, torch.cuda.is_current_stream_capturing())
     return c_void_p(h)
 
 
@@ -233,8 +233,9 @@ def store_code(dtype):
 # --------------------------------------------------------------------------------------------------
 # scratch pool: fixed-address work buffers shared by all blocks on a device (blocks run one after
 # another on one stream, so the hidden/ã/Δã/... scratch never needs to exist per block).  The pool is keyed by
-# (name, shape, dtype, device, work lane) -- NOT by stream or model: two same-shaped models share buffers, which is
-# correct while one stream orders them (`_stream` enforces that) and is what `lane` is for otherwise.
+# (name, shape, dtype, device, work lane, host thread) -- NOT by stream or model: two same-shaped models driven by one
+# thread share buffers, which is correct because their launches are ordered (`_stream` orders a stream switch within a lane)
+# and is what `lane` is for when they should overlap; every host thread has its own buffers.
 # --------------------------------------------------------------------------------------------------
 _pool = {}
 _lane = 0   # frames of one stream captured side by side on several HIP streams (graphs.FrameGraphs.run_pipelined) each
@@ -257,7 +258,8 @@ class lane:
 
 
 def scratch(name, shape, dtype, device):
-    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device(), _lane)
+    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device(), _lane,
+           threading.get_ident())
     t = _pool.get(key)
     if t is None:
         t = torch.empty(tuple(shape), dtype=dtype, device=device)

@@ -53,6 +53,7 @@ class FrameGraphs:
         self._inc_warm = False
         self._pipe = None        # (graph, static inputs, static outputs, side streams) of `run_pipelined`
         self._pipe_warm = 0
+        self._keep = []          # weight planes / rel-pos tables / sized encodings the captured graphs read
 
     def reset(self):
         """Start a new clip.  Before the first-frame graph exists this resets the model; afterwards the graph
@@ -64,6 +65,7 @@ class FrameGraphs:
     def release(self):
         """Drop the graphs (and their private memory pools) and reset the model."""
         self._first = self._inc = self._x = self._pipe = None
+        self._keep = []
         self._t = 0
         self._inc_warm = False
         self._pipe_warm = 0
@@ -98,13 +100,17 @@ class FrameGraphs:
                 # reset() dropped every cache that is rebuilt lazily: the bf16 weight planes, the rel-pos tables and the
                 # sized position encoding.  Rebuild them OUTSIDE the capture -- the bicubic resize creates host tensors
                 # and copies them to the device, which must not become graph nodes reading freed host memory.
+                # The graphs read these caches at their CAPTURED addresses: keep them alive for as long as this object lives -- a
+                # later eager `model.reset()` (or another FrameGraphs capturing the same model at another shape) drops the
+                # model's own references and would otherwise leave the replays reading freed memory.
+                self._keep = []
                 for m in self.model.modules():
                     if isinstance(m, CountedLinear):
-                        m.split_planes()
+                        self._keep.append(m.split_planes())
                     elif isinstance(m, RelativePositionEmbedding):
-                        m.tables()
+                        self._keep.append(m.tables())
                     elif isinstance(m, PositionEncoding):
-                        m.sized()
+                        self._keep.append(m.sized())
                 self._first = self._capture()
             graph, y = self._first
             graph.replay()

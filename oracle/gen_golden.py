@@ -384,8 +384,9 @@ def gen_vitdet672():
 
 def gen_vitdet1024(thr=1.0, fname="vitdet_1024.npz", steps=5, seed=93):
     """BASELINE config 5 at full size (N = 4096, bf16 A.v in the global blocks) with GENUINELY variable r: a stream with
-    continuous per-token perturbation magnitudes (O.make_varied_threshold_stream) through a backbone with sharp attention
-    (O.sharpen_qk, so that projection gates select tokens too), `steps - 1` gated frames.  The REAL reference's
+    continuous per-token perturbation magnitudes (O.make_varied_threshold_stream), `steps - 1` gated frames.  (Weights stay
+    at std 0.02: with sharp attention the bf16-cast attention outputs are O(1) and ONE flipped bf16 rounding already moves the
+    block output by 1.6e-3 -- the 1e-3 output bar of this config is tied to near-uniform attention.)  The REAL reference's
     `TokenNormThreshold` decides; the oracle must agree bit for bit.  Stored per gate and frame: the index list, its count, the
     closeness `margin` = min over tokens of | ||e|| - thr | / thr, and the NEAR list -- the tokens within 1e-3 (relative) of the
     threshold, with that distance.  With thousands of tokens and continuous norms somebody always sits within 1e-6 of the
@@ -393,11 +394,11 @@ def gen_vitdet1024(thr=1.0, fname="vitdet_1024.npz", steps=5, seed=93):
     GPU test therefore forces the reference's decisions (through the device-side index lists and counts) and requires the HIP
     selection to differ from the reference's in NEAR tokens only."""
     ref, ob, sd, N = vitdet_ref_and_oracle(64, lambda: rpolicies.TokenNormThreshold(thr),
-                                           lambda: O.Threshold(thr, save_status=True), "bfloat16", seed, qk_std=0.06)
+                                           lambda: O.Threshold(thr, save_status=True), "bfloat16", seed)
     stream_seed = seed + 2
     xs = O.make_varied_threshold_stream(N, 768, steps, stream_seed)
     pack = {"torch_version": np.bytes_(torch.__version__), "seed": np.int64(seed), "stream_seed": np.int64(stream_seed),
-            "threshold": np.float64(thr), "qk_std": np.float64(0.06), "stream": np.bytes_("varied"), "near_bar": np.float64(O.Threshold.NEAR)}
+            "threshold": np.float64(thr), "stream": np.bytes_("varied"), "near_bar": np.float64(O.Threshold.NEAR)}
     outs, counts, margins, n_near = [], [], [], 0
     with torch.inference_mode():
         for t in range(steps):

@@ -42,8 +42,19 @@ if a.dense is not None:
         for _ in range(100):
             n.attention_dense(qkv, G, H, N, D, 8.0, n.store_code(torch.float32), out_f32=out, rel_y=ry, rel_x=rx, gh=14, gw=14, qw=14)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
     lib = n.load()
+    if a.dense == "window" and not os.environ.get("EVT_DENSE_TILED"):   # the resident kernel (evt_attn_window.hip)
+        buf = (ctypes.c_ulonglong * 12)()
+        lib.evt_debug_prof_window.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+        assert lib.evt_debug_prof_window(buf) == 0
+        names = ["window map + q requests", "K staging", "V staging", "rel-pos items", "barrier", "q fragments + S^T products",
+                 "rel-pos adds + masks + row max", "exps + row sum", "P conversion + P.V", "epilogue"]
+        tot = sum(buf[q] for q in range(10))
+        print(f"K8 resident, window launch: wave 0 of one workgroup: {tot} ticks (100 MHz: {tot / 100:.1f} us)")
+        for q, nm in enumerate(names):
+            print(f"   {nm:32s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")
+        sys.exit(0)
+    buf = (ctypes.c_ulonglong * 8)()
     lib.evt_debug_prof_dense.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
     assert lib.evt_debug_prof_dense(buf) == 0
     names = ["q rows + K chunk 0 staged", "rel-pos dots + q fragments", "q.k^T chunks", "softmax + state write", "P.V chunks", "epilogue"]

@@ -30,6 +30,17 @@ case $what in
     python scripts/kbench.py ${what#kbench=} 2>&1 | tee -a $OUT/kbench.txt ;;
   osb)
     python scripts/onestream_bench.py 2>&1 | tee $OUT/osb.txt ;;
+  dense_occ)   # K8 at ViTDet's window shape: resident kernel (both workgroup shapes) and the tiled kernel
+    python scripts/dense_occ.py 2>&1 | tee $OUT/dense_occ.txt
+    EVT_WINDOW_NW=8 python scripts/dense_occ.py 2>&1 | tee -a $OUT/dense_occ.txt
+    EVT_WINDOW_NW=4 python scripts/dense_occ.py 2>&1 | tee -a $OUT/dense_occ.txt
+    EVT_DENSE_TILED=1 python scripts/dense_occ.py 2>&1 | tee -a $OUT/dense_occ.txt ;;
+  prof_window) # phase timing inside the resident K8 kernel (scripts/build_variant.sh prof -DEVT_PROF first)
+    EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so EVT_WINDOW_NW=8 python scripts/attn_prof.py --dense window 2>&1 | tee $OUT/k8_resident_phase_profile.txt
+    EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so EVT_WINDOW_NW=4 python scripts/attn_prof.py --dense window 2>&1 | tee -a $OUT/k8_resident_phase_profile.txt ;;
+  vd)          # one-stream ViTDet latency (graph replay)
+    python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log
+    python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log ;;
   py=*)        # any script with arguments: py=scripts/x.py,--a,1
     IFS=',' read -r -a ARGS <<< "${what#py=}"
     python "${ARGS[@]}" 2>&1 | tee -a $OUT/py.txt ;;

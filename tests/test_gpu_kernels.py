@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 5
+    assert lib.evt_version() == n.ABI_VERSION == 6
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -625,6 +625,54 @@ def test_attention_dense_fused_vs_fp64(cast, N, rel, qk_split):
     n.v_gate(qd, None, None, B, N, D, 0, v2, None, None, store, False)
     n.av(a2, v2, N, B, H, N, N, D, store, out_f32=out2)
     assert float((out.cpu() - out2.cpu()).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("cast,N,rel", [(None, 197, False), ("bfloat16", 197, False), (None, 196, True), ("float16", 100, True),
+                                        (None, 256, False), (None, 33, False), ("bfloat16", 196, True), (None, 144, True)])
+@pytest.mark.parametrize("qk_split", [0, 1])
+@pytest.mark.parametrize("B,H", [(2, 3), (25, 6)])
+def test_attention_dense_resident_vs_fp64(cast, N, rel, qk_split, B, H):
+    """K8, resident form (evt_attn_window.hip: the launches of evt_attention_dense WITHOUT state outputs -- ViTDet's windowed
+    blocks on every frame, dense `Block`s): one workgroup per (group, head) with K / V staged once, scores and probabilities
+    in registers.  Against an fp64 restatement of blocks.py:205-240 with the reference's rounding points and against the tiled
+    kernel (same call with a state output), for both workgroup shapes: 6 (group, head) pairs -> two 4-wave workgroups per
+    pair; 150 pairs -> one 8-wave workgroup."""
+    n = native()
+    dh = 64
+    D = H * dh
+    g = torch.Generator().manual_seed(N + (7 if rel else 0) + B)
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    scale = float(np.sqrt(dh))
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    side = int(round(N ** 0.5))
+    ry = rx = None
+    if rel:
+        assert side * side == N
+        ry = torch.randn(side, side, dh, generator=g) * 0.2
+        rx = torch.randn(side, side, dh, generator=g) * 0.2
+    q, k, v = qkv.double().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = ((q.float() / scale).double()) @ k.transpose(-2, -1)
+    if rel:
+        qg = q.reshape(B, H, side, side, dh)
+        ty = torch.einsum("bhyxd,ykd->bhyxk", qg, ry.double())
+        tx = torch.einsum("bhyxd,xkd->bhyxk", qg, rx.double())
+        s = (s.view(B, H, side, side, side, side) + ty[..., :, None] + tx[..., None, :]).reshape(B, H, N, N)
+    p = torch.softmax(s, dim=-1).to(sdt)
+    vv = v.float().to(sdt)
+    want = (p.double() @ vv.double()).to(sdt).float().permute(0, 2, 1, 3).reshape(B, N, D)
+    kw = dict(rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=side, gw=side, qw=side) if rel else {}
+    qd = qkv.to(DEV)
+    out = torch.full((B, N, D), float("nan"), device=DEV)
+    n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out, qk_split=qk_split, **kw)
+    # split arithmetic with an fp32 store type also runs P.V as bf16 hi / lo products (~1e-5 relative)
+    tol = {None: 2e-5 if not qk_split else 2e-4, "bfloat16": 1.6e-2, "float16": 2e-3}[cast]
+    err = float((out.cpu() - want).abs().max())
+    assert err <= tol, (cast, N, rel, qk_split, B, err)
+    out_t = torch.empty(B, N, D, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out_t, pv=pv, qk_split=qk_split, **kw)   # a state output: tiled kernel
+    assert float((out - out_t).abs().max()) <= tol
 
 
 def test_attention_dense_windowed_block_matches_chain():
