@@ -131,139 +131,145 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
   }
 
   WN_TICK(0);   // window map + q row requests
-  // ---- K rows -> LDS (key-major; split mode: bf16 hi | lo planes).  All loads first, then the stores. -------------------
-  {
-    constexpr int MAXIT = (MAXB * 32 * 16 + NT - 1) / NT;
-    f32x4 kr[MAXIT];
+  // ---- staging.  Every global load of the phase is requested before the first one is consumed: the first batch of rel-pos
+  //      items, the K rows, the V rows -- a workgroup then waits for ~one round trip, not one per step (in-kernel phase timing
+  //      of the first version, which loaded and consumed step by step: 23k of a workgroup's 61k ticks here). -----------------
+  // rel-pos terms (utils.py:159-168, UNSCALED q . table row) as 16 x 16 tiles: item = (grid row Y | grid column X, 16 of
+  // its queries, 16 of its table rows); the waves deal the items round robin, BS in flight per wave.
+  constexpr int BS = 2;   // (4 in flight for the 4-wave shape spilled: 64 + 64 staging registers of K / V on top)
+  const int qh_ = rel ? a.N / a.qw : 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int nqy = (a.qw + 15) >> 4, nty = (a.gh + 15) >> 4, nqx = (qh_ + 15) >> 4, ntx = (a.gw + 15) >> 4;
+  const int items_y = rel ? qh_ * nqy * nty : 0, items = rel ? items_y + a.qw * nqx * ntx : 0;
+  auto frag_chan = [&](int m) __attribute__((always_inline)) { return SPLIT ? 32 * (m >> 1) + 8 * kg + 4 * (m & 1) : 16 * kg + 4 * m; };
+  f32x4 tf[BS][4], qf[BS][4];
+  int it_qi[BS], it_e[BS];   // lane's query token (-1: none), lane's table slot in the terms row (-1: none)
+  auto load_item = [&](int it, int u) __attribute__((always_inline)) {
+    const bool isy = it < items_y;
+    const int x = isy ? it : it - items_y;
+    const int nq = isy ? nqy : nqx, nt = isy ? nty : ntx;
+    const int sel = x / (nq * nt), rem = x - sel * (nq * nt), qc = rem / nt, tc = rem - qc * nt;
+    const int qn = isy ? a.qw : qh_, tn = isy ? a.gh : a.gw;
+    const int ql = qc * 16 + l15, tl = tc * 16 + l15;
+    const int qtok = isy ? sel * a.qw + ql : ql * a.qw + sel;
+    it_qi[u] = ql < qn ? qtok : -1;
+    it_e[u] = tl < tn ? (isy ? tl : a.gh + tl) : -1;
+    const float* trow_ = (isy ? a.rel_y + ((int64_t)sel * a.gh + min(tl, tn - 1)) * DH : a.rel_x + ((int64_t)sel * a.gw + min(tl, tn - 1)) * DH);
+    const float* qrow_ = row_ptr(ql < qn ? qtok : 0) + h * DH;
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int e = tid + NT * it, j = e >> 4, c4 = e & 15;
-      kr[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (j < a.N) kr[it] = *reinterpret_cast<const f32x4*>(row_ptr(j) + a.D + h * DH + c4 * 4);
+    for (int m = 0; m < 4; ++m) {
+      tf[u][m] = *reinterpret_cast<const f32x4*>(trow_ + frag_chan(m));
+      qf[u][m] = *reinterpret_cast<const f32x4*>(qrow_ + frag_chan(m));
     }
+  };
+  auto consume_item = [&](int u) __attribute__((always_inline)) {
+    // D[i = table row 4 kg' + r][j = query l15]: lane (l15, kg) holds rows 4 kg + r of ITS query column
+    f32x4_acc acc = {0.f, 0.f, 0.f, 0.f};
+    if (SPLIT) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int e = tid + NT * it, j = e >> 4, c4 = e & 15;
-      if (j < NP) {
-        if (SPLIT) {
-          bf16x4_t hi, lo;
-          split4(make_float4(kr[it][0], kr[it][1], kr[it][2], kr[it][3]), &hi, &lo);
-          *reinterpret_cast<bf16x4_t*>(Khi + (size_t)j * KPB + c4 * 4) = hi;
-          *reinterpret_cast<bf16x4_t*>(Klo + (size_t)j * KPB + c4 * 4) = lo;
-        } else {
-          *reinterpret_cast<f32x4*>(Kf + (size_t)j * KPF + c4 * 4) = kr[it];
-        }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x4_t th0, tl0, th1, tl1, qh0, ql0, qh1, ql1;
+        split4(make_float4(tf[u][2 * s2][0], tf[u][2 * s2][1], tf[u][2 * s2][2], tf[u][2 * s2][3]), &th0, &tl0);
+        split4(make_float4(tf[u][2 * s2 + 1][0], tf[u][2 * s2 + 1][1], tf[u][2 * s2 + 1][2], tf[u][2 * s2 + 1][3]), &th1, &tl1);
+        split4(make_float4(qf[u][2 * s2][0], qf[u][2 * s2][1], qf[u][2 * s2][2], qf[u][2 * s2][3]), &qh0, &ql0);
+        split4(make_float4(qf[u][2 * s2 + 1][0], qf[u][2 * s2 + 1][1], qf[u][2 * s2 + 1][2], qf[u][2 * s2 + 1][3]), &qh1, &ql1);
+        const bf16x8_t th = __builtin_shufflevector(th0, th1, 0, 1, 2, 3, 4, 5, 6, 7), tl = __builtin_shufflevector(tl0, tl1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8_t qh8 = __builtin_shufflevector(qh0, qh1, 0, 1, 2, 3, 4, 5, 6, 7), ql8 = __builtin_shufflevector(ql0, ql1, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl, qh8, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, ql8, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, qh8, acc, 0, 0, 0);
       }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[u][m][c], qf[u][m][c], acc, 0, 0, 0);
+    }
+    // the table slot of row 4 kg + r is the `e` of lane (4 kg + r): fetch it from that lane
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = __shfl(it_e[u], 4 * kg + r, 64);
+      if (it_qi[u] >= 0 && e >= 0) terms[it_qi[u] * TP + e] = acc[r];
+    }
+  };
+  auto load_batch = [&](int n) __attribute__((always_inline)) {   // items wave + NW (BS n + u)
+#pragma unroll
+    for (int u = 0; u < BS; ++u) {
+      const int it = wave + NW * (BS * n + u);
+      if (it < items) load_item(it, u);   // wave-uniform
+    }
+  };
+  auto consume_batch = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < BS; ++u) {
+      const int it = wave + NW * (BS * n + u);
+      if (it < items) consume_item(u);
+    }
+  };
+  const int batches = rel ? (items - wave + NW * BS - 1) / (NW * BS) : 0;   // of this wave
+  if (batches > 0) load_batch(0);
+  // K rows (key-major; split mode: bf16 hi | lo planes) and V rows (transposed: [channel][key], four consecutive keys of one
+  // channel per store)
+  constexpr int KIT = (MAXB * 32 * 16 + NT - 1) / NT, VIT = (MAXB * 8 * 16 + NT - 1) / NT;
+  f32x4 kr[KIT], vv[VIT][4];
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int e = tid + NT * it, j = e >> 4, c4 = e & 15;
+    kr[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (j < a.N) kr[it] = *reinterpret_cast<const f32x4*>(row_ptr(j) + a.D + h * DH + c4 * 4);
+  }
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) {
+    const int e = tid + NT * it, jq = e >> 4, c4 = e & 15;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = 4 * jq + u;
+      vv[it][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (j < a.N) vv[it][u] = *reinterpret_cast<const f32x4*>(row_ptr(j) + 2 * a.D + h * DH + c4 * 4);
     }
   }
-  WN_TICK(1);   // K staging
-  // ---- V rows -> LDS, transposed: [channel][key], four consecutive keys of one channel per store ------------------------
-  {
-    constexpr int MAXIT = (MAXB * 8 * 16 + NT - 1) / NT;
-    f32x4 vv[MAXIT][4];
+  WN_TICK(1);   // requests issued
+  if (batches > 0) consume_batch(0);
+  if (batches > 1) load_batch(1);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int e = tid + NT * it, jq = e >> 4, c4 = e & 15;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = 4 * jq + u;
-        vv[it][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (j < a.N) vv[it][u] = *reinterpret_cast<const f32x4*>(row_ptr(j) + 2 * a.D + h * DH + c4 * 4);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int e = tid + NT * it, jq = e >> 4, c4 = e & 15;
-      if (4 * jq < NP) {   // uniform per 16-lane group
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float x0 = vv[it][0][c], x1 = vv[it][1][c], x2 = vv[it][2][c], x3 = vv[it][3][c];
-          const size_t off = (size_t)(4 * c4 + c) * VP + 4 * jq;
-          if constexpr (F32 && SPLIT) {
-            bf16x4_t hi, lo;
-            split4(make_float4(x0, x1, x2, x3), &hi, &lo);
-            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(vreg) + off) = hi;
-            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(vreg + L.v_plane_bytes) + off) = lo;
-          } else if constexpr (F32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(vreg) + off) = (f32x4){x0, x1, x2, x3};
-          } else {
-            *reinterpret_cast<typename Half<T>::v4*>(reinterpret_cast<uint16_t*>(vreg) + off) = Half<T>::cvt(x0, x1, x2, x3);
-          }
-        }
-      }
-    }
-  }
-  WN_TICK(2);   // V staging
-  // ---- rel-pos terms (utils.py:159-168, UNSCALED q . table row) as 16 x 16 tiles: item = (grid row Y | grid column X,
-  //      16 of its queries, 16 of its table rows); the waves deal the items round robin, two in flight per wave ----------
-  if (rel) {
-    const int qh_ = a.N / a.qw;
-    const int l15 = lane & 15, kg = lane >> 4;
-    const int nqy = (a.qw + 15) >> 4, nty = (a.gh + 15) >> 4, nqx = (qh_ + 15) >> 4, ntx = (a.gw + 15) >> 4;
-    const int items_y = qh_ * nqy * nty, items = items_y + a.qw * nqx * ntx;
-    auto frag_chan = [&](int m) __attribute__((always_inline)) { return SPLIT ? 32 * (m >> 1) + 8 * kg + 4 * (m & 1) : 16 * kg + 4 * m; };
-    struct Item { int qi, e, qv, tv; };   // lane's query token (-1: none), lane's table slot in the terms row (-1: none)
-    auto decode = [&](int it, const float** trow, const float** qrow, Item* d) __attribute__((always_inline)) {
-      const bool isy = it < items_y;
-      const int x = isy ? it : it - items_y;
-      const int nq = isy ? nqy : nqx, nt = isy ? nty : ntx;
-      const int sel = x / (nq * nt), rem = x - sel * (nq * nt), qc = rem / nt, tc = rem - qc * nt;
-      const int qn = isy ? a.qw : qh_, tn = isy ? a.gh : a.gw;
-      const int ql = qc * 16 + l15, tl = tc * 16 + l15;
-      const int qtok = isy ? sel * a.qw + ql : ql * a.qw + sel;
-      d->qi = ql < qn ? qtok : -1;
-      d->e = tl < tn ? (isy ? tl : a.gh + tl) : -1;
-      *trow = (isy ? a.rel_y + ((int64_t)sel * a.gh + min(tl, tn - 1)) * DH : a.rel_x + ((int64_t)sel * a.gw + min(tl, tn - 1)) * DH);
-      *qrow = row_ptr(ql < qn ? qtok : 0) + h * DH;
-    };
-    auto consume = [&](const float4* tf, const float4* qf, const Item& d) __attribute__((always_inline)) {
-      // D[i = table row 4 kg' + r][j = query l15]: lane (l15, kg) holds rows 4 kg + r of ITS query column
-      f32x4_acc acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < KIT; ++it) {
+    const int e = tid + NT * it, j = e >> 4, c4 = e & 15;
+    if (j < NP) {
       if (SPLIT) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x4_t th0, tl0, th1, tl1, qh0, ql0, qh1, ql1;
-          split4(tf[2 * s], &th0, &tl0); split4(tf[2 * s + 1], &th1, &tl1);
-          split4(qf[2 * s], &qh0, &ql0); split4(qf[2 * s + 1], &qh1, &ql1);
-          const bf16x8_t th = __builtin_shufflevector(th0, th1, 0, 1, 2, 3, 4, 5, 6, 7), tl = __builtin_shufflevector(tl0, tl1, 0, 1, 2, 3, 4, 5, 6, 7);
-          const bf16x8_t qh = __builtin_shufflevector(qh0, qh1, 0, 1, 2, 3, 4, 5, 6, 7), ql = __builtin_shufflevector(ql0, ql1, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl, qh, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, ql, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th, qh, acc, 0, 0, 0);
-        }
+        bf16x4_t hi, lo;
+        split4(make_float4(kr[it][0], kr[it][1], kr[it][2], kr[it][3]), &hi, &lo);
+        *reinterpret_cast<bf16x4_t*>(Khi + (size_t)j * KPB + c4 * 4) = hi;
+        *reinterpret_cast<bf16x4_t*>(Klo + (size_t)j * KPB + c4 * 4) = lo;
       } else {
+        *reinterpret_cast<f32x4*>(Kf + (size_t)j * KPF + c4 * 4) = kr[it];
+      }
+    }
+  }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[m].x, qf[m].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[m].y, qf[m].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[m].z, qf[m].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[m].w, qf[m].w, acc, 0, 0, 0);
+  for (int it = 0; it < VIT; ++it) {
+    const int e = tid + NT * it, jq = e >> 4, c4 = e & 15;
+    if (4 * jq < NP) {   // uniform per 16-lane group
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x0 = vv[it][0][c], x1 = vv[it][1][c], x2 = vv[it][2][c], x3 = vv[it][3][c];
+        const size_t off = (size_t)(4 * c4 + c) * VP + 4 * jq;
+        if constexpr (F32 && SPLIT) {
+          bf16x4_t hi, lo;
+          split4(make_float4(x0, x1, x2, x3), &hi, &lo);
+          *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(vreg) + off) = hi;
+          *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(vreg + L.v_plane_bytes) + off) = lo;
+        } else if constexpr (F32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(vreg) + off) = (f32x4){x0, x1, x2, x3};
+        } else {
+          *reinterpret_cast<typename Half<T>::v4*>(reinterpret_cast<uint16_t*>(vreg) + off) = Half<T>::cvt(x0, x1, x2, x3);
         }
       }
-      // the table slot of row 4 kg + r is the `e` of lane (4 kg + r): fetch it from that lane
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = __shfl(d.e, 4 * kg + r, 64);
-        if (d.qi >= 0 && e >= 0) terms[d.qi * TP + e] = acc[r];
-      }
-    };
-    for (int it0 = wave; it0 < items; it0 += 2 * NW) {
-      const int it1 = it0 + NW;
-      const bool two = it1 < items;   // wave-uniform
-      float4 tA[4], qA[4], tB[4], qB[4];
-      Item dA, dB;
-      const float *tr, *qr;
-      decode(it0, &tr, &qr, &dA);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { tA[m] = *reinterpret_cast<const float4*>(tr + frag_chan(m)); qA[m] = *reinterpret_cast<const float4*>(qr + frag_chan(m)); }
-      if (two) {
-        decode(it1, &tr, &qr, &dB);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { tB[m] = *reinterpret_cast<const float4*>(tr + frag_chan(m)); qB[m] = *reinterpret_cast<const float4*>(qr + frag_chan(m)); }
-      }
-      consume(tA, qA, dA);
-      if (two) consume(tB, qB, dB);
     }
+  }
+  WN_TICK(2);   // first rel-pos batch, K / V planes written
+  for (int n = 1; n < batches; ++n) {
+    if (n > 1) load_batch(n);
+    consume_batch(n);
   }
   WN_TICK(3);   // rel-pos items
   __syncthreads();   // the ONLY workgroup barrier after the window map: K, V^T and the rel-pos terms are resident
@@ -294,12 +300,61 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
 
   // ---- S^T = K (q / scale)^T: block b = keys 32 b .. 32 b + 31; lane (lr, lh), register r = 4 g + e holds
   //      key 32 b + 8 g + 4 lh + e of query row lr ---------------------------------------------------------------------
+  // Rel-pos terms in split mode (key grids up to 16 x 16): S^T[key][q] += sum_c E[key][c] T[c][q] with T = the query's
+  // (ky | kx) terms (bf16 hi + lo from the LDS table, this lane's B fragments for all blocks) and E the ONE-HOT rows
+  // "c == ky(key)" / "c == 16 + kx(key)" built in registers (exact in bf16): two more k-steps of the score product instead of
+  // two LDS reads, an index division and two adds per score on the VALU (10k of a workgroup's 51k ticks).
+  const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
+  const float* trow = terms + (q_on ? iq : 0) * TP;
+  const bool onehot = SPLIT && rel && a.gh <= 16 && a.gw <= 16;
+  bf16x8_t tyh, tyl, txh, txl;
+  if (onehot) {
+    float ty[8], tx[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int c = 8 * lh + n;
+      ty[n] = trow[min(c, a.gh - 1)];
+      tx[n] = trow[a.gh + min(c, a.gw - 1)];
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int c = 8 * lh + n;
+      ty[n] = c < a.gh ? ty[n] : 0.f;
+      tx[n] = c < a.gw ? tx[n] : 0.f;
+    }
+    bf16x4_t h0, l0, h1, l1;
+    split4(make_float4(ty[0], ty[1], ty[2], ty[3]), &h0, &l0);
+    split4(make_float4(ty[4], ty[5], ty[6], ty[7]), &h1, &l1);
+    tyh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    tyl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    split4(make_float4(tx[0], tx[1], tx[2], tx[3]), &h0, &l0);
+    split4(make_float4(tx[4], tx[5], tx[6], tx[7]), &h1, &l1);
+    txh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    txl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  auto one_hot8 = [&](int pos) __attribute__((always_inline)) {   // bf16 1.0 at element pos (0..7), zeros elsewhere / out of range
+    const uint32_t v = (pos & 1) ? 0x3F800000u : 0x00003F80u;
+    const int w = pos >> 1;   // negative or > 3: no dword matches
+    union { uint4 u; bf16x8_t b; } c;
+    c.u = make_uint4(w == 0 ? v : 0u, w == 1 ? v : 0u, w == 2 ? v : 0u, w == 3 ? v : 0u);
+    return c.b;
+  };
   f32x16 S[MAXB];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[b][r] = 0.f;
     if (b < NB) {
+      if (onehot) {   // wave-uniform
+        const int key = 32 * b + lr;                       // A operand row of this lane
+        const int ky = fast_div(key, inv_gw), kx = key - ky * a.gw;
+        const bool live = key < a.N;
+        const bf16x8_t ey = one_hot8(live ? ky - 8 * lh : -2), ex = one_hot8(live ? kx - 8 * lh : -2);
+        S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ey, tyl, S[b], 0, 0, 0);
+        S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ex, txl, S[b], 0, 0, 0);
+        S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ey, tyh, S[b], 0, 0, 0);
+        S[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ex, txh, S[b], 0, 0, 0);
+      }
       if (SPLIT) {
         const __bf16* kh_row = Khi + (size_t)(32 * b + lr) * KPB + 8 * lh;
         const __bf16* kl_row = Klo + (size_t)(32 * b + lr) * KPB + 8 * lh;
@@ -327,29 +382,33 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
 
   WN_TICK(5);   // q fragments + S^T products
   // ---- softmax of the lane's row (its other half sits in lane ^ 32) -------------------------------------------------------
-  const float inv_gw = rel ? 1.0f / (float)a.gw : 0.f;
-  const float* trow = terms + (q_on ? iq : 0) * TP;
   float mx = -INFINITY;
 #pragma unroll
   for (int b = 0; b < MAXB; ++b)
     if (b < NB) {
+      if (rel && !onehot) {
+        // (attn + rel_h) + rel_w, utils.py:166-168.  The 32 table reads of a block go out together through clamped, branch-free
+        // addresses (first version: a predicated read + wait per score, 194 ticks each -- 36 % of the workgroup's life).
+        float th[16], tw[16];
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int kb = 32 * b + 8 * gq + 4 * lh;
-        int ky = 0, kx = 0;
-        if (rel) { ky = fast_div(kb, inv_gw); kx = kb - ky * a.gw; }
+        for (int r = 0; r < 16; ++r) {
+          const int key = min(32 * b + 8 * (r >> 2) + 4 * lh + (r & 3), a.N - 1);
+          const int ky = fast_div(key, inv_gw), kx = key - ky * a.gw;
+          th[r] = trow[ky];
+          tw[r] = trow[a.gh + kx];
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = S[b][4 * gq + e];
-          if (rel) {
-            if (kb + e < a.N) x = (x + trow[ky]) + trow[a.gh + kx];   // (attn + rel_h) + rel_w, utils.py:166-168
-            if (++kx == a.gw) { kx = 0; ++ky; }
-          }
-          x = kb + e < a.N ? x : -INFINITY;
-          S[b][4 * gq + e] = x;
-          mx = fmaxf(mx, x);
+        for (int r = 0; r < 16; ++r) S[b][r] = (S[b][r] + th[r]) + tw[r];
+      }
+      if (32 * b + 32 > a.N) {   // only the last block has keys past N (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * b + 8 * (r >> 2) + 4 * lh + (r & 3);
+          S[b][r] = key < a.N ? S[b][r] : -INFINITY;
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[b][r]);
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   WN_TICK(6);   // rel-pos adds, masks, row max
@@ -467,11 +526,11 @@ template <typename T>
 void launch_window_t(const DenseArgs& a, int split, hipStream_t s) {
   const size_t lds = win_lds(a.N, a.gh + a.gw, (int)sizeof(T), split != 0).total;
   const int waves = (a.N + 31) / 32;
-  // Eight waves (two per SIMD) cover up to 256 query rows in one workgroup.  When there are too few (group, head) pairs to
-  // fill the chip that way (ViTDet 672^2: 9 windows x 12 heads = 108 on 256 CUs), two 4-wave workgroups share a pair's
-  // query rows -- each stages the pair's K / V itself -- so twice the CUs work, each with one wave per SIMD.
+  // Eight waves (two per SIMD) cover up to 256 query rows in one workgroup; groups of up to 128 tokens need four.  (Splitting a
+  // pair's query rows over two 4-wave workgroups when there are few pairs -- ViTDet 672^2: 108 on 256 CUs -- was measured
+  // slower, 32.0 vs 28.6 us: each workgroup stages the pair's K / V and all rel-pos items itself.  EVT_WINDOW_NW forces a shape.)
   static const int forced = getenv("EVT_WINDOW_NW") ? atoi(getenv("EVT_WINDOW_NW")) : 0;
-  const bool four = forced ? forced == 4 : (waves <= 4 || (int64_t)a.G * a.H * 2 <= (int64_t)evt_cu_count());
+  const bool four = forced ? forced == 4 : waves <= 4;
   if (split) {
     if (four) launch_window_inst<T, true, 4>(a, lds, s); else launch_window_inst<T, true, 8>(a, lds, s);
   } else {

@@ -58,23 +58,23 @@ def test_vivit_end_to_end_graph_replay_is_bit_identical(golden_dir):
     with torch.inference_mode():
         model.use_frame_graphs(0)                       # eager steps
         want = [model(c).clone() for c in clips]
+        want2, want3 = model(torch.cat(clips[:2])).clone(), model(torch.cat(clips)).clone()   # (other batch sizes run other tile shapes)
         for lanes in (1, 3, None):                      # None: the default, automatic mode (graphs at <= 2 view streams)
             model.use_frame_graphs(lanes)
             got = [model(c).clone() for c in clips]
             for w_, g_ in zip(want, got):
                 assert torch.equal(w_, g_), (lanes, float((w_ - g_).abs().max()))
             assert len(model._frames) == 1
-        # Automatic mode: a call with more than 2 view streams (two clips = 4 streams) takes the eager steps, and batch 1 then
-        # returns to its cached graphs.
-        both = model(torch.cat(clips[:2]))
-        assert torch.equal(both, torch.cat(want[:2])), float((both - torch.cat(want[:2])).abs().max())
+        # Automatic mode: a call with more than 2 view streams (two clips = 4 streams) takes the eager steps -- which reset the
+        # model and drop its weight-plane caches -- and batch 1 then returns to its cached graphs (which keep theirs alive).
+        assert torch.equal(model(torch.cat(clips[:2])), want2)
         assert len(model._frames) == 1 and torch.equal(model(clips[2]), want[2])
         # Forced graph mode: a call with another batch size must not trip over the captured shape -- every step-input shape gets
         # its own FrameGraphs, the two most recently used are kept.
         model.use_frame_graphs(3)
         assert torch.equal(model(clips[0]), want[0])
-        assert torch.equal(model(torch.cat(clips[:2])), torch.cat(want[:2])) and len(model._frames) == 2
-        assert torch.equal(model(torch.cat(clips)), torch.cat(want)) and len(model._frames) == 2
+        assert torch.equal(model(torch.cat(clips[:2])), want2) and len(model._frames) == 2
+        assert torch.equal(model(torch.cat(clips)), want3) and len(model._frames) == 2
         assert torch.equal(model(clips[1]), want[1])
         model.use_frame_graphs(0)
         assert torch.equal(model(clips[0]), want[0]) and not model._frames
