@@ -13,9 +13,6 @@ struct LinArgs {
   int a_planes, out_planes;
   // evt_linear_big.hip only: A is ONE bf16 plane (row pitch lda elements) of exactly bf16-representable values (ABI 4: a_bf16)
   int a_bf16;
-  // evt_linear_big.hip only (ABI 6, with a_planes): the third bf16 plane of the activations (row pitch lda elements), lo2 =
-  // a - hi - lo, from evt_row_pass_split: the gate reference is refreshed with hi + lo + lo2 = the exact fp32 activation
-  const uint16_t* a_lo2;
   // evt_linear_small.hip only (ABI 5): the gate's token selection runs INSIDE the launch -- every workgroup selects for the
   // clip(s) of its rows from the delta norms; a_idx / o_idx only say which sides are indexed, the list is sel_idx
   const float* sel_norms; int sel_parts, sel_N, sel_k, sel_mode; float sel_thr;

@@ -755,13 +755,6 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
                 "evt_gated_linear: this launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select): "
                 "B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
   }
-  if (d->a_lo2 != nullptr) {
-    a.a_planes = 1;
-    a.a_lo2 = reinterpret_cast<const uint16_t*>(d->a_lo2);
-    EVT_REQUIRE(!d->a_bf16 && d->sel_norms == nullptr && d->lda == d->K && (d->K & 31) == 0 && forced_tile_variant() < 0 && evt_big_choice(a) != 0,
-                EVT_ERR_BAD_SHAPE, "evt_gated_linear: split activations (a_lo2) only on the persistent 256-row kernel with lda == K, K %% 32 == 0 "
-                "(query evt_gated_linear_big_tile first): B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
-  }
   if (d->a_bf16) {
     a.a_bf16 = 1;
     EVT_REQUIRE(d->act == EVT_ACT_NONE && forced_tile_variant() < 0 && evt_big_choice(a) != 0, EVT_ERR_BAD_SHAPE,
@@ -785,10 +778,6 @@ extern "C" int evt_gated_linear_big_tile(const evt_linear_desc* d) {
   if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || forced_tile_variant() >= 0) return 0;
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
-  if (d->a_lo2 != nullptr) {   // split activations: whole hl32 lines per row
-    if (d->lda != d->K || (d->K & 31) != 0) return 0;
-    a.a_planes = 1;
-  }
   return evt_big_choice(a);
 }
 
@@ -818,13 +807,6 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
     if (rc_sel != EVT_OK) return rc_sel;
     EVT_REQUIRE(d->idx != nullptr && forced_tile_variant() < 0 && evt_small_accepts(fc1), EVT_ERR_BAD_SHAPE,
                 "evt_gated_mlp: the first launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select)");
-  }
-  if (d->a_lo2 != nullptr) {   // the gate input as three bf16 planes (evt_row_pass_split)
-    fc1.a_planes = 1;
-    fc1.a_lo2 = reinterpret_cast<const uint16_t*>(d->a_lo2);
-    EVT_REQUIRE(d->sel_norms == nullptr && d->lda == d->D && (d->D & 31) == 0 && (d->Dh & 31) == 0 && fc1.Wsplit != nullptr && forced_tile_variant() < 0 &&
-                evt_big_choice(fc1) != 0 && evt_big_choice(fc2) != 0, EVT_ERR_BAD_SHAPE,
-                "evt_gated_mlp: split activations (a_lo2) need both launches on the persistent 256-row kernel, lda == D, D and Dh %% 32 == 0");
   }
   // Both launches on the 256-row kernel: the hidden scratch holds hl32 lines (same bytes as fp32) -- GELU(x) is split once,
   // in the first launch's epilogue, and the second launch stages it without conversion.

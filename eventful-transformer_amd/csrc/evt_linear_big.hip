@@ -54,16 +54,11 @@ __device__ unsigned long long evt_prof_buf[2][8];
 // bytes of the fp32 row it replaces); staging is then a plain 16-byte copy, no conversion.  FMT bit 1 (OPL): the output is
 // written as hl32 lines instead of fp32 (same bytes).  evt_gated_mlp uses both for its hidden scratch: the first launch's
 // epilogue splits GELU(x) once per element instead of the second launch splitting it once per column tile in its k loop.
-// FMT bit 3 (AL2, with APL): a third bf16 plane, lo2 = a - hi - lo (evt_row_pass_split), rides along -- 8 bytes per staged
-// row and k-tile, fetched with the tile -- so that the gate reference can be refreshed with hi + lo + lo2, the EXACT fp32 gate
-// input (p[idx] = c[idx], modules.py:151): the QKV and MLP-1 launches then stage their activations without conversion like
-// the MLP's second launch does (the 48 conversion VALU per k-tile were what kept them off the ping-pong schedule).
 template <int ACT, int TBM, int TBN, int WM, int WN, int DEPTH, int FMT>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel(const LinArgs g, int tiles_n, int tiles_total) {
   constexpr int NT = WM * WN * 64, TBK = 32;
-  constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0, ABF = (FMT & 4) != 0, AL2 = (FMT & 8) != 0;
+  constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0, ABF = (FMT & 4) != 0;
   static_assert(!(APL && ABF), "one activation format");
-  static_assert(!AL2 || APL, "the lo2 plane belongs to pre-split activations");
   constexpr int MI = TBM / WM / 32, NJ = TBN / WN / 32;   // 32x32 accumulators per wave: MI x NJ
   // Ping-pong pacing (pre-split activations only): TWO barriers per k-tile, the multiply-first group running one barrier
   // interval behind, so that on every SIMD one wave multiplies ALONE (all of its fragment reads requested up front) while its
@@ -128,7 +123,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   int m0_s = 0;                // first row of the tile being staged
   uint32_t w_off[WJ];          // this thread's 16 bytes of the weight rows' hl32 lines (rows clamped past Nout)
   const char* const Abase = reinterpret_cast<const char*>(g.A);
-  const char* const L2base = reinterpret_cast<const char*>(g.a_lo2);
   const char* const Wbase = reinterpret_cast<const char*>(g.Wsplit);
   char* const Pbase = reinterpret_cast<char*>(g.p_upd);
   int bn_s = 0;                // column tile of the tile being staged (p refresh hand-out)
@@ -183,11 +177,9 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
   // Two sets of staging registers (stream elements of even / odd parity): the loads of element x + 2 are issued as soon as
   // element x has been written to LDS, so a load has TWO iterations to arrive.  (With one set the loop could not turn
   // faster than one load latency + one staging per iteration: ~1.4 us, more than the iteration's MFMA time.)
-  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
   struct Regs {   // (named weight registers: hipcc left an array of them in scratch)
     f32x4 a[AJ];   // (native vector type: arrays of HIP's float4 / uint4 structs were left in scratch)
     u32x4_t w0, w1, w2, w3;
-    u32x2_t l2[AL2 ? AJ : 1];   // AL2: lo2 values 4 ac4 .. 4 ac4 + 3 of the k-tile, per staged row
   };
   Regs R0, R1;
   auto fetch = [&](Regs& R, int kt) __attribute__((always_inline)) {   // k-tile kt of the load-side tile -> registers (K % 32 == 0: whole tiles only)
@@ -198,12 +190,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     if (WJ > 3) R.w3 = *reinterpret_cast<const u32x4_t*>(Wbase + (w_off[WJ > 3 ? 3 : 0] + kw));
 #pragma unroll
     for (int j = 0; j < AJ; ++j) R.a[j] = *reinterpret_cast<const f32x4*>(Abase + (a_off[j] + ka));
-    if (AL2) {   // row byte offset in the lo2 plane = half the hl32 row's (a_off / 2 = that + 8 ac4); lane c < 4 takes the k-tile's
-                 // bytes 16 c .. + 8, lane c + 4 the bytes 16 c + 8 .. + 8 (see the refresh in `stage`)
-      const uint32_t l2adj = (uint32_t)(ac4 < 4 ? 8 * ac4 : 8 * ac4 - 56);   // 16 c - 8 ac4, 16 (ac4 - 4) + 8 - 8 ac4
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) R.l2[j] = *reinterpret_cast<const u32x2_t*>(L2base + ((a_off[j] >> 1) + (uint32_t)kt * 64u + l2adj));
-    }
   };
   // stage side: the element written to LDS lags the load side by two elements, so it keeps its own tile description
   uint32_t st_off[AJ];
@@ -246,39 +232,6 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gated_linear_split_big_kernel
     if (WJ > 1) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + WROWS, wc8)) = R.w1;
     if (WJ > 2) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 2 * WROWS, wc8)) = R.w2;
     if (WJ > 3) *reinterpret_cast<u32x4_t*>(Bpl + lds_off(wr0 + 3 * WROWS, wc8)) = R.w3;
-    if (AL2 && do_upd && st_k == st_upd) {
-      // Refresh from the three planes.  The 8 lanes of a row hold its 128-byte hl32 line: lane c < 4 the hi values 8 c .. 8 c + 7,
-      // lane c + 4 the lo values of the same k; lane c has loaded lo2 8 c .. 8 c + 3, lane c + 4 lo2 8 c + 4 .. 8 c + 7.  Lane
-      // c < 4 pulls its partner's six dwords over the DPP network (row_shl:4, no LDS crossbar) and writes the 8 fp32 values
-      // (hi + lo) + lo2 -- exact -- as 32 consecutive bytes of the reference row.
-      st_upd += tiles_n;
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        union { f32x4 v; uint32_t u[4]; } in;
-        in.v = R.a[j];
-        uint32_t lo[4], m[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lo[q] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)in.u[q], 0x104, 0xf, 0xf, false);   // row_shl:4
-        m[0] = R.l2[j].x;
-        m[1] = R.l2[j].y;
-        m[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R.l2[j].x, 0x104, 0xf, 0xf, false);
-        m[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R.l2[j].y, 0x104, 0xf, 0xf, false);
-        f32x4 p0, p1;
-        p0.x = (__uint_as_float(in.u[0] << 16) + __uint_as_float(lo[0] << 16)) + __uint_as_float(m[0] << 16);
-        p0.y = (__uint_as_float(in.u[0] & 0xffff0000u) + __uint_as_float(lo[0] & 0xffff0000u)) + __uint_as_float(m[0] & 0xffff0000u);
-        p0.z = (__uint_as_float(in.u[1] << 16) + __uint_as_float(lo[1] << 16)) + __uint_as_float(m[1] << 16);
-        p0.w = (__uint_as_float(in.u[1] & 0xffff0000u) + __uint_as_float(lo[1] & 0xffff0000u)) + __uint_as_float(m[1] & 0xffff0000u);
-        p1.x = (__uint_as_float(in.u[2] << 16) + __uint_as_float(lo[2] << 16)) + __uint_as_float(m[2] << 16);
-        p1.y = (__uint_as_float(in.u[2] & 0xffff0000u) + __uint_as_float(lo[2] & 0xffff0000u)) + __uint_as_float(m[2] & 0xffff0000u);
-        p1.z = (__uint_as_float(in.u[3] << 16) + __uint_as_float(lo[3] << 16)) + __uint_as_float(m[3] << 16);
-        p1.w = (__uint_as_float(in.u[3] & 0xffff0000u) + __uint_as_float(lo[3] & 0xffff0000u)) + __uint_as_float(m[3] & 0xffff0000u);
-        if (ac4 < 4 && st_m0 + ar0 + AROWS * j < M) {
-          char* dst = Pbase + (st_off[j] + (uint32_t)st_k * (TBK * 4u) + 16u * (uint32_t)ac4);
-          *reinterpret_cast<f32x4*>(dst) = p0;
-          *reinterpret_cast<f32x4*>(dst + 16) = p1;
-        }
-      }
-    }
     if (!APL && do_upd && st_k == st_upd) {   // k-tiles st_bn, st_bn + tiles_n, ... (a counter: the modulo cost 14 scalar instructions per k-tile)
       st_upd += tiles_n;
 #pragma unroll
@@ -562,13 +515,7 @@ void launch_big_cfg(const LinArgs& a, hipStream_t s) {
   const dim3 grid(std::min(tiles_m * tiles_n, evt_cu_count()));   // persistent: one workgroup per CU
   const int tt = tiles_m * tiles_n;
   // formats in use: fp32 -> fp32 (any activation), fp32 -> hl32 with GELU (first half of the MLP), hl32 -> fp32 (second half)
-  static const bool no_l2 = getenv("EVT_PLANES_NO_L2") != nullptr;   // timing experiment: no lo2 plane, no reference refresh (results: stale p)
   if (a.a_bf16) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 4>(a, s, grid, tiles_n, tt);
-  else if (a.a_planes && a.a_lo2 != nullptr && no_l2 && a.out_planes) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, 1, 1 | 2>(a, s, grid, tiles_n, tt);
-  else if (a.a_planes && a.a_lo2 != nullptr && no_l2) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1>(a, s, grid, tiles_n, tt);
-  else if (a.a_planes && a.a_lo2 != nullptr && a.out_planes) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, 1, 1 | 2 | 8>(a, s, grid, tiles_n, tt);   // MLP-1 from evt_row_pass_split planes
-  else if (a.a_planes && a.a_lo2 != nullptr && a.act == EVT_ACT_GELU_ERF) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, 1, 1 | 8>(a, s, grid, tiles_n, tt);
-  else if (a.a_planes && a.a_lo2 != nullptr) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1 | 8>(a, s, grid, tiles_n, tt);   // QKV from planes
   else if (a.a_planes) launch_big_one<EVT_ACT_NONE, TBM, TBN, WM, WN, 1, 1>(a, s, grid, tiles_n, tt);   // (one register set: room for both fragment sets)
   else if (a.out_planes) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 2>(a, s, grid, tiles_n, tt);
   else if (a.act == EVT_ACT_GELU_ERF) launch_big_one<EVT_ACT_GELU_ERF, TBM, TBN, WM, WN, DEPTH, 0>(a, s, grid, tiles_n, tt);
@@ -602,8 +549,6 @@ int evt_big_choice(const LinArgs& a) {
     const int tiles = tiles_m * (a.Nout / tbn), rounds = (tiles + cus - 1) / cus;
     return tiles >= cus && tiles * 100 >= rounds * cus * 85;
   };
-  // pre-split activations: the 64x96 wave tile of 256x192 leaves registers for the ping-pong schedule (the 64x128 one does not)
-  if (a.a_planes && fills(192)) return 4;
   if (fills(256)) return 2;
   if (fills(192)) return 4;
   return 0;

@@ -4,38 +4,16 @@
 // Layout: one 64-lane wavefront owns one token row; lanes read float4 at stride 64 so every
 // wave-instruction moves 1 KiB contiguous.  No LDS: the row lives in registers between the
 // statistics pass and the normalise / norm pass, so each input byte is read from HBM exactly once.
-#include "evt_linear.h"   // split4, hl32 layout
+#include "evt_common.h"
 
 namespace {
-
-// c = hi + lo + lo2 EXACTLY (three bf16 values hold the 24 mantissa bits of an fp32 value; denormal remainders aside):
-// hi = rne_bf16(c), lo = rne_bf16(c - hi), lo2 = (c - hi) - lo.  hi | lo are the operands of the split-precision gated
-// linears (pre-split: the GEMM stages them without conversion), lo2 lets the GEMM refresh the gate reference with the exact
-// fp32 gate input (p[idx] = c[idx], modules.py:151).
-__device__ __forceinline__ void split3(const float4 v, bf16x4_t* hi, bf16x4_t* lo, bf16x4_t* lo2) {
-  split4(v, hi, lo);
-  union { bf16x4_t b; uint2 u; } H, L;
-  H.b = *hi;
-  L.b = *lo;
-  const float r0 = (v.x - __uint_as_float(H.u.x << 16)) - __uint_as_float(L.u.x << 16);
-  const float r1 = (v.y - __uint_as_float(H.u.x & 0xffff0000u)) - __uint_as_float(L.u.x & 0xffff0000u);
-  const float r2 = (v.z - __uint_as_float(H.u.y << 16)) - __uint_as_float(L.u.y << 16);
-  const float r3 = (v.w - __uint_as_float(H.u.y & 0xffff0000u)) - __uint_as_float(L.u.y & 0xffff0000u);
-  union { bf16x2_t b; uint32_t u; } a, b;
-  a.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
-  b.b = __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t);
-  union { uint2 u; bf16x4_t b; } R;
-  R.u = make_uint2(a.u, b.u);
-  *lo2 = R.b;
-}
 
 template <int NV>
 __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        int res_rows, float* __restrict__ sum_out, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, float eps,
                                                        float* __restrict__ c_out, const float* __restrict__ p,
-                                                       float* __restrict__ norms, int rows, int D,
-                                                       __bf16* __restrict__ c_planes, __bf16* __restrict__ c_lo2) {
+                                                       float* __restrict__ norms, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -101,18 +79,6 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (lane + i * 64 < nvec) *reinterpret_cast<float4*>(c_out + base + cc[i]) = v[i];
-  }
-  if (c_planes != nullptr) {   // the gate input as hl32 lines (hi | lo, row pitch 2 D bf16 = the fp32 row's bytes) + the lo2 plane
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (lane + i * 64 < nvec) {
-        bf16x4_t hi, lo, lo2;
-        split3(v[i], &hi, &lo, &lo2);
-        __bf16* line = c_planes + 2 * base + hl32_hi(cc[i]);
-        *reinterpret_cast<bf16x4_t*>(line) = hi;
-        *reinterpret_cast<bf16x4_t*>(line + 32) = lo;
-        *reinterpret_cast<bf16x4_t*>(c_lo2 + base + cc[i]) = lo2;
-      }
   }
   if (want_norm) {
     float q = 0.f;
@@ -184,8 +150,7 @@ extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, floa
   const dim3 grid((rows + 3) / 4), block(256);
   const int need = (D / 4 + 63) / 64;
   hipStream_t s = evt_stream(stream);
-#define LAUNCH(NV) hipLaunchKernelGGL(row_pass_kernel<NV>, grid, block, 0, s, x, res, res_rows, sum_out, ln_w, ln_b, eps, c_out, p, norms, rows, D, \
-                                      (__bf16*)nullptr, (__bf16*)nullptr)
+#define LAUNCH(NV) hipLaunchKernelGGL(row_pass_kernel<NV>, grid, block, 0, s, x, res, res_rows, sum_out, ln_w, ln_b, eps, c_out, p, norms, rows, D)
   if (need <= 1) LAUNCH(1);
   else if (need <= 2) LAUNCH(2);
   else if (need <= 3) LAUNCH(3);
@@ -194,31 +159,6 @@ extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, floa
   else LAUNCH(16);
 #undef LAUNCH
   return evt_check_launch("evt_row_pass");
-}
-
-extern "C" int evt_row_pass_split(const float* x, const float* res, int res_rows, float* sum_out, const float* ln_w,
-                                  const float* ln_b, float eps, void* c_planes, void* c_lo2, const float* p, float* norms,
-                                  int rows, int D, void* stream) {
-  EVT_REQUIRE(x != nullptr && c_planes != nullptr && c_lo2 != nullptr, EVT_ERR_BAD_ARG, "evt_row_pass_split: null x / c_planes / c_lo2");
-  EVT_REQUIRE(rows >= 0 && D > 0, EVT_ERR_BAD_ARG, "evt_row_pass_split: rows=%d D=%d", rows, D);
-  EVT_REQUIRE((D & 31) == 0 && D <= 4096, EVT_ERR_BAD_SHAPE, "evt_row_pass_split: D=%d must be a multiple of 32 (whole hl32 lines) and <= 4096", D);
-  EVT_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), EVT_ERR_BAD_ARG, "evt_row_pass_split: ln_w and ln_b must come together");
-  EVT_REQUIRE(p == nullptr || norms != nullptr, EVT_ERR_BAD_ARG, "evt_row_pass_split: p given without norms");
-  EVT_REQUIRE(res_rows >= 0, EVT_ERR_BAD_ARG, "evt_row_pass_split: res_rows=%d", res_rows);
-  if (rows == 0) return EVT_OK;
-  const dim3 grid((rows + 3) / 4), block(256);
-  const int need = (D / 4 + 63) / 64;
-  hipStream_t s = evt_stream(stream);
-#define LAUNCH(NV) hipLaunchKernelGGL(row_pass_kernel<NV>, grid, block, 0, s, x, res, res_rows, sum_out, ln_w, ln_b, eps, (float*)nullptr, p, norms, rows, D, \
-                                      reinterpret_cast<__bf16*>(c_planes), reinterpret_cast<__bf16*>(c_lo2))
-  if (need <= 1) LAUNCH(1);
-  else if (need <= 2) LAUNCH(2);
-  else if (need <= 3) LAUNCH(3);
-  else if (need <= 4) LAUNCH(4);
-  else if (need <= 8) LAUNCH(8);
-  else LAUNCH(16);
-#undef LAUNCH
-  return evt_check_launch("evt_row_pass_split");
 }
 
 extern "C" int evt_gate_gather_update(const float* c, float* p, const int32_t* idx, const int32_t* count, int B, int N,

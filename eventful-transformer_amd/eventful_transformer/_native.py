@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_row_pass_split",
+    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes",
 )
 
 
@@ -39,7 +39,6 @@ class LinearDesc(Structure):
         ("W_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64), ("a_bf16", c_int32),
         ("sel_norms", c_void_p), ("sel_parts", c_int32), ("sel_N", c_int32), ("sel_k", c_int32), ("sel_mode", c_int32),
         ("sel_thr", c_float), ("sel_idx", c_void_p), ("sel_count", c_void_p), ("sel_rest", c_void_p),
-        ("a_lo2", c_void_p),
     ]
 
 
@@ -52,7 +51,6 @@ class MlpDesc(Structure):
         ("W1_split", c_void_p), ("W2_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("sel_norms", c_void_p), ("sel_parts", c_int32), ("sel_N", c_int32), ("sel_k", c_int32), ("sel_mode", c_int32),
         ("sel_thr", c_float), ("sel_idx", c_void_p), ("sel_count", c_void_p), ("sel_rest", c_void_p),
-        ("a_lo2", c_void_p),
     ]
 
 
@@ -137,7 +135,6 @@ def _bind(lib):
     lib.evt_attention_stream_lds_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
-        "evt_row_pass_split": [P, P, I, P, P, P, F, P, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
         "evt_select_threshold": [P, I, I, F, I, P, P, P, P],
         "evt_select_topk_sq": [P, I, I, I, I, P, P, P],
@@ -289,17 +286,6 @@ def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=Non
                                _p(norms), rows, D, _stream()))
 
 
-# Gate input as three bf16 planes (evt_row_pass_split): the QKV and MLP-1 launches on the persistent 256-row kernel then stage
-# their activations without conversion (ping-pong schedule) and refresh the gate reference exactly.  EVT_SPLIT_GATE_INPUT=0: fp32.
-SPLIT_GATE_INPUT = os.environ.get("EVT_SPLIT_GATE_INPUT", "0") != "0"
-
-
-def row_pass_split(x, rows, D, c_planes, c_lo2, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=None, eps=1e-6, p=None, norms=None):
-    """evt_row_pass with the gate input written as hl32 lines (c_planes: (rows, 2 D) bf16) + the lo2 plane (c_lo2: (rows, D) bf16)."""
-    _check(load().evt_row_pass_split(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_planes), _p(c_lo2), _p(p),
-                                     _p(norms), rows, D, _stream()))
-
-
 def select_topk(norms, B, N, k, idx, rest=None, parts=0):
     """parts > 0: `norms` is (B, N, parts) partial sums of squares (evt_softmax_av_gated norm_parts)."""
     if parts:
@@ -399,14 +385,13 @@ def _splitk_workspace(device, has_count, *shapes):
     return scratch("splitk_ws", (need // 4,), torch.float32, device), need
 
 
-def gated_linear_big_tile(lda, gathered, a_rows, ldo, scattered, o_rows, has_count, B, kcap, K, Nout, has_split=True, planes=False):
+def gated_linear_big_tile(lda, gathered, a_rows, ldo, scattered, o_rows, has_count, B, kcap, K, Nout, has_split=True):
     """Tile configuration of the persistent 256-row kernel a launch of this shape runs on (0: the 128x128 kernel): the
-    launches that accept bf16 activations (`a_bf16`) or -- `planes` -- split activations (`a_lo2`).  Shape-only -- the
-    descriptor's pointers are only compared with NULL."""
+    launches that accept bf16 activations (`a_bf16`).  Shape-only -- the descriptor's pointers are only compared with NULL."""
     one = ctypes.c_void_p(1)
     d = LinearDesc(one, lda, one if gathered else None, a_rows, one, one, one, ldo, one if scattered else None, o_rows,
                    one if has_count else None, None, B, kcap, K, Nout, ACT_NONE, one if has_split else None, None, 0, 0,
-                   *_sel_fields(None), one if planes else None)
+                   *_sel_fields(None))
     return int(load().evt_gated_linear_big_tile(ctypes.byref(d)))
 
 
@@ -431,29 +416,28 @@ def embeds_select(lda, a_rows, ldo, scattered, o_rows, counted, B, kcap, K, Nout
         return False
     one = ctypes.c_void_p(1)
     d = LinearDesc(one, lda, one, a_rows, one, one, one, ldo, one if scattered else None, o_rows, one if counted else None, None,
-                   B, kcap, K, Nout, ACT_NONE, one, None, 1 << 40, 0, None, 0, N, 0, 1 if counted else 0, 0.0, None, None, None, None)
+                   B, kcap, K, Nout, ACT_NONE, one, None, 1 << 40, 0, None, 0, N, 0, 1 if counted else 0, 0.0, None, None, None)
     return bool(load().evt_gated_linear_embeds_select(ctypes.byref(d)))
 
 
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
-                 W_split=None, a_bf16=False, select=None, a_lo2=None):
+                 W_split=None, a_bf16=False, select=None):
     """a_bf16: A is a bfloat16 tensor of exactly representable activations (the A.v state; see evt_abi.h).
-    select: the gate's token selection runs inside the launch (see _sel_fields / embeds_select).
-    a_lo2: A holds hl32 lines and a_lo2 the third plane (row_pass_split)."""
+    select: the gate's token selection runs inside the launch (see _sel_fields / embeds_select)."""
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
-                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16), *_sel_fields(select), _p(a_lo2))
+                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16), *_sel_fields(select))
     _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
-              W2_split=None, select=None, a_lo2=None):
+              W2_split=None, select=None):
     s1, s2 = W1_split, W2_split
     if s1 is None or s2 is None:
         s1 = s2 = None
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
-                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes, *_sel_fields(select), _p(a_lo2))
+                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes, *_sel_fields(select))
     _timed("gemm", 4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
 
 

@@ -397,7 +397,6 @@ class EventfulTokenwiseBlock(Block):
         self.mlp_accumulator = TokenBuffer()
         self._wants_rest = False   # set by subclasses that keep a q.k^T product state
         self._rest = None
-        self._split_in_cache = {}
 
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
@@ -489,7 +488,7 @@ class EventfulTokenwiseBlock(Block):
             linear_fn(c, idx, count, buffer.b, None, B, cap)
         else:
             parts = 0
-            src16 = lo2 = None
+            src16 = None
             if ln is None and res is None:
                 c = src  # the gate input already exists in HBM: only the norms are new
                 src16 = state_src
@@ -498,28 +497,17 @@ class EventfulTokenwiseBlock(Block):
                 else:
                     _native.row_pass(src, rows, D, p=gate.p, norms=norms)
             else:
-                if self._split_gate_input(gate, tag, B, N, out_features, stgt):
-                    # the gate input as three bf16 planes: the consuming launch stages hi | lo without converting, and rebuilds
-                    # the exact fp32 row for the reference from hi + lo + lo2
-                    c = self._ws("gate_in_planes", (B, N, 2 * D), torch.bfloat16, src)
-                    lo2 = self._ws("gate_in_lo2", (B, N, D), torch.bfloat16, src)
-                    _native.row_pass_split(src, rows, D, c, lo2, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS,
-                                           p=gate.p, norms=norms)
-                else:
-                    _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
-                                     p=gate.p, norms=norms)
+                _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
+                                 p=gate.p, norms=norms)
             # (K, Nout of the consuming launch, ldo, scattered, o_rows): the MLP's first launch writes a compact hidden scratch
             embed_for = None
-            if src16 is None and lo2 is None:
+            if src16 is None:
                 Dh = self.mlp_1.out_features
                 embed_for = (D, Dh, Dh, False, policy_cap(gate, N)) if tag == "mlp" else (D, out_features, out_features, True, N)
             idx, count, cap, select = self._select(gate, c, norms, B, N, tag, parts=parts, embed_for=embed_for)
             if src16 is not None:   # the fp32 attention output was not written: the projection reads the bf16 A.v state
                 assert parts and count is None and not stgt
                 linear_fn(src16, idx, count, buffer.b, gate.p, B, cap, a_bf16=True)
-            elif lo2 is not None:
-                assert count is None and select is None
-                linear_fn(c, idx, count, buffer.b, gate.p, B, cap, a_lo2=lo2)
             else:
                 linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap, **(dict(select=select) if select is not None else {}))
                 if select is not None and INDEX_TAP is not None:
@@ -528,49 +516,23 @@ class EventfulTokenwiseBlock(Block):
                 _native.row_pass(c, rows, D, c_out=gate.p)
         return buffer.b, idx, count, cap
 
-    def _split_gate_input(self, gate, tag, B, N, out_features, stgt):
-        """True when the gate group `tag` (qkv / mlp) of a gated frame should write its gate input as three bf16 planes
-        (evt_row_pass_split): split arithmetic, a top-k norm policy (fixed count), and the consuming launch(es) on the
-        persistent 256-row kernel -- which alone takes split activations.  Cached per (tag, batch, count, tokens)."""
-        if not (_native.SPLIT_GATE_INPUT and _native.GEMM_MODE == "split") or stgt or self.gate_before_ln or _native.EMBED_SELECT:
-            return False
-        policy = gate.policy
-        if not isinstance(policy, _NormPolicy) or policy.fixed_count(N) is None:
-            return False
-        cap, D = policy.capacity(N), self.dim
-        key = (tag, B, cap, N, _native.GEMM_MODE)
-        hit = self._split_in_cache.get(key)
-        if hit is None:
-            hit = False
-            if cap > 0 and D % 32 == 0:
-                if tag == "qkv" and self.qkv.split_planes() is not None:
-                    hit = _native.gated_linear_big_tile(D, True, N, out_features, True, N, False, B, cap, D, out_features, planes=True) != 0
-                elif tag == "mlp" and self.mlp_1.split_planes() is not None and self.mlp_2.split_planes() is not None:
-                    Dh = self.mlp_1.out_features
-                    hit = (Dh % 32 == 0 and
-                           _native.gated_linear_big_tile(D, True, N, Dh, False, cap, False, B, cap, D, Dh, planes=True) != 0 and
-                           _native.gated_linear_big_tile(Dh, False, cap, D, True, N, False, B, cap, Dh, D, planes=True) != 0)
-            self._split_in_cache[key] = hit
-        return hit
-
     def _linear_fn(self, layer):
-        def run(a, idx, count, out, p_upd, B, cap, a_bf16=False, select=None, a_lo2=None):
+        def run(a, idx, count, out, p_upd, B, cap, a_bf16=False, select=None):
             N = out.shape[1]
             _native.gated_linear(a, layer.in_features, idx, N if idx is not None else cap, layer.weight, layer.bias,
                                  out, layer.out_features, idx, N if idx is not None else cap, count, p_upd, B, cap,
-                                 layer.in_features, layer.out_features, W_split=layer.split_planes(), a_bf16=a_bf16, select=select,
-                                 a_lo2=a_lo2)
+                                 layer.in_features, layer.out_features, W_split=layer.split_planes(), a_bf16=a_bf16, select=select)
             if layer.count_mode:
                 layer.count_rows(self._n_rows(B, cap, count))
         return run
 
-    def _mlp_fn(self, a, idx, count, out, p_upd, B, cap, select=None, a_lo2=None):
+    def _mlp_fn(self, a, idx, count, out, p_upd, B, cap, select=None):
         N = out.shape[1]
         D, Dh = self.dim, self.mlp_1.out_features
         hidden = self._ws("mlp_hidden", (B * cap, Dh), torch.float32, a)
         _native.gated_mlp(a, D, idx, N if idx is not None else cap, self.mlp_1.weight, self.mlp_1.bias,
                           self.mlp_2.weight, self.mlp_2.bias, hidden, out, D, count, p_upd, B, cap, D, Dh,
-                          W1_split=self.mlp_1.split_planes(), W2_split=self.mlp_2.split_planes(), select=select, a_lo2=a_lo2)
+                          W1_split=self.mlp_1.split_planes(), W2_split=self.mlp_2.split_planes(), select=select)
         if self.mlp_1.count_mode:
             n = self._n_rows(B, cap, count)
             self.mlp_1.count_rows(n)

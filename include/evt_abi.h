@@ -39,9 +39,7 @@ extern "C" {
                                     argument of evt_rel_terms, embedded selection (sel_* fields of evt_linear_desc /
                                     evt_mlp_desc, evt_gated_linear_embeds_select);
                                  6: evt_attention_stream_lds_bytes (shape-only query; evt_attention_stream now answers
-                                    EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS),
-                                    evt_row_pass_split + evt_linear_desc.a_lo2 / evt_mlp_desc.a_lo2 (gate input as three bf16
-                                    planes: pre-split activations for the gated linears, exact reference refresh) */
+                                    EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -82,15 +80,6 @@ EVT_API const char* evt_target_arch(void);
 EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* sum_out,
                          const float* ln_w, const float* ln_b, float eps, float* c_out,
                          const float* p, float* norms, int rows, int D, void* stream);
-/* ABI 6.  The same pass with the gate input c written as THREE bf16 planes instead of fp32: c_planes = hl32 lines (per row and
- * 32 features [32 hi | 32 lo], the row's 4 D bytes) with hi = rne_bf16(c), lo = rne_bf16(c - hi), and c_lo2 (rows, D) bf16 with
- * lo2 = c - hi - lo, so that hi + lo + lo2 == c exactly (24 mantissa bits in three times 8; denormal remainders aside).
- * hi | lo are what the split-precision gated linear multiplies (evt_linear_desc.a_lo2): it then stages its activations without
- * converting them in its inner loop, and rebuilds the exact fp32 row for the gate reference (p[idx] = c[idx], modules.py:151)
- * from the three planes.  6 bytes per element written instead of 4.  D % 32 == 0. */
-EVT_API int evt_row_pass_split(const float* x, const float* res, int res_rows, float* sum_out,
-                               const float* ln_w, const float* ln_b, float eps, void* c_planes, void* c_lo2,
-                               const float* p, float* norms, int rows, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K1  Token selection from per-token delta norms.  One workgroup per clip; norms staged in LDS;
@@ -172,12 +161,6 @@ typedef struct evt_linear_desc {
   /* a_idx / o_idx / idx / count are then only flags (which sides are indexed; count for the finish pass).            */
   const float* sel_norms; int32_t sel_parts, sel_N, sel_k, sel_mode; float sel_thr;
   int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
-  /* ABI 6 -- activations already SPLIT (evt_row_pass_split): a_lo2 != NULL says A holds hl32 lines (per row and 32 features  */
-  /* one 128-byte line [32 bf16 hi | 32 bf16 lo], row pitch lda * 4 bytes like the fp32 row it replaces; lda == K, K % 32 == 0) */
-  /* and a_lo2 the third bf16 plane (row pitch lda elements), lo2 = a - hi - lo.  The kernel stages the lines without         */
-  /* conversion (ping-pong schedule) and refreshes p_upd with (hi + lo) + lo2 = the exact fp32 activation.  Only launches for  */
-  /* which evt_gated_linear_big_tile() != 0 (queried with a_lo2 set) accept it.                                               */
-  const void* a_lo2;
 } evt_linear_desc;
 
 EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
@@ -239,8 +222,6 @@ typedef struct evt_mlp_desc {
   /* a_idx / o_idx / idx / count are then only flags (which sides are indexed; count for the finish pass).            */
   const float* sel_norms; int32_t sel_parts, sel_N, sel_k, sel_mode; float sel_thr;
   int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
-  const void* a_lo2;                      /* ABI 6: as in evt_linear_desc (A = hl32 lines + this lo2 plane), first launch; both   */
-                                          /* launches must run on the 256-row kernel (else EVT_ERR_BAD_SHAPE)                    */
 } evt_mlp_desc;
 
 EVT_API int evt_gated_mlp(const evt_mlp_desc* d, void* stream);

@@ -38,17 +38,8 @@ case $what in
   prof_window) # phase timing inside the resident K8 kernel (scripts/build_variant.sh prof -DEVT_PROF first)
     EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so EVT_WINDOW_NW=8 python scripts/attn_prof.py --dense window 2>&1 | tee $OUT/k8_resident_phase_profile.txt
     EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so EVT_WINDOW_NW=4 python scripts/attn_prof.py --dense window 2>&1 | tee -a $OUT/k8_resident_phase_profile.txt ;;
-  gemm_ab)     # the gated linears at the headline shape with the gate input as three bf16 planes vs fp32 (EVT_SPLIT_GATE_INPUT)
-    python scripts/gemm_planes_bench.py 2>&1 | tee $OUT/gemm_ab.txt
-    for env in "EVT_GEMM_BIG=2" "EVT_PLANES_NO_L2=1" "EVT_PLANES_NO_L2=1 EVT_GEMM_BIG=2" "EVT_GEMM_BIG=4"; do
-      echo "== $env" | tee -a $OUT/gemm_ab.txt
-      env $env python scripts/gemm_planes_bench.py 2>&1 | tee -a $OUT/gemm_ab.txt
-    done ;;
-  fused_ab)    # fused gated attention at the headline shape: this tree vs scripts/probes/bin/libevt_base.so
-    python scripts/kbench.py --clips 256 --only softmax_av_fused_qk_norm_noout,softmax_av_fused_qk_norm,softmax_av_fused_qk 2>&1 | tee $OUT/fused_ab.txt
-    EVT_LIB=$PWD/scripts/probes/bin/libevt_base.so python scripts/kbench.py --clips 256 --only softmax_av_fused_qk_norm_noout,softmax_av_fused_qk_norm,softmax_av_fused_qk 2>&1 | tee -a $OUT/fused_ab.txt ;;
   vd_ab)       # one-stream latency with the round's changes switched off one by one
-    for env in "" "EVT_ROW_SELECT=0" "EVT_DENSE_TILED=1" "EVT_ROW_SELECT=0 EVT_DENSE_TILED=1"; do
+    for env in "" "EVT_DENSE_TILED=1"; do
       echo "== $env" | tee -a $OUT/vd_ab.log
       env $env python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd_ab.log
       env $env python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd_ab.log
