@@ -44,6 +44,12 @@ case $what in
       env $env python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd_ab.log
       env $env python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd_ab.log
     done ;;
+  vd_trace)    # kernel trace of the graph-replayed one-stream frames -> per-frame totals per kernel
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/t672 -o t -- python3 $GRAFT_REPO_ROOT/scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs > $GRAFT_REPO_ROOT/$OUT/t672.log 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/t1024 -o t -- python3 $GRAFT_REPO_ROOT/scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs > $GRAFT_REPO_ROOT/$OUT/t1024.log 2>&1)
+    python scripts/trace_summary.py $(find $OUT/t672 -name "*kernel_trace.csv" | head -1) 6000 | tee $OUT/trace_vitdet672_one_stream.txt
+    python scripts/trace_summary.py $(find $OUT/t1024 -name "*kernel_trace.csv" | head -1) 3000 | tee $OUT/trace_vitdet1024_one_stream.txt
+    find $OUT -name "*kernel_trace.csv" -delete ;;
   vd)          # one-stream ViTDet latency (graph replay)
     python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log
     python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log ;;
