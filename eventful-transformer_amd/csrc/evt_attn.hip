@@ -6,6 +6,7 @@
 // products are exact and accumulation is fp32 -- the same arithmetic a bf16 MFMA would do --
 // and every point where the reference rounds to the cast dtype is reproduced by Store<T>::round.
 #include "evt_common.h"
+#include "evt_prep_roles.h"
 
 namespace {
 
@@ -424,45 +425,9 @@ __global__ __launch_bounds__(256) void v_gate_t_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ count, int N, int D, int kcap,
                                                        T* __restrict__ v_state, T* __restrict__ v_delta_t,
                                                        T* __restrict__ v_old_t) {
-  constexpr int TP = 64 + 8;  // LDS pitch in elements (16-byte aligned rows)
-  __shared__ __attribute__((aligned(16))) T td[64 * TP];
-  __shared__ __attribute__((aligned(16))) T to[64 * TP];
-  const int tid = threadIdx.x;
-  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
-  const int cnt = count ? count[b] : kcap;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int r = (tid >> 4) + 16 * it, c4 = (tid & 15) * 4, ii = k0 + r;
-    float dl[4] = {0.f, 0.f, 0.f, 0.f}, vo[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ii < cnt) {
-      const int tok = idx[(int64_t)b * kcap + ii];
-      const float4 v = *reinterpret_cast<const float4*>(vsrc + ((int64_t)b * N + tok) * v_rs + c0 + c4);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      T* st = v_state + ((int64_t)b * N + tok) * D + c0 + c4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float nv = Store<T>::round(vv[q]);
-        const float old = Store<T>::load(st + q);
-        dl[q] = Store<T>::round(nv - old);
-        vo[q] = Store<T>::round(nv - dl[q]);  // v_n_tilde - v_delta_tilde, modules.py:294
-        Store<T>::store(st + q, nv);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Store<T>::store(td + (c4 + q) * TP + r, dl[q]);
-      Store<T>::store(to + (c4 + q) * TP + r, vo[q]);
-    }
-  }
-  __syncthreads();
-  constexpr int VEC = 16 / (int)sizeof(T);
-  for (int e = tid; e < 64 * (64 / VEC); e += 256) {
-    const int ch = e / (64 / VEC), kk = (e - ch * (64 / VEC)) * VEC;
-    if (k0 + kk >= kcap) continue;  // kcap % VEC == 0 is required by the launcher
-    const int64_t o = ((int64_t)b * D + c0 + ch) * kcap + k0 + kk;
-    *reinterpret_cast<uint4*>(v_delta_t + o) = *reinterpret_cast<const uint4*>(td + ch * TP + kk);
-    *reinterpret_cast<uint4*>(v_old_t + o) = *reinterpret_cast<const uint4*>(to + ch * TP + kk);
-  }
+  __shared__ __attribute__((aligned(16))) unsigned char vg_smem[evt_vgate_lds<T>()];
+  evt_v_gate_t_role<T>(vsrc, v_rs, idx, count, N, D, kcap, v_state, v_delta_t, v_old_t, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                       vg_smem);   // evt_prep_roles.h
 }
 
 // =============================================================================================

@@ -27,6 +27,7 @@
 // column panel update (K4) touches 88 % of the state and costs more than this full recompute, and the state would
 // only be written (K4) to be read once here: K4 and 2 x 477 MB of state traffic per launch at B = 256 go away.
 #include "evt_attn_tiles.h"   // Tile<T> (LDS pitch + MFMA sweep), fast_exp, split4
+#include "evt_prep_roles.h"
 #include <algorithm>
 
 namespace {
@@ -867,62 +868,8 @@ __global__ __launch_bounds__(256) void rel_terms_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void rel_terms_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rel_y,
                                                              const float* __restrict__ rel_x, int H, int N, int D, int gh, int gw,
                                                              int qw, float* __restrict__ terms) {
-  constexpr int DH = 64, LP = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float rt_smem[];
-  const int qh = N / qw, nrel = gh + gw;
-  const bool is_y = (int)blockIdx.x < qh;
-  const int pos = is_y ? (int)blockIdx.x : (int)blockIdx.x - qh;   // y, or x
-  const int nq = is_y ? qw : qh, nkey = is_y ? gh : gw;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  float* qs = rt_smem;               // [nq][LP]
-  float* ts = rt_smem + nq * LP;     // [nkey][LP]
-  const float* tab = is_y ? rel_y + (int64_t)pos * gh * DH : rel_x + (int64_t)pos * gw * DH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
-  for (int e = tid; e < nq * (DH / 4); e += 256) {
-    const int r = e / (DH / 4), c4 = e - r * (DH / 4);
-    const int i = is_y ? pos * qw + r : r * qw + pos;
-    *reinterpret_cast<float4*>(qs + r * LP + c4 * 4) =
-        *reinterpret_cast<const float4*>(qkv + ((int64_t)b * N + i) * 3 * D + h * DH + c4 * 4);
-  }
-  for (int e = tid; e < nkey * (DH / 4); e += 256) {
-    const int r = e / (DH / 4), c4 = e - r * (DH / 4);
-    *reinterpret_cast<float4*>(ts + r * LP + c4 * 4) = *reinterpret_cast<const float4*>(tab + (int64_t)r * DH + c4 * 4);
-  }
-  __syncthreads();
-  auto frag = [&](const float* rows, int n, int tile, int m, bf16x8_t* hi, bf16x8_t* lo) __attribute__((always_inline)) {
-    const float* p = rows + min(tile * 16 + l15, n - 1) * LP + 32 * m + 8 * kg;   // k-block m: channels 32 m + 8 kg .. + 8
-    bf16x4_t h0, l0, h1, l1;
-    split4(*reinterpret_cast<const float4*>(p), &h0, &l0);
-    split4(*reinterpret_cast<const float4*>(p + 4), &h1, &l1);
-    *hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
-  const int TQ = (nq + 15) >> 4, TK = (nkey + 15) >> 4;
-  for (int tq = wave; tq < TQ; tq += 4) {
-    bf16x8_t qhi[2], qlo[2];
-    frag(qs, nq, tq, 0, &qhi[0], &qlo[0]);
-    frag(qs, nq, tq, 1, &qhi[1], &qlo[1]);
-    for (int tk = 0; tk < TK; ++tk) {
-      f32x4_acc acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        bf16x8_t thi, tlo;
-        frag(ts, nkey, tk, m, &thi, &tlo);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qlo[m], thi, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qhi[m], tlo, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qhi[m], thi, acc, 0, 0, 0);
-      }
-      const int key = tk * 16 + l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tq * 16 + 4 * kg + r;
-        if (row < nq && key < nkey) {
-          const int i = is_y ? pos * qw + row : row * qw + pos;
-          terms[((int64_t)bh * N + i) * nrel + (is_y ? 0 : gh) + key] = acc[r];
-        }
-      }
-    }
-  }
+  evt_rel_terms_mfma_role(qkv, rel_y, rel_x, H, N, D, gh, gw, qw, terms, (int)blockIdx.x, (int)blockIdx.y, rt_smem);   // evt_prep_roles.h
 }
 
 }  // namespace

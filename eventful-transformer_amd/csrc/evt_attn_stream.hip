@@ -33,6 +33,7 @@
 // partial ||out - ref||^2 for the projection gate) is that of evt_softmax_av_gated; every rounding point of the reference
 // is kept.  Head dim 64, un-pooled keys.
 #include "evt_attn_tiles.h"
+#include "evt_prep_roles.h"
 #include <algorithm>
 #include <stdlib.h>
 
@@ -46,6 +47,7 @@ struct StreamArgs {
   void* k_split;
   int B, H, N, D, kcap, gh, gw;
   float scale;
+  int k_split_ready;   // the key plane has been written by evt_stream_prep: no pre-kernel
 };
 
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
@@ -124,33 +126,7 @@ template <> struct Sweep16<float> {
 constexpr int SKH = 4;   // heads per workgroup
 __global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB) {
   __shared__ __attribute__((aligned(16))) uint4 tile[SKH * 256];   // [head][256]: a head's 4 KB block in its final order
-  const int b = blockIdx.x / NKB, kb = blockIdx.x - b * NKB;
-  const int h0 = blockIdx.y * SKH, nh = min(SKH, H - h0);
-  const int units = 16 * nh * 8;                     // (key i, head, 8-channel group c8), c8 fastest: 32 consecutive bytes each
-  for (int u = threadIdx.x; u < units; u += 256) {
-    const int c8 = u & 7, hh = (u >> 3) % nh, i = (u >> 3) / nh, key = kb * 16 + i;
-    bf16x8_t hi = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
-    if (key < N) {
-      const float* src = qkv + ((int64_t)b * N + key) * 3 * (int64_t)D + D + (h0 + hh) * SDH + c8 * 8;
-      const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
-      bf16x4_t hx, lx, hy, ly;
-      split4(x, &hx, &lx);
-      split4(y, &hy, &ly);
-      hi = __builtin_shufflevector(hx, hy, 0, 1, 2, 3, 4, 5, 6, 7);
-      lo = __builtin_shufflevector(lx, ly, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-    // final position p = hh * 256 + (2 m + hl) * 64 + kg * 16 + i; in LDS the low four bits are rotated by the piece's
-    // (c8 + 8 hh): a wave's lanes share i and differ in (c8, hh), un-rotated they would all hit the same four banks
-    const int m = c8 >> 2, kg = c8 & 3, rot = (i + c8 + 8 * hh) & 15;
-    uint4* dst = tile + hh * 256 + (m * 2) * 64 + kg * 16 + rot;
-    dst[0] = __builtin_bit_cast(uint4, hi);
-    dst[64] = __builtin_bit_cast(uint4, lo);
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nh * 256; e += 256) {
-    const int hh = e >> 8, g = e >> 4, c8 = ((g >> 3) & 1) * 4 + (g & 3);
-    out[(((int64_t)b * H + h0 + hh) * NKB + kb) * 256 + (e & 255)] = tile[(e & ~15) | ((e + c8 + 8 * hh) & 15)];
-  }
+  evt_split_keys_role(qkv, out, B, H, N, D, NKB, (int)blockIdx.x, (int)blockIdx.y, tile);   // evt_prep_roles.h
 }
 
 // QK: 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = q, k as bf16 hi + lo (three v_mfma_f32_16x16x32_bf16 per
@@ -798,7 +774,7 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   const size_t lds = stream_lds_bytes<T, NHR>(a.gh + a.gw);
   const int tiles_x = (a.N + FRT - 1) / FRT, total = tiles_x * a.B * a.H;
   EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
-  if (QK == 2) {
+  if (QK == 2 && !a.k_split_ready) {
     const int nkb = (a.N + 15) / 16;
     hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb), (unsigned)((a.H + SKH - 1) / SKH)), dim3(256), 0, s, a.qkv,
                        reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, nkb);
@@ -876,7 +852,7 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
                 "evt_softmax_av_gated for this shape", d->gh, d->gw, (long long)need, EVT_LDS_PER_CU);
   }
   StreamArgs a{d->qkv, d->rel_terms, d->a_state_t, d->idx, d->count, d->v_delta_t, d->v_old_t, d->v_state, d->pv, d->out_f32,
-               d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale};
+               d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale, d->k_split_ready};
   hipStream_t s = evt_stream(stream);
   EVT_DISPATCH_STORE(d->store, T, {
     if (d->first) launch_stream<T, true>(a, d->qk_split, s);

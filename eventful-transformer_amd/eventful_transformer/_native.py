@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes",
+    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_stream_prep",
 )
 
 
@@ -115,7 +115,15 @@ class AttnStreamDesc(Structure):
         ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32), ("v_delta_t", c_void_p), ("v_old_t", c_void_p),
         ("v_state", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("store", c_int32), ("scale", c_float),
-        ("qk_split", c_int32), ("first", c_int32), ("k_split", c_void_p),
+        ("qk_split", c_int32), ("first", c_int32), ("k_split", c_void_p), ("k_split_ready", c_int32),
+    ]
+
+
+class StreamPrepDesc(Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("rel_y", c_void_p), ("rel_x", c_void_p), ("terms", c_void_p), ("k_split", c_void_p),
+        ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32), ("v_state", c_void_p), ("v_delta_t", c_void_p), ("v_old_t", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("gh", c_int32), ("gw", c_int32), ("qw", c_int32), ("store", c_int32),
     ]
 
 
@@ -155,6 +163,7 @@ def _bind(lib):
         "evt_rel_terms": [P, P, P, I, I, I, I, I, I, I, I, P, P],
         "evt_attention_dense": [POINTER(AttnDenseDesc), P],
         "evt_attention_stream": [POINTER(AttnStreamDesc), P],
+        "evt_stream_prep": [POINTER(StreamPrepDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -553,16 +562,38 @@ def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
     return 0 < load().evt_attention_stream_lds_bytes(store, gh, gw) <= LDS_PER_CU
 
 
+# One stream: the three preparations of a gated evt_attention_stream frame (rel-pos terms, key plane, value gate) as ONE launch
+# (evt_stream_prep).  EVT_STREAM_PREP=0: three launches.
+STREAM_PREP = os.environ.get("EVT_STREAM_PREP", "1") != "0"
+
+
+def k_split_plane(qkv, B, H, N):
+    """The key-plane workspace of evt_attention_stream / evt_stream_prep (4 KB per 16 keys and head)."""
+    return scratch("k_split", (B, H, (N + 15) // 16, 2048), torch.bfloat16, qkv.device)
+
+
+def stream_prep_fits(D, H, kcap, has_rel):
+    return STREAM_PREP and QK_SPLIT and has_rel and D == 64 * H and kcap > 0 and kcap % 8 == 0
+
+
+def stream_prep(qkv, rel_y, rel_x, terms, idx, count, kcap, v_state, v_delta_t, v_old_t, B, H, N, D, gh, gw, qw, store):
+    """rel-pos terms + key plane + transposed value gate of a gated frame in one launch; attention_stream(..., k_split_ready=True)
+    then skips its key-plane pre-kernel."""
+    d = StreamPrepDesc(_p(qkv), _p(rel_y), _p(rel_x), _p(terms), _p(k_split_plane(qkv, B, H, N)), _p(idx), _p(count), kcap, _p(v_state),
+                       _p(v_delta_t), _p(v_old_t), B, H, N, D, gh, gw, qw, store)
+    _check(load().evt_stream_prep(ctypes.byref(d), _stream()))
+
+
 def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_terms=None, gh=0, gw=0, idx=None, count=None,
                      kcap=0, v_delta_t=None, v_old_t=None, v_state=None, out_f32=None, norm_ref=None, norm_parts=None,
-                     qk_split=None):
+                     qk_split=None, k_split_ready=False):
     """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N)."""
     split = int(QK_SPLIT if qk_split is None else qk_split)
     # split arithmetic: the frame's key rows as bf16 hi / lo fragments, written by the call's pre-kernel (4 KB per 16 keys and head)
-    ksp = scratch("k_split", (B, H, (N + 15) // 16, 2048), torch.bfloat16, qkv.device) if split else None
+    ksp = k_split_plane(qkv, B, H, N) if split else None
     d = AttnStreamDesc(_p(qkv), _p(rel_terms), gh, gw, _p(a_state_t), _p(idx), _p(count), kcap, _p(v_delta_t), _p(v_old_t),
                        _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts), B, H, N, D, store, float(scale),
-                       split, int(first), _p(ksp))
+                       split, int(first), _p(ksp), int(bool(k_split_ready) and bool(split)))
     # algorithmic bytes: q, k read once per clip (8ND), rel terms, gate-reference columns read + rewritten (first frame:
     # written whole), v pieces, A.v state read-modify-write (first frame: v state read, state written), fp32 output
     # The gated form is priced by the LIVE selected-key count (threshold policy: `count` on the device, capacity N), never by kcap.

@@ -833,7 +833,9 @@ class EventfulBlock(EventfulMatmul1Block):
         terms = None
         if ry is not None:   # decomposed rel-pos terms of every query token, once per frame (utils.py:159-168)
             terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
-            _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
+            # (a gated frame computes them together with the key plane and the value gate: evt_stream_prep, below)
+            if acc.first or not _native.stream_prep_fits(D, H, cap, True):
+                _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
             self.relative_position.count_fused(B, H)
         if acc.first:   # first frame of the clip: gate reference, value state, A.v state and the output in one launch
             vg.first = ag.first = acc.first = acc1.first = False
@@ -852,7 +854,13 @@ class EventfulBlock(EventfulMatmul1Block):
             return attn, None, None
         v_delta = self._ws("v_delta_t", (B, D, cap), sdt, qkv)
         v_old = self._ws("v_old_t", (B, D, cap), sdt, qkv)
-        _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
+        prepped = False
+        if terms is not None and _native.stream_prep_fits(D, H, cap, True):
+            # rel-pos terms, key plane and value gate depend only on the updated token buffer (and the index list): one launch
+            _native.stream_prep(qkv, ry, rx, terms, idx, count, cap, vg._state, v_delta, v_old, B, H, N, D, gh, gw, qw, store)
+            prepped = True
+        else:
+            _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
         pg = self.projection_gate
         fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
@@ -864,7 +872,7 @@ class EventfulBlock(EventfulMatmul1Block):
         _native.attention_stream(qkv, ag._state_t, acc._state, B, H, N, D, self.scale, store, False, rel_terms=terms,
                                  gh=gh, gw=gw, idx=idx, count=count, kcap=cap, v_delta_t=v_delta, v_old_t=v_old,
                                  out_f32=None if state_src else attn, norm_ref=pg.p if fuse_norm else None,
-                                 norm_parts=nparts)
+                                 norm_parts=nparts, k_split_ready=prepped)
         self._defer_scores(B, N)
         if self.count_mode or acc.count_mode or vg.count_mode or acc1.matmul.count_mode:
             n = self._n_rows(B, cap, count)

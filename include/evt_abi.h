@@ -39,7 +39,9 @@ extern "C" {
                                     argument of evt_rel_terms, embedded selection (sel_* fields of evt_linear_desc /
                                     evt_mlp_desc, evt_gated_linear_embeds_select);
                                  6: evt_attention_stream_lds_bytes (shape-only query; evt_attention_stream now answers
-                                    EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS) */
+                                    EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS);
+                                    evt_stream_prep + evt_attn_stream_desc.k_split_ready (rel-pos terms, key plane and value gate
+                                    of a gated frame in one launch) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -416,6 +418,7 @@ typedef struct evt_attn_stream_desc {
   int32_t first;                          /* 1 = first frame of a clip                                       */
   void* k_split;                          /* workspace, B * H * ceil(N/16) * 4096 bytes, required with qk_split: the frame's
                                              key rows as bf16 hi / lo MFMA fragments (written by a pre-kernel of this call) */
+  int32_t k_split_ready;                  /* ABI 6: 1 = evt_stream_prep has already written k_split for this frame: no pre-kernel */
 } evt_attn_stream_desc;
 
 EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
@@ -425,6 +428,27 @@ EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
  * answer exceeds the CU's 160 KB to evt_qk + evt_softmax_av_gated (the reference ops are the same, blocks.py:506-523,558-575);
  * evt_attention_stream itself returns EVT_ERR_BAD_SHAPE for it. */
 EVT_API int64_t evt_attention_stream_lds_bytes(int32_t store, int32_t gh, int32_t gw);
+
+/* ABI 6.  The three preparations of a GATED frame of evt_attention_stream in ONE launch (a role per workgroup range): the rel-pos
+ * terms of every query token (what evt_rel_terms writes with split = 1: utils.py:159-168), the key plane `k_split` (then pass
+ * k_split_ready = 1 to evt_attention_stream) and the value delta gate with transposed outputs (what evt_v_gate writes with
+ * gated = transposed = 1 on the value slice of the packed buffer: modules.py:187-201 + blocks.py:561-567).  All three read the
+ * updated token buffer and none reads another's output.  Same kernels' bodies: same results bit for bit.  Head dim 64,
+ * N == gh * gw == qh * qw, kcap a positive multiple of 8.  A one-stream frame runs this once per global block instead of three
+ * launches. */
+typedef struct evt_stream_prep_desc {
+  const float* qkv;                        /* (B,N,3D) packed token buffer (qkv_accumulator.b)                              */
+  const float* rel_y; const float* rel_x;  /* (qh,gh,64), (qw,gw,64) rel-pos tables                                          */
+  float* terms;                            /* out (B,H,N,gh+gw)                                                              */
+  void* k_split;                           /* out: evt_attn_stream_desc.k_split                                              */
+  const int32_t* idx; const int32_t* count; int32_t kcap;   /* the qkv gate's selected tokens (count nullable)               */
+  void* v_state;                           /* in/out (B,N,D) store type: v_gate.p                                            */
+  void* v_delta_t; void* v_old_t;          /* out (B,D,kcap) store type                                                      */
+  int32_t B, H, N, D, gh, gw, qw;
+  int32_t store;                           /* evt_dtype of v_state / v_delta_t / v_old_t                                     */
+} evt_stream_prep_desc;
+
+EVT_API int evt_stream_prep(const evt_stream_prep_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K/V token pooling (`pool_size`, blocks.py:303-326, 525-540).

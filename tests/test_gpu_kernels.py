@@ -769,6 +769,55 @@ def test_fused_attention_with_precomputed_rel_terms(cast, N, k):
 
 
 
+@pytest.mark.parametrize("cast,N,gw,k,counted", [(None, 1764, 42, 256, False), ("bfloat16", 4096, 64, 400, True), ("float16", 324, 18, 104, False),
+                                                 (None, 272, 17, 40, True)])
+def test_stream_prep_matches_the_three_launches(cast, N, gw, k, counted):
+    """evt_stream_prep (rel-pos terms + key plane + transposed value gate as roles of ONE launch) against evt_rel_terms +
+    evt_v_gate + evt_attention_stream's own key-plane pre-kernel: the terms, the value-gate outputs and state, and everything
+    the following evt_attention_stream launch produces (with k_split_ready) must be bit-identical -- top-k and a device-side
+    count (capacity N), fp32 / bf16 / fp16 store, ViTDet's 42 x 42 and 64 x 64 grids."""
+    n = native()
+    B, H, dh, scale = 1, 12, 64, 8.0
+    D = H * dh
+    gh = N // gw
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator(device=DEV).manual_seed(N + k)
+    qkv = torch.randn(B, N, 3 * D, device=DEV, generator=g)
+    ry = torch.randn(gh, gh, dh, device=DEV, generator=g) * 0.2
+    rx = torch.randn(gw, gw, dh, device=DEV, generator=g) * 0.2
+    cap = N if counted else k
+    idx = torch.zeros(B, cap, dtype=torch.int32, device=DEV)
+    idx[0, :k] = torch.randperm(N, device=DEV, generator=g)[:k].sort()[0].int()
+    count = torch.full((B,), k, dtype=torch.int32, device=DEV) if counted else None
+    apT0 = torch.rand(B, H, N, N, device=DEV, generator=g).to(sdt)
+    vp0 = torch.randn(B, N, D, device=DEV, generator=g).to(sdt)
+    pv0 = torch.randn(B, N, D, device=DEV, generator=g).to(sdt)
+    pref = torch.randn(B, N, D, device=DEV, generator=g)
+    res = []
+    for prep in (False, True):
+        n.clear_scratch()
+        apT, vp, pv = apT0.clone(), vp0.clone(), pv0.clone()
+        terms = torch.full((B, H, N, gh + gw), float("nan"), device=DEV)
+        vd = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+        vo = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+        out = torch.empty(B, N, D, device=DEV)
+        parts = torch.empty(B, N, H, device=DEV)
+        if prep:
+            assert n.stream_prep_fits(D, H, cap, True)
+            n.stream_prep(qkv, ry, rx, terms, idx, count, cap, vp, vd, vo, B, H, N, D, gh, gw, gw, store)
+        else:
+            n.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, gw, terms)
+            n.v_gate(qkv, idx, count, B, N, D, cap, vp, vd, vo, store, True, transposed=True)
+        n.attention_stream(qkv, apT, pv, B, H, N, D, scale, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx, count=count, kcap=cap,
+                           v_delta_t=vd, v_old_t=vo, out_f32=out, norm_ref=pref, norm_parts=parts, k_split_ready=prep)
+        kplane = n.k_split_plane(qkv, B, H, N).clone()
+        res.append([t.cpu() for t in (terms, vd[..., :k], vo[..., :k], vp, kplane.view(torch.int16), apT, pv, out, parts)])
+    for name, a_, b_ in zip(("terms", "v_delta", "v_old", "v_state", "key plane", "a_state_t", "pv", "out", "norm_parts"), res[0], res[1]):
+        assert torch.equal(a_.view(torch.uint8) if a_.dtype == torch.bfloat16 else a_, b_.view(torch.uint8) if b_.dtype == torch.bfloat16 else b_), name
+    assert torch.isfinite(res[1][7]).all()
+
+
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
                                              (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True),
                                              ("bfloat16", 197, 197, 128, False), (None, 262, 131, 77, False)])
