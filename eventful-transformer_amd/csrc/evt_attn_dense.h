@@ -10,9 +10,10 @@ struct DenseArgs {
   int groups_per_clip, clip_rows;
   int G, H, N, D, gh, gw, qw;
   float scale;
+  const float* norm_ref; float* norm_parts;   // resident kernel only: (rows, D) reference of the next gate -> (rows, H) partial ||out - ref||^2
 };
 
 // evt_attn_window.hip.  evt_window_fits: shape-only (LDS budget of the resident K / V planes); evt_launch_window returns false
 // when it does not take the launch (state outputs requested, or the planes do not fit a CU's LDS).
-bool evt_window_fits(int N, int nrel, int store, int split);
+bool evt_window_fits(int N, int nrel, int store, int split);   // (also exported as evt_attention_dense_resident)
 bool evt_launch_window(const DenseArgs& a, int store, int split, hipStream_t s);

@@ -551,12 +551,15 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
   }
   DenseArgs a{d->qkv, d->rel_y, d->rel_x, d->tok_map, d->pad_row, d->out_f32, d->product, d->a_state, d->pv,
               d->tok_map ? d->groups_per_clip : 1, d->tok_map ? d->clip_rows : d->N, d->G, d->H, d->N, d->D,
-              d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale};
+              d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale, d->norm_ref, d->norm_parts};
+  EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_attention_dense: norm_ref / norm_parts come together");
   // Resident form first (evt_attn_window.hip: the group's K / V staged once per (group, head)); the tiled kernel below keeps
   // the launches that want state outputs and the shapes whose planes do not fit a CU's LDS.  EVT_DENSE_TILED=1 forces it.
   static const bool tiled_only = getenv("EVT_DENSE_TILED") != nullptr && atoi(getenv("EVT_DENSE_TILED")) != 0;
   if (a.G == 0) return EVT_OK;
   if (!tiled_only && evt_launch_window(a, d->store, d->qk_split, evt_stream(stream))) return evt_check_launch("evt_attention_dense (resident)");
+  EVT_REQUIRE(d->norm_ref == nullptr, EVT_ERR_BAD_SHAPE, "evt_attention_dense: norm_ref / norm_parts are outputs of the resident kernel only "
+              "(no state outputs, planes within a CU's LDS: ask evt_attention_dense_resident first)");
   EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, d->qk_split, stream); });
   return EVT_OK;
 }

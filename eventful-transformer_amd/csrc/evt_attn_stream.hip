@@ -118,15 +118,27 @@ template <> struct Sweep16<float> {
 // is stored as the 64 lanes' 16-byte pieces in lane order: a wave's load instruction reads 1 KB of consecutive bytes.
 // The conversion of a key row, repeated by every row tile before (128 x at 1024^2; ~50 of the pass's 177 VALU
 // instructions per chunk and wave), happens once.  Layout: uint4 index (((bh * NKB + key / 16) * 2 + m) * 2 + hl) * 64 +
-// kg * 16 + key % 16, NKB = ceil(N / 16); keys past N are zero rows.  One thread per (b, key, h, 8 channels).
+// kg * 16 + key % 16, NKB = ceil(N / 16); keys past N are zero rows.  With a rel-pos key grid every grid row starts a new
+// 16-key block (evt_key_blocks, evt_prep_roles.h: NKB = gh ceil(gw / 16), zero rows behind a grid row's last key).
 // One workgroup per (clip, 16-key block, group of 4 heads): the block's key rows are read as 1 KB token-row slices
 // (coalesced), converted, placed at their fragment positions in LDS and written out as 4 KB of consecutive bytes per head
 // (one thread per 8 channels with two scattered 16-byte stores each: 11.2 us at 1024^2; one workgroup for all 12 heads of a
 // block: 111 workgroups at 672^2, 7.5 us).
 constexpr int SKH = 4;   // heads per workgroup
-__global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB) {
+__global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB, int gw) {
   __shared__ __attribute__((aligned(16))) uint4 tile[SKH * 256];   // [head][256]: a head's 4 KB block in its final order
-  evt_split_keys_role(qkv, out, B, H, N, D, NKB, (int)blockIdx.x, (int)blockIdx.y, tile);   // evt_prep_roles.h
+  evt_split_keys_role(qkv, out, B, H, N, D, NKB, gw, (int)blockIdx.x, (int)blockIdx.y, tile);   // evt_prep_roles.h
+}
+
+// Rel-pos terms of a tile's rows in LDS, per row: [0, gh) row terms ty, -inf up to TYP = (gh + 4) & ~3 (slot gh is what
+// key blocks past the grid read), then from TYP the column terms tx of 16 ceil(gw / 16) columns, -inf behind column gw (the zero
+// rows of the key plane are masked by their term).  Pitch = 4 x odd words: the 16-byte reads of tx (16 lanes = 16 rows, same
+// column quad) cover all 64 banks, and so do the 4-byte reads of 16 rows.
+__host__ __device__ inline int stream_rel_typ(int gh) { return (gh + 4) & ~3; }
+__host__ __device__ inline int stream_rel_pitch(int gh, int gw) {
+  if (gw <= 0) return 1;
+  const int q = (stream_rel_typ(gh) + 16 * ((gw + 15) >> 4)) >> 2;
+  return 4 * (q | 1);
 }
 
 // QK: 1 = exact fp32 products (v_mfma_f32_16x16x4_f32), 2 = q, k as bf16 hi + lo (three v_mfma_f32_16x16x32_bf16 per
@@ -141,8 +153,9 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   T* Ad = An + FRT * P;                                 // [FRT][P] da~
   T* Vd = Ad + FRT * P;                                 // [64][P]  dv~^T (first frame: v^T) of the chunk
   T* Vo = Vd + SDH * P;                                 // [64][P]  v_old^T
-  const int nrel = a.gh + a.gw, RP = nrel | 1;          // odd pitch: the 16 rows of a lane group hit different banks
-  float* relv = reinterpret_cast<float*>(Vo + SDH * P); // [FRT][RP] rel-pos terms of the tile's rows
+  const int nrel = a.gh + a.gw, RP = stream_rel_pitch(a.gh, a.gw), TYP = stream_rel_typ(a.gh);
+  const int KBR = (a.gw + 15) >> 4;                     // key blocks per grid row (key plane, rel-pos grid)
+  float* relv = reinterpret_cast<float*>(Vo + SDH * P); // [FRT][RP] rel-pos terms of the tile's rows (stream_rel_pitch)
   float* wst = relv + FRT * RP;                         // [4][FRT][2] per-wave (max, sum) of each row
   float* fin = wst + 4 * FRT * 2;                       // [FRT][2] row max, 1 / row sum
   float* red1 = reinterpret_cast<float*>(stream_smem);  // [FRT][64] epilogue (the chunk tiles are idle then)
@@ -193,11 +206,13 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   }
   // Key fragments -> 4 pieces.  QK == 1: fp32 channels of key row j from the token buffer.  QK == 2: pieces 2m, 2m + 1 = hi,
   // lo of k-block m from the fragment-major plane (split_keys_kernel).
-  const int NKB = (a.N + 15) >> 4;
+  const int NKB = evt_key_blocks(a.N, a.gh, a.gw);
   const uint4* ksp = reinterpret_cast<const uint4*>(a.k_split) + (int64_t)bh * NKB * 256;
   auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps): a gather
     if (QK == 2) {
-      const uint4* kp = ksp + (int64_t)(j >> 4) * 256 + kg * 16 + (j & 15);
+      int pos = j;   // slot of key j in the plane: grid rows start new blocks
+      if (rel) { const int ky = fast_div(j, inv_gw); pos = ky * (KBR * 16) + (j - ky * a.gw); }
+      const uint4* kp = ksp + (int64_t)(pos >> 4) * 256 + kg * 16 + (pos & 15);
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
     } else {
@@ -206,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
     }
   };
-  auto load_chunk = [&](int c0, float4* kf) __attribute__((always_inline)) {   // keys c0 + 16 wave + l15 of a streamed chunk (clamped past N)
-    if (QK == 2) {   // the wave's 16-key block: four loads of 1 KB of consecutive bytes
+  auto load_chunk = [&](int c0, float4* kf) __attribute__((always_inline)) {   // slots c0 + 16 wave + l15 of a streamed chunk (clamped past the end)
+    if (QK == 2) {   // the wave's 16-key block of the plane: four loads of 1 KB of consecutive bytes
       const int kb = (c0 >> 4) + wave;
       const uint4* kp = ksp + (int64_t)(kb < NKB ? kb : NKB - 1) * 256 + lane;
 #pragma unroll
@@ -233,8 +248,14 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + tid + 256 * u;
-        if (e < total) { const int r = fast_div(e, inv_nrel); relv[r * RP + (e - r * nrel)] = v[u]; }
+        if (e < total) { const int r = fast_div(e, inv_nrel), c = e - r * nrel; relv[r * RP + (c < a.gh ? c : TYP + c - a.gh)] = v[u]; }
       }
+    }
+    const int npad = RP - nrel, ypad = TYP - a.gh;   // the -inf slots of every row
+    const float inv_npad = 1.0f / (float)npad;
+    for (int e = tid; e < FRT * npad; e += 256) {
+      const int r = fast_div(e, inv_npad), c = e - r * npad;
+      relv[r * RP + (c < ypad ? a.gh + c : TYP + a.gw + c - ypad)] = -INFINITY;
     }
   }
   {
@@ -259,9 +280,12 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   }
   // k (q / scale)^T: the 16 keys whose fragments are in kf against the tile's rows.  Keys are the A operand: sacc[hr][r] is
   // the score of query row 16 hr + l15 and key 4 kg + r of the 16.
-  auto scores = [&](const float4* kf, f32x4_acc* sacc) __attribute__((always_inline)) {
+  // `preset`: the accumulators already hold the rel-pos terms (split mode: the terms are the products' starting value)
+  auto scores = [&](const float4* kf, f32x4_acc* sacc, const bool preset = false) __attribute__((always_inline)) {
+    if (!preset) {
 #pragma unroll
-    for (int hr = 0; hr < NHR; ++hr) sacc[hr] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+      for (int hr = 0; hr < NHR; ++hr) sacc[hr] = (f32x4_acc){0.f, 0.f, 0.f, 0.f};
+    }
     if (QK == 1) {
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_)
@@ -285,16 +309,29 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       }
     }
   };
-  // + rel-pos terms of the lane's 4 keys js[0..3] (valid key indices), in the reference's order (x + ty) + tx (utils.py:166-172)
-  auto with_rel = [&](f32x4_acc* sacc, const int* js) __attribute__((always_inline)) {
-    if (!rel) return;
+  // Scores of the 16 keys in kf + the rel-pos terms of the lane's 4 keys js[0..3] (valid key indices).  Exact mode: the
+  // reference's order (x + ty) + tx (utils.py:166-172).  Split mode: ty + tx is the accumulators' starting value, in every
+  // pass alike (one add per score instead of two and no zeroing; the products' own rounding is ~1e-5 of the score).
+  auto scores_rel = [&](const float4* kf, f32x4_acc* sacc, const int* js) __attribute__((always_inline)) {
+    if (!rel) { scores(kf, sacc); return; }
     int oy[4], ox[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ky = fast_div(js[r], inv_gw);
       oy[r] = ky;
-      ox[r] = a.gh + js[r] - ky * a.gw;
+      ox[r] = TYP + js[r] - ky * a.gw;
     }
+    if (QK == 2) {
+#pragma unroll
+      for (int hr = 0; hr < NHR; ++hr) {
+        const float* rv = relv + (16 * hr + l15) * RP;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[hr][r] = rv[oy[r]] + rv[ox[r]];
+      }
+      scores(kf, sacc, true);
+      return;
+    }
+    scores(kf, sacc);
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
       const float* rv = relv + (16 * hr + l15) * RP;
@@ -315,7 +352,47 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   const int cdy = rel ? 64 / a.gw : 0, cdx = rel ? 64 - cdy * a.gw : 0;   // a chunk = cdy grid rows + cdx columns
   int ky0 = 0, kx0 = 0;                                                    // of key 16 wave + 4 kg of the current chunk
   if (rel) { const int j0 = wave * 16 + 4 * kg; ky0 = fast_div(j0, inv_gw); kx0 = j0 - ky0 * a.gw; }
+  constexpr float L2E = 1.44269504088896340736f;
+  // (max, sum) update of row group hr by 4 scores of ONE row: one rescale of the running sum per group, one exponential per
+  // score, the subtraction of the maximum folded into the exponent's multiply (exp2(x log2e - max log2e))
+  auto group = [&](int hr, const float* x) __attribute__((always_inline)) {
+    const float nm = fmaxf(rm[hr], fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));   // finite: rm starts at -1e30
+    const float nml = -nm * L2E;
+    const float part = (__builtin_amdgcn_exp2f(fmaf(x[0], L2E, nml)) + __builtin_amdgcn_exp2f(fmaf(x[1], L2E, nml))) +
+                       (__builtin_amdgcn_exp2f(fmaf(x[2], L2E, nml)) + __builtin_amdgcn_exp2f(fmaf(x[3], L2E, nml)));
+    // (the rescale factor from the difference: with rm = nm = -1e30, nothing seen yet, rm log2e + nml is a rounding error of 1e22)
+    rsum[hr] = fmaf(rsum[hr], __builtin_amdgcn_exp2f((rm[hr] - nm) * L2E), part);
+    rm[hr] = nm;
+  };
+  // Split mode with a rel-pos grid: the wave's 16-key block lies inside ONE grid row of the key plane -- its grid row gky and
+  // column block gxb are wave-uniform (scalar registers, advanced by 4 blocks per chunk), the row term is one LDS word and the
+  // 4 column terms one 16-byte read per row group, they are the accumulators' starting value, and the plane's zero rows and the
+  // blocks past the grid are masked by -inf terms: 2 LDS reads + 4 adds per row group instead of 8 reads, 8 adds, the index
+  // arithmetic and the masks.
+  int gky = 0, gxb = 0, sdy = 0, sdx = 0;
+  if (QK == 2 && rel) { gky = wave / KBR; gxb = wave - gky * KBR; sdy = 4 / KBR; sdx = 4 - sdy * KBR; }
+  auto stats_grid = [&](const float4* kf) __attribute__((always_inline)) {
+    f32x4_acc sacc[NHR];
+    const int tyo = min(gky, a.gh), txo = TYP + 16 * gxb + 4 * kg;
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      const float* rv = relv + (16 * hr + l15) * RP;
+      const float ty = rv[tyo];
+      const float4 tx = *reinterpret_cast<const float4*>(rv + txo);
+      sacc[hr] = (f32x4_acc){ty + tx.x, ty + tx.y, ty + tx.z, ty + tx.w};
+    }
+    scores(kf, sacc, true);
+    gxb += sdx;
+    gky += sdy;
+    if (gxb >= KBR) { gxb -= KBR; ++gky; }
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      const float x[4] = {sacc[hr][0], sacc[hr][1], sacc[hr][2], sacc[hr][3]};
+      group(hr, x);
+    }
+  };
   auto stats = [&](int c0, const float4* kf, const bool mask) __attribute__((always_inline)) {
+    if (QK == 2 && rel) { stats_grid(kf); return; }
     f32x4_acc sacc[NHR];
     scores(kf, sacc);
     const int jb = c0 + wave * 16 + 4 * kg;
@@ -326,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
         const int kx = kx0 + r;
         const bool wrap = kx >= a.gw;
         oy[r] = min(ky0 + (wrap ? 1 : 0), a.gh - 1);   // (keys past N: any valid slot, their scores are masked)
-        ox[r] = a.gh + (wrap ? kx - a.gw : kx);
+        ox[r] = TYP + (wrap ? kx - a.gw : kx);
       }
 #pragma unroll
       for (int hr = 0; hr < NHR; ++hr) {
@@ -344,24 +421,22 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       float x[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[r] = (!mask || jb + r < a.N) ? sacc[hr][r] : -INFINITY;
-      const float nm = fmaxf(rm[hr], fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));   // finite: rm starts at -1e30
-      const float part = (fast_exp(x[0] - nm) + fast_exp(x[1] - nm)) + (fast_exp(x[2] - nm) + fast_exp(x[3] - nm));
-      rsum[hr] = fmaf(rsum[hr], fast_exp(rm[hr] - nm), part);
-      rm[hr] = nm;
+      group(hr, x);
     }
   };
   // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
   {
+    const int NS = (QK == 2 && rel) ? NKB * 16 : a.N;   // slots to stream (the key plane's, with a rel-pos grid)
     int c0 = 0;
-    for (; c0 + 128 <= a.N; c0 += 128) {   // whole chunk pairs: no masks
+    for (; c0 + 128 <= NS; c0 += 128) {   // whole chunk pairs: no masks
       stats(c0, kA, false);
       load_chunk(c0 + 128, kA);
       stats(c0 + 64, kB, false);
       load_chunk(c0 + 192, kB);
     }
-    if (c0 < a.N) stats(c0, kA, true);          // the last (partial) pair: its fragments were requested above / in the prologue
-    if (c0 + 64 < a.N) stats(c0 + 64, kB, true);
+    if (c0 < NS) stats(c0, kA, true);          // the last (partial) pair: its fragments were requested above / in the prologue
+    if (c0 + 64 < NS) stats(c0 + 64, kB, true);
   }
   bool rok[NHR];   // query row 16 hr + l15 of the tile exists
 #pragma unroll
@@ -509,8 +584,10 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 
   if (FIRST) {
     const T* vst = reinterpret_cast<const T*>(a.v_state) + (int64_t)b * a.N * a.D + h * SDH;
-    load_chunk(0, kA);
-    load_chunk(64, kB);
+    // keys in index order here (the state columns and value rows are): key c0 + 16 wave + l15, gathered from the plane
+    auto load_keys = [&](int c0, float4* kf) __attribute__((always_inline)) { const int j = c0 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kf); };
+    load_keys(0, kA);
+    load_keys(64, kB);
     auto first_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
       // the chunk's 64 value rows (16 channels per thread), requested ahead of the score MFMAs
       const int vkey = tid >> 2, vc0 = (tid & 3) * 16, vj = c0 + vkey;
@@ -519,12 +596,11 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       for (int q = 0; q < (int)((16 * sizeof(T)) / 16); ++q)
         vv.u[q] = reinterpret_cast<const uint4*>(vst + (int64_t)(vj < a.N ? vj : a.N - 1) * a.D + vc0)[q];
       f32x4_acc sacc[NHR];
-      scores(kf, sacc);
       const int jb = c0 + wave * 16 + 4 * kg;
       int js[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) js[r] = jb + r < a.N ? jb + r : a.N - 1;
-      with_rel(sacc, js);
+      scores_rel(kf, sacc, js);
 #pragma unroll
       for (int hr = 0; hr < NHR; ++hr) {
         QuadT nw;
@@ -556,9 +632,9 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     };
     for (int c0 = 0; c0 < a.N; c0 += 128) {
       first_chunk(c0, kA);
-      load_chunk(c0 + 128, kA);
+      load_keys(c0 + 128, kA);
       if (c0 + 64 < a.N) first_chunk(c0 + 64, kB);
-      load_chunk(c0 + 192, kB);
+      load_keys(c0 + 192, kB);
     }
     STR_TICK(3);   // pass B (first frame: all keys)
     // ---- epilogue: out = state = round(acc(keys 0..31 of each chunk) + acc(keys 32..63)) ------------------------
@@ -604,11 +680,10 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   const bool tile_full = i0 + FRT <= a.N;
   auto process = [&](int k0, const Cols& q, const Cols& qnext, const float4* kf, uint4* vpd, uint4* vpo) __attribute__((always_inline)) {
     f32x4_acc sacc[NHR];
-    scores(kf, sacc);
     int js[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) js[r] = q.g[r] >= 0 ? q.g[r] : 0;
-    with_rel(sacc, js);
+    scores_rel(kf, sacc, js);
     const bool full = tile_full && k0 + FKC <= cnt;
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
@@ -763,21 +838,21 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 }
 
 template <typename T, int NHR>
-size_t stream_lds_bytes(int nrel) {
+size_t stream_lds_bytes(int gh, int gw) {
   constexpr int P = Tile<T>::PITCH, FRT = 16 * NHR;
-  return (size_t)(2 * FRT + 2 * SDH) * P * sizeof(T) + ((size_t)FRT * (nrel | 1) + 4 * FRT * 2 + FRT * 2) * sizeof(float);
+  return (size_t)(2 * FRT + 2 * SDH) * P * sizeof(T) + ((size_t)FRT * stream_rel_pitch(gh, gw) + 4 * FRT * 2 + FRT * 2) * sizeof(float);
 }
 
 template <typename T, bool FIRST, int QK, int NHR>
 void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   constexpr int FRT = 16 * NHR;
-  const size_t lds = stream_lds_bytes<T, NHR>(a.gh + a.gw);
+  const size_t lds = stream_lds_bytes<T, NHR>(a.gh, a.gw);
   const int tiles_x = (a.N + FRT - 1) / FRT, total = tiles_x * a.B * a.H;
   EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
   if (QK == 2 && !a.k_split_ready) {
-    const int nkb = (a.N + 15) / 16;
+    const int nkb = evt_key_blocks(a.N, a.gh, a.gw);
     hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb), (unsigned)((a.H + SKH - 1) / SKH)), dim3(256), 0, s, a.qkv,
-                       reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, nkb);
+                       reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, nkb, a.gw);
   }
   hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
 }
@@ -789,8 +864,8 @@ template <typename T>
 int stream_pick_nhr(const StreamArgs& a) {
   static const int forced = getenv("EVT_STREAM_NHR") ? atoi(getenv("EVT_STREAM_NHR")) : 0;
   if (forced >= 2 && forced <= 3) return forced;
-  const int cus = evt_cu_count(), nrel = a.gh + a.gw;
-  const size_t lds[2] = {stream_lds_bytes<T, 2>(nrel), stream_lds_bytes<T, 3>(nrel)};
+  const int cus = evt_cu_count();
+  const size_t lds[2] = {stream_lds_bytes<T, 2>(a.gh, a.gw), stream_lds_bytes<T, 3>(a.gh, a.gw)};
   int best = 2;
   int64_t best_cost = -1;
   for (int nhr = 2; nhr <= 3; ++nhr) {   // (64-row tiles, NHR = 4, spill 60-600 registers in the gated variants: not built)
@@ -815,13 +890,20 @@ void launch_stream(const StreamArgs& a, int qk_split, hipStream_t s) {
 }  // namespace
 
 extern "C" int64_t evt_attention_stream_lds_bytes(int32_t store, int32_t gh, int32_t gw) {
-  const int nrel = (gh > 0 && gw > 0) ? gh + gw : 0;
+  const bool rel = gh > 0 && gw > 0;
+  if (!rel) gh = gw = 0;
   switch (store) {
-    case EVT_F32: return (int64_t)stream_lds_bytes<float, 2>(nrel);
-    case EVT_BF16: return (int64_t)stream_lds_bytes<bf16_t, 2>(nrel);
-    case EVT_F16: return (int64_t)stream_lds_bytes<f16_t, 2>(nrel);
+    case EVT_F32: return (int64_t)stream_lds_bytes<float, 2>(gh, gw);
+    case EVT_BF16: return (int64_t)stream_lds_bytes<bf16_t, 2>(gh, gw);
+    case EVT_F16: return (int64_t)stream_lds_bytes<f16_t, 2>(gh, gw);
     default: return -1;
   }
+}
+
+extern "C" int64_t evt_attention_stream_key_blocks(int32_t N, int32_t gh, int32_t gw) {
+  if (N <= 0) return -1;
+  const bool rel = gh > 0 && gw > 0;
+  return evt_key_blocks(N, rel ? gh : 0, rel ? gw : 0);
 }
 
 extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream) {
@@ -842,7 +924,7 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
                 "evt_attention_stream: out_f32 may only be omitted with a 16-bit store type (the output then IS the pv state)");
   }
   EVT_REQUIRE(!d->qk_split || d->k_split != nullptr, EVT_ERR_BAD_ARG,
-              "evt_attention_stream: qk_split needs the k_split workspace (B * H * ceil(N / 16) * 4096 bytes)");
+              "evt_attention_stream: qk_split needs the k_split workspace (B * H * evt_attention_stream_key_blocks * 4096 bytes)");
   if (d->B == 0) return EVT_OK;
   const bool rel = d->rel_terms != nullptr;
   {

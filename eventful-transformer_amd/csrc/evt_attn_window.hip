@@ -493,6 +493,7 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
   WN_TICK(8);   // P conversion + P.V products
   // ---- epilogue: round, merge heads, un-window: lane (query lr, lh), register 4 g + e = channel 32 d + 8 g + 4 lh + e ----
   const int tr = q_on ? tmap[iq] : -1;   // < 0: padding token, dropped on un-windowing (blocks.py:346-376)
+  float ss = 0.f;   // norm_ref: this lane's 32 channels of || out - ref ||^2 (the projection gate's delta norm, per head)
   if (tr >= 0) {
   float* orow = a.out_f32 + ((int64_t)(g / a.groups_per_clip) * a.clip_rows + tr) * a.D + h * DH + 4 * lh;
 #pragma unroll
@@ -505,7 +506,18 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
       v.z = Store<T>::round(O[d][4 * gq + 2]);
       v.w = Store<T>::round(O[d][4 * gq + 3]);
       *reinterpret_cast<float4*>(orow + 32 * d + 8 * gq) = v;
+      if (a.norm_ref != nullptr) {   // launch-uniform
+        const float4 p = *reinterpret_cast<const float4*>(a.norm_ref + (orow - a.out_f32) + 32 * d + 8 * gq);
+        const float e0 = v.x - p.x, e1 = v.y - p.y, e2 = v.z - p.z, e3 = v.w - p.w;
+        ss += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+      }
     }
+  }
+  if (a.norm_ref != nullptr) {
+    // the other half of the head's channels sits in lane ^ 32; lane half 0 writes the (token, head) partial.  The selection
+    // (evt_select_*_sq) adds the H partials of a token in index order: no separate pass over the attention output.
+    ss += __shfl_xor(ss, 32, 64);
+    if (tr >= 0 && lh == 0) a.norm_parts[((int64_t)(g / a.groups_per_clip) * a.clip_rows + tr) * a.H + h] = ss;
   }
 #ifdef EVT_PROF
   WN_TICK(9);   // epilogue
@@ -544,6 +556,10 @@ bool evt_window_fits(int N, int nrel, int store, int split) {
   if (N <= 0 || N > 32 * MAXB) return false;
   const int sb = store == EVT_F32 ? 4 : 2;
   return win_lds(N, nrel, sb, split != 0).total <= (size_t)EVT_LDS_PER_CU;
+}
+
+extern "C" int evt_attention_dense_resident(int32_t N, int32_t gh, int32_t gw, int32_t store, int32_t qk_split) {
+  return evt_window_fits(N, (gh > 0 && gw > 0) ? gh + gw : 0, store, qk_split) ? 1 : 0;
 }
 
 bool evt_launch_window(const DenseArgs& a, int store, int split, hipStream_t s) {

@@ -83,17 +83,25 @@ __device__ __forceinline__ void evt_rel_terms_mfma_role(const float* __restrict_
   }
 }
 
-// block (bx, by) of a (B NKB) x ceil(H / 4) grid; `tile`: EVT_KEY_PLANE_LDS bytes
+// 16-key blocks of K9's key plane.  Without a rel-pos key grid: block kb = keys 16 kb .. 16 kb + 15.  With one (gw > 0) every
+// grid ROW starts a new block -- block kb = keys (ky, 16 xb .. 16 xb + 15) with ky = kb / ceil(gw / 16), xb = kb % ceil(gw / 16),
+// slots past the row's end are zero rows -- so that a block lies inside ONE grid row and its rel-pos terms are one row term
+// (uniform per wave) + 16 consecutive column terms (evt_attn_stream.hip, pass A).
+__host__ __device__ inline int evt_key_blocks(int N, int gh, int gw) { return gw > 0 ? gh * ((gw + 15) >> 4) : (N + 15) >> 4; }
+
+// block (bx, by) of a (B NKB) x ceil(H / 4) grid, NKB = evt_key_blocks(N, gh, gw); `tile`: EVT_KEY_PLANE_LDS bytes
 __device__ __forceinline__ void evt_split_keys_role(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D,
-                                                    int NKB, int bx, int by, uint4* tile) {
+                                                    int NKB, int gw, int bx, int by, uint4* tile) {
   constexpr int SKH = EVT_SKH, SDH = 64;
   const int b = bx / NKB, kb = bx - b * NKB;
   const int h0 = by * SKH, nh = min(SKH, H - h0);
   const int units = 16 * nh * 8;                     // (key i, head, 8-channel group c8), c8 fastest: 32 consecutive bytes each
+  const int kbr = (gw + 15) >> 4, ky = gw > 0 ? kb / kbr : 0, kx0 = gw > 0 ? (kb - ky * kbr) * 16 : 0;
   for (int u = threadIdx.x; u < units; u += 256) {
-    const int c8 = u & 7, hh = (u >> 3) % nh, i = (u >> 3) / nh, key = kb * 16 + i;
+    const int c8 = u & 7, hh = (u >> 3) % nh, i = (u >> 3) / nh;
+    const int key = gw > 0 ? ky * gw + kx0 + i : kb * 16 + i;
     bf16x8_t hi = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
-    if (key < N) {
+    if (key < N && (gw == 0 || kx0 + i < gw)) {
       const float* src = qkv + ((int64_t)b * N + key) * 3 * (int64_t)D + D + (h0 + hh) * SDH + c8 * 8;
       const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
       bf16x4_t hx, lx, hy, ly;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void stream_prep_kernel(const PrepArgs a) {
   }
   w -= a.n_rel;
   if (w < a.n_key) {
-    evt_split_keys_role(a.qkv, reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, (a.N + 15) >> 4, w % a.key_x_blocks, w / a.key_x_blocks,
+    evt_split_keys_role(a.qkv, reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, evt_key_blocks(a.N, a.gh, a.gw), a.gw, w % a.key_x_blocks, w / a.key_x_blocks,
                         reinterpret_cast<uint4*>(prep_smem));
     return;
   }
@@ -51,7 +51,7 @@ extern "C" int evt_stream_prep(const evt_stream_prep_desc* d, void* stream) {
   const size_t lds_rel = evt_rel_terms_lds(qh, d->qw, d->gh, d->gw);
   EVT_REQUIRE(lds_rel <= (size_t)EVT_LDS_PER_CU, EVT_ERR_BAD_SHAPE, "evt_stream_prep: grid %dx%d too large", qh, d->qw);
   if (d->B == 0) return EVT_OK;
-  const int nkb = (d->N + 15) / 16;
+  const int nkb = evt_key_blocks(d->N, d->gh, d->gw);
   PrepArgs a{d->qkv, d->rel_y, d->rel_x, d->terms, d->k_split, d->idx, d->count, d->v_state, d->v_delta_t, d->v_old_t,
              d->B, d->H, d->N, d->D, d->gh, d->gw, d->qw, d->kcap, 0, 0, qh + d->qw, d->B * nkb, (d->kcap + 63) / 64, d->D / 64};
   a.n_rel = a.rel_x_blocks * d->B * d->H;

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_stream_prep",
+    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_attention_dense_resident",
 )
 
 
@@ -105,7 +105,7 @@ class AttnDenseDesc(Structure):
         ("tok_map", c_void_p), ("groups_per_clip", c_int32), ("clip_rows", c_int32), ("pad_row", c_void_p),
         ("out_f32", c_void_p), ("product", c_void_p), ("a_state", c_void_p), ("pv", c_void_p),
         ("G", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("scale", c_float), ("store", c_int32),
-        ("qk_split", c_int32),
+        ("qk_split", c_int32), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
     ]
 
 
@@ -141,6 +141,10 @@ def _bind(lib):
     lib.evt_split_weights_bytes.restype = c_int64
     lib.evt_attention_stream_lds_bytes.argtypes = [c_int32, c_int32, c_int32]
     lib.evt_attention_stream_lds_bytes.restype = c_int64
+    lib.evt_attention_stream_key_blocks.argtypes = [c_int32, c_int32, c_int32]
+    lib.evt_attention_stream_key_blocks.restype = c_int64
+    lib.evt_attention_dense_resident.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
+    lib.evt_attention_dense_resident.restype = c_int
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
@@ -567,9 +571,11 @@ def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
 STREAM_PREP = os.environ.get("EVT_STREAM_PREP", "1") != "0"
 
 
-def k_split_plane(qkv, B, H, N):
-    """The key-plane workspace of evt_attention_stream / evt_stream_prep (4 KB per 16 keys and head)."""
-    return scratch("k_split", (B, H, (N + 15) // 16, 2048), torch.bfloat16, qkv.device)
+def k_split_plane(qkv, B, H, N, gh=0, gw=0):
+    """The key-plane workspace of evt_attention_stream / evt_stream_prep (4 KB per 16-key block and head; with a rel-pos key grid
+    every grid row starts a new block: evt_attention_stream_key_blocks)."""
+    blocks = int(load().evt_attention_stream_key_blocks(N, gh, gw))
+    return scratch("k_split", (B, H, blocks, 2048), torch.bfloat16, qkv.device)
 
 
 def stream_prep_fits(D, H, kcap, has_rel):
@@ -579,7 +585,7 @@ def stream_prep_fits(D, H, kcap, has_rel):
 def stream_prep(qkv, rel_y, rel_x, terms, idx, count, kcap, v_state, v_delta_t, v_old_t, B, H, N, D, gh, gw, qw, store):
     """rel-pos terms + key plane + transposed value gate of a gated frame in one launch; attention_stream(..., k_split_ready=True)
     then skips its key-plane pre-kernel."""
-    d = StreamPrepDesc(_p(qkv), _p(rel_y), _p(rel_x), _p(terms), _p(k_split_plane(qkv, B, H, N)), _p(idx), _p(count), kcap, _p(v_state),
+    d = StreamPrepDesc(_p(qkv), _p(rel_y), _p(rel_x), _p(terms), _p(k_split_plane(qkv, B, H, N, gh, gw)), _p(idx), _p(count), kcap, _p(v_state),
                        _p(v_delta_t), _p(v_old_t), B, H, N, D, gh, gw, qw, store)
     _check(load().evt_stream_prep(ctypes.byref(d), _stream()))
 
@@ -590,7 +596,7 @@ def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_te
     """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N)."""
     split = int(QK_SPLIT if qk_split is None else qk_split)
     # split arithmetic: the frame's key rows as bf16 hi / lo fragments, written by the call's pre-kernel (4 KB per 16 keys and head)
-    ksp = k_split_plane(qkv, B, H, N) if split else None
+    ksp = k_split_plane(qkv, B, H, N, *((gh, gw) if rel_terms is not None else (0, 0))) if split else None
     d = AttnStreamDesc(_p(qkv), _p(rel_terms), gh, gw, _p(a_state_t), _p(idx), _p(count), kcap, _p(v_delta_t), _p(v_old_t),
                        _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts), B, H, N, D, store, float(scale),
                        split, int(first), _p(ksp), int(bool(k_split_ready) and bool(split)))
@@ -613,12 +619,22 @@ def attention_dense_fits(N, D, H):
     return D == 64 * H and 0 < N <= 256
 
 
+def attention_dense_resident(N, D, H, store, gh=0, gw=0, qk_split=None):
+    """True when an evt_attention_dense launch of this shape without state outputs runs the resident kernel (the one that can
+    also emit the next gate's per-head delta norms, `norm_ref` / `norm_parts`).  EVT_DENSE_TILED=1 forces the tiled kernel."""
+    if D != 64 * H or os.environ.get("EVT_DENSE_TILED", "0") not in ("", "0"):
+        return False
+    return bool(load().evt_attention_dense_resident(N, gh, gw, store, int(QK_SPLIT if qk_split is None else qk_split)))
+
+
 def attention_dense(qkv, G, H, N, D, scale, store, out_f32=None, rel_y=None, rel_x=None, gh=0, gw=0, qw=0, tok_map=None,
-                    groups_per_clip=1, clip_rows=0, pad_row=None, product=None, a_state=None, pv=None, qk_split=None):
-    """K8: q.k^T + rel-pos + softmax + A.v of whole groups in one launch (scores never reach HBM)."""
+                    groups_per_clip=1, clip_rows=0, pad_row=None, product=None, a_state=None, pv=None, qk_split=None,
+                    norm_ref=None, norm_parts=None):
+    """K8: q.k^T + rel-pos + softmax + A.v of whole groups in one launch (scores never reach HBM).
+    norm_ref / norm_parts (resident kernel only): per (token, head) || out - ref ||^2 for the gate that consumes `out`."""
     d = AttnDenseDesc(_p(qkv), _p(rel_y), _p(rel_x), gh, gw, qw, _p(tok_map), groups_per_clip, clip_rows, _p(pad_row),
                       _p(out_f32), _p(product), _p(a_state), _p(pv), G, H, N, D, float(scale), store,
-                      int(QK_SPLIT if qk_split is None else qk_split))
+                      int(QK_SPLIT if qk_split is None else qk_split), _p(norm_ref), _p(norm_parts))
     es = 4 if store == EVT_F32 else 2
     work = G * (12.0 * N * D + 4.0 * N * D) + (G * H * N * N * (4.0 + es) + G * N * D * es if product is not None else 0.0)
     if product is not None:   # only the state-producing (global-block) form is part of the "attn" family

@@ -60,6 +60,10 @@ def policy_cap(gate, n_tokens):
 QK_FULL_RATIO = 0.7
 FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
 PROJ_FROM_STATE = os.environ.get("EVT_PROJ_FROM_STATE", "1") != "0"   # bf16 cast: projection reads the A.v state, no fp32 attention output
+# Windowed / dense blocks (resident K8): the same norm from K8's epilogue.  One stream: 1.84 vs 1.81 ms per 672^2 frame (the
+# epilogue's reference reads and the 12-partial selection cost what the 6 us row pass did); eight streams 6.37 vs 6.41 ms --
+# used from FUSE_DENSE_NORM_ROWS token rows per launch on (EVT_FUSE_DENSE_NORM_ROWS=0: always).
+FUSE_DENSE_NORM_ROWS = int(os.environ.get("EVT_FUSE_DENSE_NORM_ROWS", "8192"))
 REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
 # Diagnostic tap: a callable (block, gate tag, idx (B,cap) int32, count or None) invoked after every fused gate selection
 # with the DEVICE index list (scratch memory: clone to keep).  bench.py's self-check records the timed run's index sets
@@ -156,6 +160,7 @@ class Block(ExtendedModule):
         self.gelu = nn.GELU()
         self.mlp_2 = CountedLinear(in_features=dim * mlp_ratio, out_features=dim)
         self._wmap = None
+        self._norm_fusable = {}
 
     # ---------------------------------------------------------------------------------------------
     # helpers shared by all block classes
@@ -293,8 +298,10 @@ class Block(ExtendedModule):
         return x.float().contiguous(), index
 
     # -- dense attention (also the windowed attention of ViTDet's EventfulTokenwiseBlocks) -----------
-    def _attention_dense(self, qkv, B, N, out):
-        """qkv (B,N,3D) -> out (B,N,D) fp32.  Block._forward_attention (blocks.py:205-240)."""
+    def _attention_dense(self, qkv, B, N, out, norm=None):
+        """qkv (B,N,3D) -> out (B,N,D) fp32.  Block._forward_attention (blocks.py:205-240).
+        norm = (reference (B,N,D), partials (B,N,H)): the launch also emits, per token and head, || out - reference ||^2 (the
+        caller has checked `_dense_norm_fusable`: the resident K8 kernel runs)."""
         D, H = self.dim, self.heads
         dh = D // H
         sdt = self._store_dtype()
@@ -317,7 +324,8 @@ class Block(ExtendedModule):
         if self.pool_size is None and _native.attention_dense_fits(n, D, H) and _native.DENSE_FUSED:
             # K8: the whole group in one launch, no score / probability tensors in HBM
             _native.attention_dense(qkv, G, H, n, D, self.scale, store, out_f32=out, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
-                                    qw=qw, tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad)
+                                    qw=qw, tok_map=tok_map, groups_per_clip=gpc, clip_rows=N, pad_row=pad,
+                                    norm_ref=None if norm is None else norm[0], norm_parts=None if norm is None else norm[1])
             self.matmul.count_product(G * H * n * n, dh)
             if self.relative_position is not None:
                 self.relative_position.count_fused(G, H)
@@ -336,6 +344,21 @@ class Block(ExtendedModule):
         self._v_full(qkv, kv, G, n, nk, v_s, store, **win)
         _native.av(a_s, v_s, nk, G, H, n, nk, D, store, out_f32=out, out_map=tok_map, groups_per_clip=gpc, clip_rows=N)
         self.matmul.count_product(G * H * n * dh, nk)
+
+    def _dense_norm_fusable(self, N):
+        """True when `_attention_dense` runs the resident K8 kernel for this block (windowed or one group of <= 256 tokens, head dim
+        64, no pooling / ATS, planes within a CU's LDS): the kernel that can emit the next gate's per-head delta norms."""
+        if self.ats_fraction is not None or self.pool_size is not None or not _native.DENSE_FUSED:
+            return False
+        key = (N, _native.QK_SPLIT)
+        hit = self._norm_fusable.get(key)
+        if hit is None:
+            n = N if self.window_size is None else prod(self.window_size)
+            _, _, gh, gw, _ = self._rel_tables()
+            hit = _native.attention_dense_fits(n, self.dim, self.heads) and \
+                _native.attention_dense_resident(n, self.dim, self.heads, _native.store_code(self._store_dtype()), gh, gw)
+            self._norm_fusable[key] = hit
+        return hit
 
     def _dense_tail(self, attn, skip, B, N):
         """projection + skip + LN2 + MLP + skip over all tokens (Block.forward, blocks.py:127-137)."""
@@ -567,8 +590,17 @@ class EventfulTokenwiseBlock(Block):
     def _forward_attention(self, qkv, idx, count, cap, B, N):
         """-> (attention output, ATS indices or None, fused hand-over dict or None)"""
         attn = self._ws("attn_out", (B, N, self.dim), torch.float32, qkv)
-        ats = self._attention_dense(qkv, B, N, attn)
-        return (ats[0], ats[1], None) if ats is not None else (attn, None, None)
+        # The projection gate's delta norm || attn - p ||^2 comes out of the attention epilogue, per head (the select kernel adds the H
+        # partials): no separate pass over the attention output -- as in the global blocks' fused attention kernels.
+        pg = self.projection_gate
+        norm = None
+        if FUSE_PROJ_NORM and B * N >= FUSE_DENSE_NORM_ROWS and not pg.first and pg.p is not None and isinstance(pg.policy, _NormPolicy) \
+                and self._dense_norm_fusable(N):
+            norm = (pg.p, self._ws("norm_parts", (B, N, self.heads), torch.float32, qkv))
+        ats = self._attention_dense(qkv, B, N, attn, norm=norm)
+        if ats is not None:
+            return ats[0], ats[1], None
+        return attn, None, (None if norm is None else dict(norm_parts=(norm[1], self.heads), state_src=None))
 
     def forward(self, x, _defer_output=False):
         """_defer_output (ViTBackbone only, never with hooks registered): return the block output as a PendingSum."""

@@ -41,7 +41,9 @@ extern "C" {
                                  6: evt_attention_stream_lds_bytes (shape-only query; evt_attention_stream now answers
                                     EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS);
                                     evt_stream_prep + evt_attn_stream_desc.k_split_ready (rel-pos terms, key plane and value gate
-                                    of a gated frame in one launch) */
+                                    of a gated frame in one launch); evt_attn_dense_desc.norm_ref / norm_parts +
+                                    evt_attention_dense_resident (the projection gate's delta norm from the attention epilogue of
+                                    the windowed blocks) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -416,8 +418,9 @@ typedef struct evt_attn_stream_desc {
   float scale;                            /* q / scale (blocks.py:514)                                       */
   int32_t qk_split;                       /* 1 = q, k as bf16 hi + lo (3 bf16 MFMAs per product), 0 = exact fp32 MFMA */
   int32_t first;                          /* 1 = first frame of a clip                                       */
-  void* k_split;                          /* workspace, B * H * ceil(N/16) * 4096 bytes, required with qk_split: the frame's
-                                             key rows as bf16 hi / lo MFMA fragments (written by a pre-kernel of this call) */
+  void* k_split;                          /* workspace, B * H * evt_attention_stream_key_blocks(N, gh, gw) * 4096 bytes, required
+                                             with qk_split: the frame's key rows as bf16 hi / lo MFMA fragments (written by a
+                                             pre-kernel of this call) */
   int32_t k_split_ready;                  /* ABI 6: 1 = evt_stream_prep has already written k_split for this frame: no pre-kernel */
 } evt_attn_stream_desc;
 
@@ -428,6 +431,11 @@ EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
  * answer exceeds the CU's 160 KB to evt_qk + evt_softmax_av_gated (the reference ops are the same, blocks.py:506-523,558-575);
  * evt_attention_stream itself returns EVT_ERR_BAD_SHAPE for it. */
 EVT_API int64_t evt_attention_stream_lds_bytes(int32_t store, int32_t gh, int32_t gw);
+
+/* 16-key blocks (4 KB per head each) of the k_split workspace: ceil(N / 16) without a rel-pos key grid (gh = gw = 0);
+ * gh * ceil(gw / 16) with one -- every grid row starts a new block, so that a block's rel-pos terms are one row term and 16
+ * consecutive column terms (utils.py:159-172).  Shape-only; negative for N <= 0. */
+EVT_API int64_t evt_attention_stream_key_blocks(int32_t N, int32_t gh, int32_t gw);
 
 /* ABI 6.  The three preparations of a GATED frame of evt_attention_stream in ONE launch (a role per workgroup range): the rel-pos
  * terms of every query token (what evt_rel_terms writes with split = 1: utils.py:159-168), the key plane `k_split` (then pass
@@ -489,9 +497,18 @@ typedef struct evt_attn_dense_desc {
   int32_t store;
   int32_t qk_split;                       /* ABI 5: 1 = q, k and the rel-pos tables as bf16 hi + lo on the matrix cores (3 bf16  */
                                           /* MFMAs per product, ~1e-5 relative, like evt_qk split); 0 = exact fp32 products      */
+  const float* norm_ref; float* norm_parts;   /* ABI 6, nullable pair: norm_ref (B, clip_rows, D) = the reference of the gate that  */
+                                          /* consumes `out` (projection_gate.p); norm_parts (B, clip_rows, H) receives, per token   */
+                                          /* and head, sum over the head's channels of (out - ref)^2 -- evt_select_*_sq then        */
+                                          /* selects on sqrt of their sum (`c - self.p` + vector_norm, modules.py:149,               */
+                                          /* policies.py:63/:28) and no separate pass reads the attention output.  Launches that    */
+                                          /* run the resident kernel only: ask evt_attention_dense_resident first                   */
 } evt_attn_dense_desc;
 
 EVT_API int evt_attention_dense(const evt_attn_dense_desc* d, void* stream);
+/* 1 when a launch of this shape WITHOUT state outputs runs the resident kernel (one workgroup per (group, head), the group's K / V
+ * planes staged once: they must fit a CU's LDS); gh = gw = 0: no relative position.  Shape-only. */
+EVT_API int evt_attention_dense_resident(int32_t N, int32_t gh, int32_t gw, int32_t store, int32_t qk_split);
 
 #ifdef __cplusplus
 }

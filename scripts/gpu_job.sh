@@ -28,6 +28,19 @@ case $what in
     python scripts/kbench.py 2>&1 | tee $OUT/kbench.txt ;;
   kbench=*)
     python scripts/kbench.py ${what#kbench=} 2>&1 | tee -a $OUT/kbench.txt ;;
+  k9_ab)       # K9 (evt_attention_stream): this tree vs the previous commit's package + build (scripts/probes/bin/base_pkg), one
+               # stream and eight, + phase profiles (-DEVT_PROF builds)
+    BASE=$PWD/scripts/probes/bin/base_pkg
+    for b in 1 8; do
+      echo "== previous batch=$b" | tee -a $OUT/k9_ab.txt
+      EVT_PKG_ROOT=$BASE python scripts/onestream_bench.py --only stream,stream_first --batch $b 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt
+      echo "== tree batch=$b" | tee -a $OUT/k9_ab.txt
+      python scripts/onestream_bench.py --only stream,stream_first --batch $b 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt
+    done
+    echo "== previous, phase profile" | tee -a $OUT/k9_ab.txt
+    EVT_PKG_ROOT=$BASE EVT_LIB=$BASE/libevt_profbase.so python scripts/onestream_bench.py --only stream,stream_first 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt
+    echo "== tree, phase profile" | tee -a $OUT/k9_ab.txt
+    EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so python scripts/onestream_bench.py --only stream,stream_first 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt ;;
   osb)
     python scripts/onestream_bench.py 2>&1 | tee $OUT/osb.txt ;;
   dense_occ)   # K8 at ViTDet's window shape: resident kernel (both workgroup shapes) and the tiled kernel
@@ -50,6 +63,20 @@ case $what in
     python scripts/trace_summary.py $(find $OUT/t672 -name "*kernel_trace.csv" | head -1) 6000 | tee $OUT/trace_vitdet672_one_stream.txt
     python scripts/trace_summary.py $(find $OUT/t1024 -name "*kernel_trace.csv" | head -1) 3000 | tee $OUT/trace_vitdet1024_one_stream.txt
     find $OUT -name "*kernel_trace.csv" -delete ;;
+  vd_env)      # one-stream latency under runtime environment switches of the HIP graph executor
+    for env in "" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" "GPU_MAX_HW_QUEUES=1" "HIP_FORCE_DEV_KERNARG=1" "HIP_FORCE_DEV_KERNARG=0" "AMD_DIRECT_DISPATCH=0" "ROC_USE_FGS_KERNARG=0"; do
+      echo "== $env" | tee -a $OUT/vd_env.log
+      env $env python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c1-230 | tee -a $OUT/vd_env.log
+    done ;;
+  vd_batch)    # ViTDet 672^2: streams per GPU as one batch, and the windowed blocks' fused projection norm on / off
+    for fuse in 1 0; do for b in 1 8; do
+      echo "== EVT_FUSE_PROJ_NORM=$fuse batch $b" | tee -a $OUT/vd_batch.log
+      EVT_FUSE_PROJ_NORM=$fuse python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log
+    done; done
+    for b in 16 32 64; do
+      echo "== batch $b" | tee -a $OUT/vd_batch.log
+      python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log
+    done ;;
   vd)          # one-stream ViTDet latency (graph replay)
     python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log
     python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log ;;

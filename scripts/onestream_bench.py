@@ -4,7 +4,7 @@
 Each kernel is timed in a chain of `iters` back-to-back launches after a 150 ms spin (warm clock)."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "eventful-transformer_amd"))
+sys.path.insert(0, os.environ.get("EVT_PKG_ROOT") or os.path.join(ROOT, "eventful-transformer_amd"))   # EVT_PKG_ROOT: another tree's host package (A/B across an ABI change)
 import torch
 from eventful_transformer import _native as n
 
@@ -29,7 +29,9 @@ def timeit(fn, iters=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=1, help="streams per launch (the attention kernels only: --only stream,stream_first)")
     a = ap.parse_args()
+    Bn = a.batch
     only = set(a.only.split(",")) if a.only else None
     dev = torch.device("cuda", 0)
     D, H, dh = 768, 12, 64
@@ -39,23 +41,24 @@ def main():
         sdt = torch.float32 if cast is None else getattr(torch, cast)
         store = n.store_code(sdt)
         gh = N // gw
-        qkv = torch.randn(1, N, 3 * D, device=dev, generator=g)
+        qkv = torch.randn(Bn, N, 3 * D, device=dev, generator=g)
         ry = torch.randn(gh, gh, dh, device=dev, generator=g) * 0.2
         rx = torch.randn(gw, gw, dh, device=dev, generator=g) * 0.2
-        terms = torch.empty(1, H, N, gh + gw, device=dev)
-        n.rel_terms(qkv, ry, rx, 1, H, N, D, gh, gw, gw, terms)
+        terms = torch.empty(Bn, H, N, gh + gw, device=dev)
+        n.rel_terms(qkv, ry, rx, Bn, H, N, D, gh, gw, gw, terms)
         cap = N if thr else k
-        idx = torch.zeros(1, cap, dtype=torch.int32, device=dev)
-        idx[0, :k] = torch.randperm(N, device=dev, generator=g)[:k].sort()[0].int()
-        count = torch.full((1,), k, dtype=torch.int32, device=dev) if thr else None
-        apT = torch.rand(1, H, N, N, device=dev, generator=g).to(sdt)
-        vp = torch.randn(1, N, D, device=dev, generator=g).to(sdt)
-        pv = torch.randn(1, N, D, device=dev, generator=g).to(sdt)
-        o32 = torch.empty(1, N, D, device=dev)
-        vd = torch.zeros(1, D, cap, device=dev, dtype=sdt)
-        vo = torch.zeros(1, D, cap, device=dev, dtype=sdt)
-        pref = torch.randn(1, N, D, device=dev, generator=g)
-        parts = torch.empty(1, N, H, device=dev)
+        idx = torch.zeros(Bn, cap, dtype=torch.int32, device=dev)
+        for bi in range(Bn):
+            idx[bi, :k] = torch.randperm(N, device=dev, generator=g)[:k].sort()[0].int()
+        count = torch.full((Bn,), k, dtype=torch.int32, device=dev) if thr else None
+        apT = torch.rand(Bn, H, N, N, device=dev, generator=g).to(sdt)
+        vp = torch.randn(Bn, N, D, device=dev, generator=g).to(sdt)
+        pv = torch.randn(Bn, N, D, device=dev, generator=g).to(sdt)
+        o32 = torch.empty(Bn, N, D, device=dev)
+        vd = torch.zeros(Bn, D, cap, device=dev, dtype=sdt)
+        vo = torch.zeros(Bn, D, cap, device=dev, dtype=sdt)
+        pref = torch.randn(Bn, N, D, device=dev, generator=g)
+        parts = torch.empty(Bn, N, H, device=dev)
         norms = torch.rand(1, N, device=dev, generator=g)
         sel = torch.empty(1, cap, dtype=torch.int32, device=dev)
         rest = torch.empty(1, N, dtype=torch.int32, device=dev)
@@ -76,9 +79,9 @@ def main():
         hidden = torch.empty(cap, 4 * D, device=dev)
         wmap_blocks = None
         kernels = {
-            "stream": lambda: n.attention_stream(qkv, apT, pv, 1, H, N, D, 8.0, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx,
+            "stream": lambda: n.attention_stream(qkv, apT, pv, Bn, H, N, D, 8.0, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx,
                                                  count=count, kcap=cap, v_delta_t=vd, v_old_t=vo, out_f32=o32, norm_ref=pref, norm_parts=parts),
-            "stream_first": lambda: n.attention_stream(qkv, apT, pv, 1, H, N, D, 8.0, store, True, rel_terms=terms, gh=gh, gw=gw,
+            "stream_first": lambda: n.attention_stream(qkv, apT, pv, Bn, H, N, D, 8.0, store, True, rel_terms=terms, gh=gh, gw=gw,
                                                        v_state=vp, out_f32=o32),
             "rel_terms": lambda: n.rel_terms(qkv, ry, rx, 1, H, N, D, gh, gw, gw, terms),
             "v_gate_t": lambda: n.v_gate(qkv, idx, count, 1, N, D, cap, vp, vd, vo, store, True, transposed=True),
@@ -89,7 +92,7 @@ def main():
             "mlp": lambda: n.gated_mlp(c, D, idx, N, W1, b4, W2, b1, hidden, o1, D, count, p, 1, cap, D, 4 * D, W1_split=s1, W2_split=s2),
         }
         for kn, fn in kernels.items():
-            if only and kn not in only:
+            if (only and kn not in only) or (Bn > 1 and not kn.startswith("stream")):
                 continue
             us = timeit(fn)
             out[f"{name}.{kn}"] = round(us, 1)

@@ -344,10 +344,15 @@ def _vitdet_run(golden_dir, fixture, grid, policy_cls, policy_kw, cast, stream_f
     return g, bb
 
 
-def test_vitdet_672_topk(golden_dir):
+@pytest.mark.parametrize("dense_norm_rows", [None, 0])
+def test_vitdet_672_topk(golden_dir, monkeypatch, dense_norm_rows):
     """BASELINE config 3: ViTDet-B backbone 672^2 (N=1764; 8 windowed EventfulTokenwiseBlocks with 14x14
     windows + rel-pos, 4 global EventfulBlocks with rel-pos resized 64->42), top-k 256, fp32, free-running
-    against the reference's golden output slices."""
+    against the reference's golden output slices.  dense_norm_rows = 0: the windowed blocks' projection gates select on the
+    per-head norms from the resident K8 epilogue (the batched-streams path) instead of a row pass."""
+    if dense_norm_rows is not None:
+        from eventful_transformer import blocks
+        monkeypatch.setattr(blocks, "FUSE_DENSE_NORM_ROWS", dense_norm_rows)
     _vitdet_run(golden_dir, "vitdet_672.npz", 42, "TokenNormTopK", dict(k=256), None,
                 lambda steps, g: O.make_token_stream(1, 42 * 42, 768, steps, 256, seed=int(g["seed"]) + 2, small=0.01),
                 16, 1e-3)

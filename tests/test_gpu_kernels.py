@@ -664,7 +664,19 @@ def test_attention_dense_resident_vs_fp64(cast, N, rel, qk_split, B, H):
     kw = dict(rel_y=ry.to(DEV), rel_x=rx.to(DEV), gh=side, gw=side, qw=side) if rel else {}
     qd = qkv.to(DEV)
     out = torch.full((B, N, D), float("nan"), device=DEV)
-    n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out, qk_split=qk_split, **kw)
+    assert n.attention_dense_resident(N, D, H, store, side if rel else 0, side if rel else 0, qk_split=qk_split)
+    ref_next = torch.randn(B, N, D, generator=g).to(DEV)      # stands for the projection gate's reference
+    parts = torch.full((B, N, H), float("nan"), device=DEV)
+    n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out, qk_split=qk_split, norm_ref=ref_next, norm_parts=parts, **kw)
+    # fused delta norm: per-head ||out - ref||^2, and the selection from those partials == the selection from the norms
+    want_parts = (out - ref_next).view(B, N, H, dh).pow(2).sum(-1)
+    assert torch.allclose(parts, want_parts, rtol=1e-5, atol=1e-6), float((parts - want_parts).abs().max())
+    kk_sel = max(1, N // 3)
+    i1 = torch.empty(B, kk_sel, dtype=torch.int32, device=DEV)
+    i2 = torch.empty(B, kk_sel, dtype=torch.int32, device=DEV)
+    n.select_topk(want_parts.sum(-1).sqrt().contiguous(), B, N, kk_sel, i1)
+    n.select_topk(parts, B, N, kk_sel, i2, parts=H)
+    assert torch.equal(i1, i2) or float((parts - want_parts).abs().max()) > 0
     # split arithmetic with an fp32 store type also runs P.V as bf16 hi / lo products (~1e-5 relative)
     tol = {None: 2e-5 if not qk_split else 2e-4, "bfloat16": 1.6e-2, "float16": 2e-3}[cast]
     err = float((out.cpu() - want).abs().max())
@@ -673,6 +685,8 @@ def test_attention_dense_resident_vs_fp64(cast, N, rel, qk_split, B, H):
     pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
     n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out_t, pv=pv, qk_split=qk_split, **kw)   # a state output: tiled kernel
     assert float((out - out_t).abs().max()) <= tol
+    with pytest.raises(RuntimeError, match="resident kernel only"):
+        n.attention_dense(qd, B, H, N, D, scale, store, out_f32=out_t, pv=pv, qk_split=qk_split, norm_ref=ref_next, norm_parts=parts, **kw)
 
 
 def test_attention_dense_windowed_block_matches_chain():
@@ -811,7 +825,7 @@ def test_stream_prep_matches_the_three_launches(cast, N, gw, k, counted):
             n.v_gate(qkv, idx, count, B, N, D, cap, vp, vd, vo, store, True, transposed=True)
         n.attention_stream(qkv, apT, pv, B, H, N, D, scale, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx, count=count, kcap=cap,
                            v_delta_t=vd, v_old_t=vo, out_f32=out, norm_ref=pref, norm_parts=parts, k_split_ready=prep)
-        kplane = n.k_split_plane(qkv, B, H, N).clone()
+        kplane = n.k_split_plane(qkv, B, H, N, gh, gw).clone()
         res.append([t.cpu() for t in (terms, vd[..., :k], vo[..., :k], vp, kplane.view(torch.int16), apT, pv, out, parts)])
     for name, a_, b_ in zip(("terms", "v_delta", "v_old", "v_state", "key plane", "a_state_t", "pv", "out", "norm_parts"), res[0], res[1]):
         assert torch.equal(a_.view(torch.uint8) if a_.dtype == torch.bfloat16 else a_, b_.view(torch.uint8) if b_.dtype == torch.bfloat16 else b_), name
@@ -820,6 +834,7 @@ def test_stream_prep_matches_the_three_launches(cast, N, gw, k, counted):
 
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
                                              (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True),
+                                             ("bfloat16", 512, 64, 100, True), (None, 350, 70, 60, True),
                                              ("bfloat16", 197, 197, 128, False), (None, 262, 131, 77, False)])
 @pytest.mark.parametrize("qk_split", [0, 1])
 def test_attention_stream_matches_oracle(cast, N, gw, k, rel, qk_split):

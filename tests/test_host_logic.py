@@ -42,6 +42,9 @@ def test_abi_argument_errors_without_gpu():
         assert 0 < lib.evt_attention_stream_lds_bytes(store, 64, 64) <= _native.LDS_PER_CU
     assert lib.evt_attention_stream_lds_bytes(_native.EVT_F32, 1000, 1000) > _native.LDS_PER_CU
     assert lib.evt_attention_stream_lds_bytes(7, 8, 8) < 0
+    # key plane: 16-key blocks; with a rel-pos key grid every grid row starts a new block
+    assert lib.evt_attention_stream_key_blocks(197, 0, 0) == 13 and lib.evt_attention_stream_key_blocks(1764, 42, 42) == 42 * 3
+    assert lib.evt_attention_stream_key_blocks(4096, 64, 64) == 256 and lib.evt_attention_stream_key_blocks(0, 0, 0) < 0
     assert not _native.attention_stream_fits(1000000, 768, 12, _native.EVT_F32, 1000, 1000)
     assert _native.attention_stream_fits(4096, 768, 12, _native.EVT_BF16, 64, 64)
 
