@@ -65,6 +65,10 @@ template <> struct Quad<float> { union { float4 v; float t[4]; }; };
 
 constexpr int SDH = 64;   // head dim
 
+#ifndef EVT_K9_ABLATE   // timing experiments only (results are wrong), a bit mask: 1 no reference stores, 2 no old-reference loads,
+#define EVT_K9_ABLATE 0 // 4 no V piece loads, 8 no rel-pos terms in the selected-column pass, 16 no statistics pass, 32 no key loads in it
+#endif
+
 // 16 rows x 16 channels += A-tile rows (16 x k) . V^T-tile rows (16 channels x k) over the k range [KB, KB + KLEN) of a chunk.
 // a: first element of this lane's tile row (row l15 of the group), b: of this lane's channel row; kg = lane >> 4.
 template <typename T> struct Sweep16;
@@ -107,6 +111,38 @@ template <> struct Sweep16<float> {
     return acc;
   }
 };
+
+// fp32 store type in split mode: the same sweep as bf16 hi / lo products (three v_mfma_f32_16x16x32_bf16 per 32 k instead of
+// eight v_mfma_f32_16x16x4_f32 at a sixteenth of the rate: 48 vs 256 matrix-core cycles), both operands split into hi / lo while
+// their fragments are loaded (8 consecutive k per lane: two 16-byte LDS reads; 16 lanes = 16 rows at the fp32 pitch cover all
+// banks), like the scores and like the resident K8 kernel's P.V.  NR row groups x 2 channel groups per call.
+template <int NR, int KB, int KLEN>
+__device__ __forceinline__ void sweep_split_f32(const float* a, int a_step, const float* b, int b_step, int kg, f32x4_acc (*acc)[2]) {
+#pragma unroll
+  for (int kk = KB; kk < KB + KLEN; kk += 32) {
+    bf16x8_t ah[NR], al[NR], bh[2], bl[2];
+    auto frag = [&](const float* p, bf16x8_t* hi, bf16x8_t* lo) __attribute__((always_inline)) {
+      const float4 u = *reinterpret_cast<const float4*>(p + kk + 8 * kg), v = *reinterpret_cast<const float4*>(p + kk + 8 * kg + 4);
+      bf16x4_t h0, l0, h1, l1;
+      split4(u, &h0, &l0);
+      split4(v, &h1, &l1);
+      *hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int hr = 0; hr < NR; ++hr) frag(a + hr * a_step, &ah[hr], &al[hr]);
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) frag(b + cg * b_step, &bh[cg], &bl[cg]);
+#pragma unroll
+    for (int hr = 0; hr < NR; ++hr)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        acc[hr][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[hr], bl[cg], acc[hr][cg], 0, 0, 0);
+        acc[hr][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[hr], bh[cg], acc[hr][cg], 0, 0, 0);
+        acc[hr][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[hr], bh[cg], acc[hr][cg], 0, 0, 0);
+      }
+  }
+}
 
 // Key rows of the frame as bf16 hi / lo MFMA fragments in FRAGMENT-MAJOR order, once per launch (QK == 2).
 // Why.  Ablation builds of the statistics pass at 1024^2 (N = 4096; whole launch 231 us): without the (max, exp, sum)
@@ -211,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps): a gather
     if (QK == 2) {
       int pos = j;   // slot of key j in the plane: grid rows start new blocks
-      if (rel) { const int ky = fast_div(j, inv_gw); pos = ky * (KBR * 16) + (j - ky * a.gw); }
+      if (rel) { const int ky = fast_div(j, inv_gw); pos = (int)evt_mul24(ky, KBR * 16) + (j - (int)evt_mul24(ky, a.gw)); }
       const uint4* kp = ksp + (int64_t)(pos >> 4) * 256 + kg * 16 + (pos & 15);
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
@@ -297,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
           sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].w, qf[hr][p_].w, sacc[hr], 0, 0, 0);
         }
     } else {
+      // (Separate accumulators for the two channel halves, 2 NHR independent chains of three MFMAs instead of NHR of six, measured
+      // SLOWER: 1185 vs 1133 us for eight 1024^2 streams -- dependent MFMAs on one accumulator forward their result.)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const bf16x8_t kh = __builtin_bit_cast(bf16x8_t, kf[2 * m]), kl = __builtin_bit_cast(bf16x8_t, kf[2 * m + 1]);
@@ -319,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     for (int r = 0; r < 4; ++r) {
       const int ky = fast_div(js[r], inv_gw);
       oy[r] = ky;
-      ox[r] = TYP + js[r] - ky * a.gw;
+      ox[r] = TYP + js[r] - (int)evt_mul24(ky, a.gw);
     }
     if (QK == 2) {
 #pragma unroll
@@ -353,16 +391,23 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   int ky0 = 0, kx0 = 0;                                                    // of key 16 wave + 4 kg of the current chunk
   if (rel) { const int j0 = wave * 16 + 4 * kg; ky0 = fast_div(j0, inv_gw); kx0 = j0 - ky0 * a.gw; }
   constexpr float L2E = 1.44269504088896340736f;
-  // (max, sum) update of row group hr by 4 scores of ONE row: one rescale of the running sum per group, one exponential per
-  // score, the subtraction of the maximum folded into the exponent's multiply (exp2(x log2e - max log2e))
-  auto group = [&](int hr, const float* x) __attribute__((always_inline)) {
-    const float nm = fmaxf(rm[hr], fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));   // finite: rm starts at -1e30
-    const float nml = -nm * L2E;
-    const float part = (__builtin_amdgcn_exp2f(fmaf(x[0], L2E, nml)) + __builtin_amdgcn_exp2f(fmaf(x[1], L2E, nml))) +
-                       (__builtin_amdgcn_exp2f(fmaf(x[2], L2E, nml)) + __builtin_amdgcn_exp2f(fmaf(x[3], L2E, nml)));
-    // (the rescale factor from the difference: with rm = nm = -1e30, nothing seen yet, rm log2e + nml is a rounding error of 1e22)
-    rsum[hr] = fmaf(rsum[hr], __builtin_amdgcn_exp2f((rm[hr] - nm) * L2E), part);
-    rm[hr] = nm;
+  // (max, sum) update of the tile's rows by a chunk's scores, 4 scores of ONE row per row group: one rescale of the running sum
+  // per 4 scores, one exponential per score, everything in log2 units (ref2 = running maximum x log2e) so that the subtraction of
+  // the maximum is the exponent's fma.  Measured and not kept: a lazily raised REFERENCE instead of the exact maximum (raised only
+  // when a score exceeds it by more than 8: no fifth exponential, 40 instead of 52 VALU instructions per chunk and wave, one
+  // wave-uniform branch) -- within noise, the pass is not bound by its VALU instruction count (1024^2, eight streams: 1201 vs 1185 us).
+  float ref2[NHR];
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) ref2[hr] = rm[hr] * L2E;
+  auto update = [&](const float (*x)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr) {
+      const float nref = fmaxf(ref2[hr], fmaxf(fmaxf(x[hr][0], x[hr][1]), fmaxf(x[hr][2], x[hr][3])) * L2E);   // finite: starts at -1e30 log2e
+      const float part = (__builtin_amdgcn_exp2f(fmaf(x[hr][0], L2E, -nref)) + __builtin_amdgcn_exp2f(fmaf(x[hr][1], L2E, -nref))) +
+                         (__builtin_amdgcn_exp2f(fmaf(x[hr][2], L2E, -nref)) + __builtin_amdgcn_exp2f(fmaf(x[hr][3], L2E, -nref)));
+      rsum[hr] = fmaf(rsum[hr], __builtin_amdgcn_exp2f(ref2[hr] - nref), part);
+      ref2[hr] = nref;
+    }
   };
   // Split mode with a rel-pos grid: the wave's 16-key block lies inside ONE grid row of the key plane -- its grid row gky and
   // column block gxb are wave-uniform (scalar registers, advanced by 4 blocks per chunk), the row term is one LDS word and the
@@ -371,25 +416,36 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   // arithmetic and the masks.
   int gky = 0, gxb = 0, sdy = 0, sdx = 0;
   if (QK == 2 && rel) { gky = wave / KBR; gxb = wave - gky * KBR; sdy = 4 / KBR; sdx = 4 - sdy * KBR; }
-  auto stats_grid = [&](const float4* kf) __attribute__((always_inline)) {
-    f32x4_acc sacc[NHR];
+  // The terms of a chunk are REQUESTED A CHUNK AHEAD (behind the score MFMAs' issue, in front of the previous chunk's (max, exp,
+  // sum) instructions): they are the accumulators' starting value, i.e. the first thing a chunk needs, and an LDS round trip
+  // in front of every chunk's MFMAs is not hidden by two waves per SIMD (1-2 % of the launch).
+  float nty[NHR];
+  float4 ntx[NHR];
+  auto request_terms = [&]() __attribute__((always_inline)) {
     const int tyo = min(gky, a.gh), txo = TYP + 16 * gxb + 4 * kg;
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
       const float* rv = relv + (16 * hr + l15) * RP;
-      const float ty = rv[tyo];
-      const float4 tx = *reinterpret_cast<const float4*>(rv + txo);
-      sacc[hr] = (f32x4_acc){ty + tx.x, ty + tx.y, ty + tx.z, ty + tx.w};
+      nty[hr] = rv[tyo];
+      ntx[hr] = *reinterpret_cast<const float4*>(rv + txo);
     }
-    scores(kf, sacc, true);
     gxb += sdx;
     gky += sdy;
     if (gxb >= KBR) { gxb -= KBR; ++gky; }
+  };
+  if (QK == 2 && rel) request_terms();
+  auto stats_grid = [&](const float4* kf) __attribute__((always_inline)) {
+    f32x4_acc sacc[NHR];
 #pragma unroll
-    for (int hr = 0; hr < NHR; ++hr) {
-      const float x[4] = {sacc[hr][0], sacc[hr][1], sacc[hr][2], sacc[hr][3]};
-      group(hr, x);
-    }
+    for (int hr = 0; hr < NHR; ++hr) sacc[hr] = (f32x4_acc){nty[hr] + ntx[hr].x, nty[hr] + ntx[hr].y, nty[hr] + ntx[hr].z, nty[hr] + ntx[hr].w};
+    scores(kf, sacc, true);
+    request_terms();
+    float x[NHR][4];
+#pragma unroll
+    for (int hr = 0; hr < NHR; ++hr)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[hr][r] = sacc[hr][r];
+    update(x);
   };
   auto stats = [&](int c0, const float4* kf, const bool mask) __attribute__((always_inline)) {
     if (QK == 2 && rel) { stats_grid(kf); return; }
@@ -415,28 +471,43 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       ky0 += cdy;
       if (kx0 >= a.gw) { kx0 -= a.gw; ++ky0; }
     }
+    float x[NHR][4];
 #pragma unroll
-    for (int hr = 0; hr < NHR; ++hr) {
-      // 4 scores of ONE row: one rescale of the running sum per group, one exponential per score
-      float x[4];
+    for (int hr = 0; hr < NHR; ++hr)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[r] = (!mask || jb + r < a.N) ? sacc[hr][r] : -INFINITY;
-      group(hr, x);
-    }
+      for (int r = 0; r < 4; ++r) x[hr][r] = (!mask || jb + r < a.N) ? sacc[hr][r] : -INFINITY;
+    update(x);
   };
   // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
   {
+#if EVT_K9_ABLATE & 16
+    const int NS = 128;
+#else
     const int NS = (QK == 2 && rel) ? NKB * 16 : a.N;   // slots to stream (the key plane's, with a rel-pos grid)
+#endif
     int c0 = 0;
     for (; c0 + 128 <= NS; c0 += 128) {   // whole chunk pairs: no masks
       stats(c0, kA, false);
+#if !(EVT_K9_ABLATE & 32)   // (32: the key fragments of the first two chunks again and again)
       load_chunk(c0 + 128, kA);
+#endif
       stats(c0 + 64, kB, false);
+#if !(EVT_K9_ABLATE & 32)
       load_chunk(c0 + 192, kB);
+#endif
     }
     if (c0 < NS) stats(c0, kA, true);          // the last (partial) pair: its fragments were requested above / in the prologue
     if (c0 + 64 < NS) stats(c0 + 64, kB, true);
+  }
+#pragma unroll
+  for (int hr = 0; hr < NHR; ++hr) {
+    // The combine works in natural units.  The product is PINNED: contracted into the combine's "m - M" as fma(ref2, ln2, -M), with
+    // M the ROUNDED product of a lane that has seen no key (reference -1e30: the never-valid key slots of a narrow grid), the
+    // difference is the product's rounding error, ~1e22, and exp2 of it is inf or 0 -- 0 x inf = NaN in every row of the tile.
+    float v = ref2[hr] * 0.69314718055994530942f;
+    asm volatile("" : "+v"(v));
+    rm[hr] = v;
   }
   bool rok[NHR];   // query row 16 hr + l15 of the tile exists
 #pragma unroll
@@ -468,12 +539,27 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     }
     return q;
   };
+  // element (key j, row i) of this head's reference: a 32-bit byte offset from the head's (wave-uniform) base -- the launcher
+  // checks N^2 sizeof(T) < 2^32 -- so that an access is one 24-bit multiply, one add and a scalar-base load / store instead of
+  // 64-bit address arithmetic per element
+  auto st_at = [&](uint32_t col_off, int i) __attribute__((always_inline)) -> T* {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(stT) + (col_off + (uint32_t)i * (uint32_t)sizeof(T)));
+  };
   auto request_old = [&](const Cols& q, T (*old)[4]) __attribute__((always_inline)) {   // old reference values of the lane's 4 columns
+    uint32_t co[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) co[r] = evt_mul24(q.g[r] >= 0 ? q.g[r] : 0, a.N * (int)sizeof(T));
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
       const int i = rok[hr] ? i0 + 16 * hr + l15 : 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) old[hr][r] = stT[(int64_t)(q.g[r] >= 0 ? q.g[r] : 0) * a.N + i];
+      for (int r = 0; r < 4; ++r) {
+#if EVT_K9_ABLATE & 2
+        Store<T>::store(&old[hr][r], (float)(co[r] + i) * 1e-9f);
+#else
+        old[hr][r] = *st_at(co[r], i);
+#endif
+      }
     }
   };
   auto load_v = [&](int k0, uint4* pd, uint4* po) __attribute__((always_inline)) {   // chunk k0 of dv~^T / v_old^T -> registers (branch-free, clamped)
@@ -483,7 +569,11 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kv = k0 + jj;
       const bool in = kv < a.kcap;
       const int64_t o = (int64_t)d * a.kcap + (in ? kv : 0);
+#if EVT_K9_ABLATE & 4
+      const uint4 xd = make_uint4((unsigned)o, 0, 0, 0), xo = xd;
+#else
       const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+#endif
       pd[it] = in ? xd : make_uint4(0, 0, 0, 0);
       po[it] = in ? xo : make_uint4(0, 0, 0, 0);
     }
@@ -574,7 +664,12 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   };
   typedef Quad<T> QuadT;
   // both accumulator products of the chunk staged in LDS: rows of a~ / da~ (A operand) x channels of dv~^T / v_old^T (B)
+  constexpr bool SWEEP_SPLIT = QK == 2 && sizeof(T) == 4;   // fp32 store type, split arithmetic: bf16 hi / lo sweeps
   auto sweep = [&](const T* At, const T* Vt) __attribute__((always_inline)) {
+    if constexpr (SWEEP_SPLIT) {
+      sweep_split_f32<NHR, 0, FKC>(reinterpret_cast<const float*>(At) + l15 * P, 16 * P, reinterpret_cast<const float*>(Vt) + (32 * half + l15) * P, 16 * P, kg, acc);
+      return;
+    }
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr)
 #pragma unroll
@@ -619,6 +714,12 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       for (int q = 0; q < 16; ++q) Vd[(vc0 + q) * P + vkey] = vj < a.N ? vv.t[q] : z;
       __syncthreads();
       // keys 0..31 of the chunk on waves 0, 1, keys 32..63 on waves 2, 3 (summed unrounded in the epilogue)
+      if constexpr (SWEEP_SPLIT) {
+        const float* At = reinterpret_cast<const float*>(An) + l15 * P;
+        const float* Vt = reinterpret_cast<const float*>(Vd) + (32 * half + l15) * P;
+        if (psel == 0) sweep_split_f32<NHR, 0, 32>(At, 16 * P, Vt, 16 * P, kg, acc);
+        else sweep_split_f32<NHR, 32, 32>(At, 16 * P, Vt, 16 * P, kg, acc);
+      } else
 #pragma unroll
       for (int hr = 0; hr < NHR; ++hr)
 #pragma unroll
@@ -683,28 +784,45 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     int js[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) js[r] = q.g[r] >= 0 ? q.g[r] : 0;
+#if EVT_K9_ABLATE & 8
+    scores(kf, sacc);
+#else
     scores_rel(kf, sacc, js);
+#endif
     const bool full = tile_full && k0 + FKC <= cnt;
+    uint32_t co[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) co[r] = evt_mul24(js[r], a.N * (int)sizeof(T));
+    T zero_t;
+    Store<T>::store(&zero_t, 0.f);
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr) {
-      QuadT nw, dl;
-      float anv[4];
+      QuadT nw, dl;   // a~ and da~ of the lane's 4 columns, rounded to the store type (modules.py:187-201), four at a time
+      float e[4], an[4], d[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = rok[hr] && q.g[r] >= 0;
-        const float an = Store<T>::round(fast_exp(sacc[hr][r] - fm[hr]) * fi[hr]);
-        const float ad = Store<T>::round(an - Store<T>::load(&old[hr][r]));
-        anv[r] = an;
-        Store<T>::store(&nw.t[r], ok ? an : 0.f);
-        Store<T>::store(&dl.t[r], ok ? ad : 0.f);
-      }
+      for (int r = 0; r < 4; ++r) e[r] = fast_exp(sacc[hr][r] - fm[hr]) * fi[hr];
+      Store<T>::round4(e, nw.t, an);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = an[r] - Store<T>::load(&old[hr][r]);
+      Store<T>::round4(d, dl.t, nullptr);
+#if EVT_K9_ABLATE & 1
+      if (a.N < 0) {   // never
+#else
       if (full) {
+#endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Store<T>::store(stT + (int64_t)js[r] * a.N + i0 + 16 * hr + l15, anv[r]);
+        for (int r = 0; r < 4; ++r) *st_at(co[r], i0 + 16 * hr + l15) = nw.t[r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (rok[hr] && q.g[r] >= 0) Store<T>::store(stT + (int64_t)q.g[r] * a.N + i0 + 16 * hr + l15, anv[r]);
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rok[hr] && q.g[r] >= 0;
+#if EVT_K9_ABLATE & 1
+          if (!ok) { nw.t[r] = zero_t; dl.t[r] = zero_t; }
+#else
+          if (ok) *st_at(co[r], i0 + 16 * hr + l15) = nw.t[r];
+          else { nw.t[r] = zero_t; dl.t[r] = zero_t; }
+#endif
+        }
       }
       *reinterpret_cast<decltype(nw.v)*>(An + (16 * hr + l15) * P + wave * 16 + 4 * kg) = nw.v;
       *reinterpret_cast<decltype(dl.v)*>(Ad + (16 * hr + l15) * P + wave * 16 + 4 * kg) = dl.v;
@@ -912,6 +1030,7 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
   EVT_REQUIRE(d->B >= 0 && d->H > 0 && d->N > 0 && d->D == d->H * 64, EVT_ERR_BAD_SHAPE,
               "evt_attention_stream: head dim 64 required (B=%d H=%d N=%d D=%d)", d->B, d->H, d->N, d->D);
   EVT_REQUIRE(d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_attention_stream: scale must be positive");
+  EVT_REQUIRE(d->N <= 32767, EVT_ERR_BAD_SHAPE, "evt_attention_stream: N=%d (32-bit byte offsets into a head's N x N reference: N <= 32767)", d->N);
   EVT_REQUIRE(d->rel_terms == nullptr || (d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N), EVT_ERR_BAD_SHAPE,
               "evt_attention_stream: rel-pos key grid %dx%d does not match N=%d", d->gh, d->gw, d->N);
   EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_attention_stream: norm_ref / norm_parts come together");

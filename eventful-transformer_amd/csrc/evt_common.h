@@ -137,22 +137,47 @@ __device__ __forceinline__ float bf16_round_bits(float x, uint16_t* out) {
   return __uint_as_float(c.u << 16);
 }
 
+// round4: four values rounded at once, `out` = the stored elements (consecutive: an LDS tile quad), `back` (nullable) = the
+// rounded values widened again.  bf16: two packed conversions for the four (round + store + round-again of one value at a
+// time converted every element three times: 34 of the ~300 VALU instructions of a K9 gate chunk).
 template <typename T> struct Store;
 template <> struct Store<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }
   static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
   static __device__ __forceinline__ float round(float v) { return v; }
+  static __device__ __forceinline__ void round4(const float* x, float* out, float* back) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { out[r] = x[r]; if (back) back[r] = x[r]; }
+  }
 };
 template <> struct Store<bf16_t> {
   static __device__ __forceinline__ float load(const bf16_t* p) { return __uint_as_float(((uint32_t)p->u) << 16); }
   static __device__ __forceinline__ void store(bf16_t* p, float v) { uint16_t b; bf16_round_bits(v, &b); p->u = b; }
   static __device__ __forceinline__ float round(float v) { uint16_t b; return bf16_round_bits(v, &b); }
+  static __device__ __forceinline__ void round4(const float* x, bf16_t* out, float* back) {
+    union { evt_bf16x2_t b; uint32_t u; } c0, c1;
+    c0.b = __builtin_convertvector((evt_f32x2_t){x[0], x[1]}, evt_bf16x2_t);
+    c1.b = __builtin_convertvector((evt_f32x2_t){x[2], x[3]}, evt_bf16x2_t);
+    out[0].u = (uint16_t)c0.u; out[1].u = (uint16_t)(c0.u >> 16);
+    out[2].u = (uint16_t)c1.u; out[3].u = (uint16_t)(c1.u >> 16);
+    if (back) {
+      back[0] = __uint_as_float(c0.u << 16); back[1] = __uint_as_float(c0.u & 0xffff0000u);
+      back[2] = __uint_as_float(c1.u << 16); back[3] = __uint_as_float(c1.u & 0xffff0000u);
+    }
+  }
 };
 template <> struct Store<f16_t> {
   static __device__ __forceinline__ float load(const f16_t* p) { return (float)p->h; }
   static __device__ __forceinline__ void store(f16_t* p, float v) { p->h = (_Float16)v; }
   static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+  static __device__ __forceinline__ void round4(const float* x, f16_t* out, float* back) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { out[r].h = (_Float16)x[r]; if (back) back[r] = (float)out[r].h; }
+  }
 };
+// a * b for 0 <= a, b < 2^24 with a product below 2^32 (token index x row length): v_mul_u32_u24 is a full-rate instruction,
+// the 32-bit integer multiply a quarter-rate one
+__device__ __forceinline__ uint32_t evt_mul24(int a, int b) { return __umul24((uint32_t)a, (uint32_t)b); }
 
 // Dispatch a callable templated on the storage type.
 #define EVT_DISPATCH_STORE(store, T, ...)                                  \

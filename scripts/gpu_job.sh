@@ -15,6 +15,10 @@ case $what in
   tests_x)     # stop at the first failure
     EVT_PARITY_SUMMARY=$PWD/$OUT/parity_summary.txt timeout 1500 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1
     tail -40 $OUT/pytest.log ;;
+  tests_lib=*) # a subset against another build: tests_lib=<variant>:<pytest -k expression>
+    spec=${what#tests_lib=}; v=${spec%%:*}; k=${spec#*:}
+    EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so timeout 1200 python -m pytest tests -m gpu -q -x -k "$k" > $OUT/pytest_$v.log 2>&1
+    tail -5 $OUT/pytest_$v.log ;;
   tests_k=*)   # a subset: tests_k=<pytest -k expression>
     EVT_PARITY_SUMMARY=$PWD/$OUT/parity_summary.txt timeout 1200 python -m pytest tests -m gpu -q -k "${what#tests_k=}" > $OUT/pytest_k.log 2>&1
     tail -40 $OUT/pytest_k.log ;;
@@ -41,6 +45,22 @@ case $what in
     EVT_PKG_ROOT=$BASE EVT_LIB=$BASE/libevt_profbase.so python scripts/onestream_bench.py --only stream,stream_first 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt
     echo "== tree, phase profile" | tee -a $OUT/k9_ab.txt
     EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so python scripts/onestream_bench.py --only stream,stream_first 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_ab.txt ;;
+  k9_var)      # K9 build variants: k9_var (uses scripts/probes/bin/libevt_<v>.so for v in $K9_VARIANTS)
+    for v in tree ${K9_VARIANTS:-k9lazy0 k9ahead0}; do
+      echo "== $v" | tee -a $OUT/k9_var.txt
+      for b in 1 8; do
+        if [ $v = tree ]; then python scripts/onestream_bench.py --only stream --batch $b; else EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so python scripts/onestream_bench.py --only stream --batch $b; fi 2>&1 | grep -v amdgpu.ids | sed "s/^/batch $b  /" | tee -a $OUT/k9_var.txt
+      done
+    done
+    EVT_LIB=$PWD/scripts/probes/bin/libevt_prof.so python scripts/onestream_bench.py --only stream 2>&1 | grep -v amdgpu.ids | tee -a $OUT/k9_var.txt ;;
+  k9_ablate)   # K9 timing ablations (scripts/build_variant.sh k9a<mask> -DEVT_K9_ABLATE=<mask>): what the gated launch pays for
+    python eventful-transformer_amd/build.py > /dev/null
+    echo "== tree" | tee -a $OUT/k9_ablate.txt
+    for b in 1 8; do python scripts/onestream_bench.py --only stream --batch $b 2>&1 | grep -v amdgpu.ids | sed "s/^/batch $b  /" | tee -a $OUT/k9_ablate.txt; done
+    for m in 1 2 3 4 8 15 16; do
+      echo "== EVT_K9_ABLATE=$m" | tee -a $OUT/k9_ablate.txt
+      for b in 1 8; do EVT_LIB=$PWD/scripts/probes/bin/libevt_k9a$m.so python scripts/onestream_bench.py --only stream --batch $b 2>&1 | grep -v amdgpu.ids | sed "s/^/batch $b  /" | tee -a $OUT/k9_ablate.txt; done
+    done ;;
   osb)
     python scripts/onestream_bench.py 2>&1 | tee $OUT/osb.txt ;;
   dense_occ)   # K8 at ViTDet's window shape: resident kernel (both workgroup shapes) and the tiled kernel

@@ -834,13 +834,14 @@ def test_stream_prep_matches_the_three_launches(cast, N, gw, k, counted):
 
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
                                              (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True),
-                                             ("bfloat16", 512, 64, 100, True), (None, 350, 70, 60, True),
+                                             ("bfloat16", 512, 64, 100, True), (None, 350, 70, 60, True), (None, 280, 20, 50, True),
                                              ("bfloat16", 197, 197, 128, False), (None, 262, 131, 77, False)])
 @pytest.mark.parametrize("qk_split", [0, 1])
 def test_attention_stream_matches_oracle(cast, N, gw, k, rel, qk_split):
     """evt_attention_stream (N > 256, scores computed in the kernel, TRANSPOSED gate reference): first frame + 3 gated
     frames against the oracle's softmax / delta gates / accumulator on the same token buffers -- incl. a device-side
-    count < kcap, rel-pos terms from evt_rel_terms, a partial last row tile (N % 32 != 0), odd token counts (ViViT's 197) and the fused per-head
+    count < kcap, rel-pos terms from evt_rel_terms, a partial last row tile (N % 32 != 0), odd token counts (ViViT's 197), grids whose
+    rows end early in a 16-key block (gw = 18, 20: lanes of the statistics pass that never see a valid key) and the fused per-head
     ||out - ref||^2 partials."""
     n = native()
     B, H, dh, scale = 2, 2, 64, 8.0
