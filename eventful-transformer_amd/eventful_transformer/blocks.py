@@ -119,12 +119,8 @@ class Block(ExtendedModule):
         super().__init__()
         if ats_fraction is not None:
             assert not (ats_fraction < 0.0 or ats_fraction > 1.0)
-            if pool_size is not None or window_size is not None:
-                raise NotImplementedError("ats_fraction together with pool_size / window_size is not built in the MI355X "
-                                          "path (the reference's ATS configs use neither)")
-        if pool_size is not None and window_size is not None:
-            raise NotImplementedError("pool_size together with window_size is not built in the MI355X path "
-                                      "(the reference's configs pool only the global blocks)")
+            # the reference asserts the same (blocks.py:71-73)
+            assert pool_size is None and window_size is None, "ats_fraction excludes pool_size and window_size"
         assert not (drop_path_rate < 0.0 or drop_path_rate > 1.0)
         assert matmul_2_cast in [None, "float16", "bfloat16"]
         self.dim = dim
@@ -160,6 +156,7 @@ class Block(ExtendedModule):
         self.gelu = nn.GELU()
         self.mlp_2 = CountedLinear(in_features=dim * mlp_ratio, out_features=dim)
         self._wmap = None
+        self._wpool_index = None
         self._norm_fusable = {}
 
     # ---------------------------------------------------------------------------------------------
@@ -321,6 +318,8 @@ class Block(ExtendedModule):
             if self.relative_position is not None:
                 self.relative_position.count_fused(B, H)
             return self._ats_attention(prod_s, qkv, B, N, eventful=False)
+        if self.pool_size is not None and self.window_size is not None:
+            return self._attention_window_pooled(qkv, B, N, out, tok_map)
         if self.pool_size is None and _native.attention_dense_fits(n, D, H) and _native.DENSE_FUSED:
             # K8: the whole group in one launch, no score / probability tensors in HBM
             _native.attention_dense(qkv, G, H, n, D, self.scale, store, out_f32=out, rel_y=ry, rel_x=rx, gh=gh, gw=gw,
@@ -344,6 +343,49 @@ class Block(ExtendedModule):
         self._v_full(qkv, kv, G, n, nk, v_s, store, **win)
         _native.av(a_s, v_s, nk, G, H, n, nk, D, store, out_f32=out, out_map=tok_map, groups_per_clip=gpc, clip_rows=N)
         self.matmul.count_product(G * H * n * dh, nk)
+
+    def _attention_window_pooled(self, qkv, B, N, out, tok_map):
+        """window_size together with pool_size (Block._forward_attention, blocks.py:205-240: `_partition_windows` in the qkv domain,
+        then `_pool_tokens` on the WINDOW grid, blocks.py:308).  No reference config uses the combination, so it is kept simple:
+        the windows are gathered into contiguous groups (padding tokens = the qkv bias row, blocks.py:270-283; index ops on the
+        device), every window is pooled like a small clip (evt_pool_kv) and runs through the q.k^T / softmax / A.v launches with
+        pooled keys; the rows are copied back to their tokens."""
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        ry, rx, gh, gw, qw = self._rel_tables()
+        gpc, n = tok_map.shape
+        G = B * gpc
+        d0, d1 = self.window_size
+        p0, p1 = self.pool_size
+        assert d0 % p0 == 0 and d1 % p1 == 0, "token pooling needs a window size divisible by the pool size, as in the reference"
+        nk = (d0 // p0) * (d1 // p1)
+        if self._wpool_index is None or self._wpool_index[0].device != qkv.device:
+            flat = tok_map.reshape(-1).long()
+            valid = (flat >= 0).nonzero().flatten()
+            self._wpool_index = (flat.clamp(min=0), (flat < 0).nonzero().flatten(), valid, flat[valid])
+        src, pad_pos, valid_pos, valid_tok = self._wpool_index
+        wq = self._ws("window_qkv", (B, gpc * n, 3 * D), torch.float32, qkv)
+        torch.index_select(qkv, 1, src, out=wq)
+        if pad_pos.numel():
+            wq[:, pad_pos] = self.qkv.bias
+        wq = wq.view(G, n, 3 * D)
+        kv = self._ws("pooled_kv", (G, nk, 2 * D), torch.float32, qkv)
+        _native.pool_kv(wq, G, d0, d1, D, p0, p1, kv)
+        prod_s = self._ws("attn_scores", (G, H, n, nk), torch.float32, qkv)
+        a_s = self._ws("attn_probs", (G, H, n, nk), sdt, qkv)
+        v_s = self._ws("attn_values", (G, nk, D), sdt, qkv)
+        out_w = self._ws("window_out", (B, gpc * n, D), torch.float32, qkv)
+        _native.qk_packed(wq, G, n, D, H, self.scale, prod_s, kv=kv, Nk=nk)
+        self.matmul.count_product(G * H * n * nk, dh)
+        if self.relative_position is not None:
+            self.relative_position.count_fused(G, H)
+        _native.softmax_gate(prod_s, a_s, G, H, n, nk, D, store, qkv=wq, rel_y=ry, rel_x=rx, gh=gh, gw=gw, qw=qw)
+        self._v_full(wq, kv, G, n, nk, v_s, store)
+        _native.av(a_s, v_s, nk, G, H, n, nk, D, store, out_f32=out_w.view(G, n, D))
+        self.matmul.count_product(G * H * n * dh, nk)
+        out.index_copy_(1, valid_tok, out_w.index_select(1, valid_pos))
 
     def _dense_norm_fusable(self, N):
         """True when `_attention_dense` runs the resident K8 kernel for this block (windowed or one group of <= 256 tokens, head dim

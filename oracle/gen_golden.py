@@ -152,6 +152,10 @@ def small_cases():
     cs["Block_pool_rel"] = ("Block", (6, 6), False, dict(pool_size=2, relative_embedding_size=(6, 6)), None)
     cs["Block_dense"] = ("Block", (6, 6), True, {}, None)
     cs["Block_win_rel"] = ("Block", (7, 5), False, dict(window_size=(3, 3), relative_embedding_size=(8, 8)), None)
+    # K/V pooling INSIDE windows (blocks.py:308): no reference config uses it, the reference supports it
+    cs["Block_winpool_rel"] = ("Block", (8, 8), False, dict(window_size=(4, 4), pool_size=2, relative_embedding_size=(8, 8)), None)
+    cs["EventfulTokenwiseBlock_winpool_pad"] = ("EventfulTokenwiseBlock", (7, 6), False,
+                                                dict(window_size=(4, 4), pool_size=2, relative_embedding_size=(8, 8)), ("topk", 12))
     return cs
 
 
