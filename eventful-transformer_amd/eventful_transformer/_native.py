@@ -561,7 +561,7 @@ def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
     """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest), and a 32-row tile with
     the rel-pos terms of a gh x gw key grid inside a CU's LDS (evt_attention_stream_lds_bytes; larger grids take the
     evt_qk + evt_softmax_av_gated path)."""
-    if not (STREAM_QK and FUSED_QK and D == 64 * H and N >= STREAM_MIN_N):
+    if not (STREAM_QK and FUSED_QK and D == 64 * H and STREAM_MIN_N <= N <= 32767):   # (32-bit offsets into a head's N x N reference)
         return False
     return 0 < load().evt_attention_stream_lds_bytes(store, gh, gw) <= LDS_PER_CU
 

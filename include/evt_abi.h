@@ -424,6 +424,8 @@ typedef struct evt_attn_stream_desc {
   int32_t k_split_ready;                  /* ABI 6: 1 = evt_stream_prep has already written k_split for this frame: no pre-kernel */
 } evt_attn_stream_desc;
 
+/* Limits: head dim 64 (D == 64 H), N <= 32767 (32-bit byte offsets into a head's N x N reference), the tile's LDS within a CU
+ * (evt_attention_stream_lds_bytes); EVT_ERR_BAD_SHAPE otherwise. */
 EVT_API int evt_attention_stream(const evt_attn_stream_desc* d, void* stream);
 
 /* LDS bytes of evt_attention_stream's smallest (32-row) tile for a store type and rel-pos key grid (gh = gw = 0: no relative

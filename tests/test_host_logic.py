@@ -101,11 +101,11 @@ def test_state_dict_keys_and_constructor_contract():
                                         "relative_embedding_size", "matmul_2_cast", "pool_size", "window_size"]
     with pytest.raises(AssertionError):
         blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, window_size=(3, 3))  # blocks.py:485
-    with pytest.raises(NotImplementedError):
-        blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, window_size=(3, 3))
+    winpool = blocks.Block(dim=64, heads=4, input_size=(8, 8), mlp_ratio=4, pool_size=2, window_size=(4, 4))   # blocks.py:308
+    assert winpool.pool_size == (2, 2) and winpool.window_size == (4, 4)
     ats = blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5)
     assert ats.ats_fraction == 0.5 and ats.last_ats_indices is None
-    with pytest.raises(NotImplementedError):   # ATS + pooling: not built (the reference's ATS configs use neither)
+    with pytest.raises(AssertionError):   # ATS excludes pooling and windows, as in the reference (blocks.py:71-73)
         blocks.Block(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, ats_fraction=0.5, pool_size=2)
     pooled = blocks.EventfulBlock(dim=64, heads=4, input_size=(6, 6), mlp_ratio=4, pool_size=2, relative_embedding_size=(6, 6))
     assert pooled.pool_size == (2, 2) and pooled.relative_position.pool_size == (2, 2)
