@@ -26,6 +26,11 @@ case $what in
     timeout 1500 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; tail -5 $OUT/bench.err; cat $OUT/bench.json ;;
   bench_short) # headline only
     timeout 900 python bench.py --no-other --no-cpu-baseline 2> $OUT/bench_short.err | tail -1 > $OUT/bench_short.json; cat $OUT/bench_short.json ;;
+  bench_events) # headline with and without the per-launch HIP events around the gated linears (what the measurement costs)
+    for rep in 1 2; do for fl in "" "--no-kernel-events"; do
+      echo "== rep $rep $fl" | tee -a $OUT/bench_events.txt
+      timeout 900 python bench.py --no-other --no-cpu-baseline --no-check --no-exact $fl 2>/dev/null | tail -1 | cut -c1-330 | tee -a $OUT/bench_events.txt
+    done; done ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
   kbench)
