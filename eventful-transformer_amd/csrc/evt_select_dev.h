@@ -97,7 +97,7 @@ __device__ __forceinline__ int evt_select_block(const float* __restrict__ norms,
         }
       }
     }
-    uint32_t kth = 0, need_eq = 0;
+    uint32_t kth = 0, need_eq = 0, kmask = 0xffffffffu;   // keys are compared on the digits the passes have resolved
     if (mode == 0) {
       for (int e = tid; e < 3 * SET; e += THREADS) hs[e] = 0;
       __syncthreads();
@@ -126,11 +126,11 @@ __device__ __forceinline__ int evt_select_block(const float* __restrict__ norms,
         const uint32_t incl = evt_wave_scan_u32(mine);      // keys in the bins of lanes 0 .. lane, i.e. in all HIGHER-or-equal bins
         const uint32_t higher = incl - mine;
         const bool here = higher < remaining && remaining <= incl;   // exactly one lane
-        uint32_t acc = higher, bin = 0, rank = 0;
+        uint32_t acc = higher, bin = 0, rank = 0, pop = 0;
         if (here) {
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            if (rank == 0 && acc + hb[d] >= remaining) { bin = 255u - 4u * lane - d; rank = remaining - acc; }
+            if (rank == 0 && acc + hb[d] >= remaining) { bin = 255u - 4u * lane - d; rank = remaining - acc; pop = hb[d]; }
             acc += hb[d];
           }
         }
@@ -138,11 +138,17 @@ __device__ __forceinline__ int evt_select_block(const float* __restrict__ norms,
         const int src = __ffsll((long long)bal) - 1;
         bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, src);
         rank = (uint32_t)__builtin_amdgcn_readlane((int)rank, src);
+        pop = (uint32_t)__builtin_amdgcn_readlane((int)pop, src);
         prefix |= bin << shift;
         mask |= 255u << shift;
         remaining = rank;
+        // EVERY key of the chosen bin is selected (with distinct norms: the bin holds one key after three passes): the lower
+        // digits cannot change the selection -- "above the prefix" and "in the bin" decide, lowest index first among equals
+        // as before.  Every wave takes the same decision from the same histogram.
+        if (pop == rank) break;
       }
       kth = prefix;
+      kmask = mask;
       need_eq = remaining;
     }
     // ordered compaction from the registers
@@ -151,8 +157,8 @@ __device__ __forceinline__ int evt_select_block(const float* __restrict__ norms,
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
       if (c < C && i_lo + c < N) {
-        const bool gt = mode == 0 ? key[c] > kth : __uint_as_float(key[c]) > thr_f;
-        const bool eq = mode == 0 && key[c] == kth;
+        const bool gt = mode == 0 ? (key[c] & kmask) > kth : __uint_as_float(key[c]) > thr_f;
+        const bool eq = mode == 0 && (key[c] & kmask) == kth;
         my_gt += gt;
         my_eq += eq;
       }
@@ -173,8 +179,8 @@ __device__ __forceinline__ int evt_select_block(const float* __restrict__ norms,
     for (int c = 0; c < CMAX; ++c) {
       const int i = i_lo + c;
       if (c < C && i < N) {
-        const bool gt = mode == 0 ? key[c] > kth : __uint_as_float(key[c]) > thr_f;
-        const bool eq = mode == 0 && key[c] == kth;
+        const bool gt = mode == 0 ? (key[c] & kmask) > kth : __uint_as_float(key[c]) > thr_f;
+        const bool eq = mode == 0 && (key[c] & kmask) == kth;
         const uint32_t pos = gt_run + (eq_run < need_eq ? eq_run : need_eq);   // selected tokens before i
         const bool is_sel = gt || (eq && eq_run < need_eq);
         if (is_sel && pos < (uint32_t)kcap) {
