@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
-    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_attention_dense_resident",
+    "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
 )
 
 
@@ -141,6 +141,8 @@ def _bind(lib):
     lib.evt_split_weights_bytes.restype = c_int64
     lib.evt_attention_stream_lds_bytes.argtypes = [c_int32, c_int32, c_int32]
     lib.evt_attention_stream_lds_bytes.restype = c_int64
+    lib.evt_prefetch.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    lib.evt_select_prefetch_next.argtypes = [c_void_p, c_int64, c_void_p]
     lib.evt_attention_stream_key_blocks.argtypes = [c_int32, c_int32, c_int32]
     lib.evt_attention_stream_key_blocks.restype = c_int64
     lib.evt_attention_dense_resident.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
@@ -569,6 +571,26 @@ def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
 # One stream: the three preparations of a gated evt_attention_stream frame (rel-pos terms, key plane, value gate) as ONE launch
 # (evt_stream_prep).  EVT_STREAM_PREP=0: three launches.
 STREAM_PREP = os.environ.get("EVT_STREAM_PREP", "1") != "0"
+
+
+def prefetch(t, sink):
+    """Read a read-only tensor (weight planes) into the memory-side cache on the CURRENT stream (evt_prefetch); graphs.py issues it
+    on a side stream one block ahead.  sink: an int32 tensor of >= 1 element on the same device."""
+    _check(load().evt_prefetch(_p(t), t.numel() * t.element_size(), _p(sink), _stream()))
+
+
+# One stream: the selection launches carry prefetch riders for the weight planes of a gated linear a few launches ahead
+# (evt_select_prefetch_next).  EVT_PREFETCH=0 turns it off; used below PREFETCH_MAX_ROWS token rows per launch.
+PREFETCH = os.environ.get("EVT_PREFETCH", "1") != "0"
+PREFETCH_MAX_ROWS = 8192
+
+
+def select_prefetch_next(t):
+    """Arm the next select launch of this thread with a prefetch of tensor t (weight planes)."""
+    if t is None:
+        return
+    sink = scratch("prefetch_sink", (4,), torch.int32, t.device)
+    _check(load().evt_select_prefetch_next(_p(t), t.numel() * t.element_size(), _p(sink)))
 
 
 def k_split_plane(qkv, B, H, N, gh=0, gw=0):

@@ -28,6 +28,11 @@ class ViTBackbone(ExtendedModule):
             else:
                 config["window_size"] = None
             self.blocks.append(getattr(blocks, name)(input_size=input_size, **config))
+        # every block knows its successor (the first block follows the last: the next frame) -- its MLP gate's selection launch
+        # prefetches the successor's QKV weight planes (blocks.py::_select).  Not a registered submodule.
+        mods = list(self.blocks)
+        for i, blk in enumerate(mods):
+            object.__setattr__(blk, "_next_block", mods[(i + 1) % len(mods)])
         # graphs.FrameGraphs.run_pipelined sets this while it captures several frames of one stream side by side: an
         # object whose before_block(i, n) / after_block(i, n) order block i of a frame behind the previous frame's blocks
         self.block_sync = None

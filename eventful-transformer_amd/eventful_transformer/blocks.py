@@ -71,6 +71,14 @@ REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt
 INDEX_TAP = None
 
 
+def _PREFETCH_MAP(blk, nxt):
+    """gate tag -> the linears whose weight planes its selection launch prefetches.  EVT_PREFETCH_MAP=late: one launch ahead
+    (measured worse: the riders of two linears outlast the selection); default: three to five launches ahead."""
+    if os.environ.get("EVT_PREFETCH_MAP", "early") == "late":
+        return {"projection": (blk.mlp_1,), "mlp": (blk.mlp_2, None if nxt is None else nxt.qkv)}
+    return {"qkv": (blk.mlp_1,), "projection": (blk.mlp_2,), "mlp": (None if nxt is None else nxt.qkv,)}
+
+
 class PendingSum:
     """Block output handed to the next block as an UNEVALUATED residual sum `src + res` (backbone-internal).
 
@@ -487,6 +495,15 @@ class EventfulTokenwiseBlock(Block):
                     B=B, kcap=cap, K=embed_for[0], Nout=embed_for[1], N=N):
                 mode, k, thr = policy.select_params(N)
                 return idx, count, cap, dict(norms=norms, parts=parts, N=N, k=k, mode=mode, thr=thr, idx=idx, count=count, rest=rest)
+            if _native.PREFETCH and B * N <= _native.PREFETCH_MAX_ROWS:
+                # one stream: the single-workgroup selection launch also pulls the weight planes of the gated linears one or two
+                # launches ahead into the memory-side cache (MLP-1 behind the projection gate; MLP-2 and the NEXT block's QKV
+                # behind the MLP gate -- close to their use: the attention state of a 1024^2 frame would evict them) -- a
+                # frame walks 340 MB of planes, colder than any cache by the time it comes round again
+                nxt = self.__dict__.get("_next_block")
+                for lin in _PREFETCH_MAP(self, nxt).get(tag, ()):
+                    if lin is not None:
+                        _native.select_prefetch_next(lin.split_planes())
             policy.select_into(norms, B, N, idx, count, rest, parts=parts)
             if INDEX_TAP is not None:
                 INDEX_TAP(self, tag, idx, count)

@@ -69,6 +69,19 @@ EVT_API const char* evt_last_error_string(void);
 /* Compile-time target of the embedded code object, e.g. "gfx950". */
 EVT_API const char* evt_target_arch(void);
 
+/* ABI 6.  Reads `bytes` (16-byte aligned pointer) of a read-only operand -- a CountedLinear's weight planes (evt_split_weights) --
+ * into the memory-side cache ahead of the launch that streams them; `sink` = 4 writable bytes (never written in practice: it keeps
+ * the loads).  No reference counterpart: the reference's per-layer weights (blocks.py:102-116) are re-read from HBM by every frame of
+ * one video stream, and a 6-14 us launch pays for cold reads.  Issue it on a side stream; results are unaffected. */
+EVT_API int evt_prefetch(const void* ptr, int64_t bytes, void* sink, void* stream);
+
+/* ABI 6.  One-shot rider: the NEXT evt_select_* launch issued from this host thread (any of the four) also reads [ptr, ptr + bytes)
+ * like evt_prefetch, with extra workgroups of its own grid -- the selection of one video stream is a single workgroup for ~5 us, so
+ * the riders cost no launch and no time.  The caller arms it with the weight planes of a gated linear a few launches ahead
+ * (blocks.py:430-450: MLP-1 behind the projection gate, MLP-2 and the next block's QKV behind the MLP gate).  A second call before
+ * the launch arms a second range.  Results are unaffected. */
+EVT_API int evt_select_prefetch_next(const void* ptr, int64_t bytes, void* sink);
+
 /* ------------------------------------------------------------------------------------------ *
  * K0/K1a  Row pass: [residual add] -> [LayerNorm] -> [delta-norm against a gate reference].
  *

@@ -102,6 +102,22 @@ case $what in
       echo "== batch $b" | tee -a $OUT/vd_batch.log
       python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log
     done ;;
+  vd_trace672=*) # kernel trace of the 672^2 one-stream frames under an environment setting: vd_trace672=EVT_PREFETCH=0
+    (cd /tmp && env ${what#vd_trace672=} rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/t672 -o t -- python3 $GRAFT_REPO_ROOT/scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs > $GRAFT_REPO_ROOT/$OUT/t672.log 2>&1)
+    python scripts/trace_summary.py $(find $OUT/t672 -name "*kernel_trace.csv" | head -1) 6000 | tee $OUT/trace672_${what#vd_trace672=}.txt
+    find $OUT -name "*kernel_trace.csv" -delete; rm -rf $OUT/t672 ;;
+  vd_rider)    # rider shapes: workgroups x loads in flight
+    for cfg in "EVT_PREFETCH=0" "EVT_RIDER_WGS=128" "EVT_RIDER_WGS=64" "EVT_RIDER_WGS=192" "EVT_RIDER_WGS=128 EVT_RIDER_DEPTH=4" "EVT_PREFETCH=0"; do
+      echo "== $cfg" | tee -a $OUT/vd_rider.log
+      env $cfg python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c100-200 | tee -a $OUT/vd_rider.log
+      env $cfg python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | cut -c110-210 | tee -a $OUT/vd_rider.log
+    done ;;
+  vd_prefetch) # one-stream latency with / without the weight prefetch on a side stream
+    for rep in 1 2; do for pf in 1 0; do
+      echo "== EVT_PREFETCH=$pf" | tee -a $OUT/vd_prefetch.log
+      EVT_PREFETCH=$pf python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c1-230 | tee -a $OUT/vd_prefetch.log
+      EVT_PREFETCH=$pf python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | cut -c1-230 | tee -a $OUT/vd_prefetch.log
+    done; done ;;
   vd)          # one-stream ViTDet latency (graph replay)
     python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log
     python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | tee -a $OUT/vd.log ;;

@@ -91,6 +91,18 @@ def main():
             "proj": lambda: n.gated_linear(c, D, idx, N, Wp, b1, o1, D, idx, N, count, p, 1, cap, D, D, W_split=sp),
             "mlp": lambda: n.gated_mlp(c, D, idx, N, W1, b4, W2, b1, hidden, o1, D, count, p, 1, cap, D, 4 * D, W1_split=s1, W2_split=s2),
         }
+        if Bn == 1:   # the same QKV / MLP launches cycling through 40 different weight sets (~1.1 GB: colder than any cache)
+            cold = [(n.split_weight(torch.randn(3 * D, D, device=dev, generator=g) * 0.02), n.split_weight(torch.randn(4 * D, D, device=dev, generator=g) * 0.02),
+                     n.split_weight(torch.randn(D, 4 * D, device=dev, generator=g) * 0.02)) for _ in range(40)]
+            turn = [0]
+            def qkv_cold():
+                turn[0] = (turn[0] + 1) % 40
+                n.gated_linear(c, D, idx, N, Wq, b3, qkv_out, 3 * D, idx, N, count, p, 1, cap, D, 3 * D, W_split=cold[turn[0]][0])
+            def mlp_cold():
+                turn[0] = (turn[0] + 1) % 40
+                n.gated_mlp(c, D, idx, N, W1, b4, W2, b1, hidden, o1, D, count, p, 1, cap, D, 4 * D, W1_split=cold[turn[0]][1], W2_split=cold[turn[0]][2])
+            kernels["qkv_cold_weights"] = qkv_cold
+            kernels["mlp_cold_weights"] = mlp_cold
         for kn, fn in kernels.items():
             if (only and kn not in only) or (Bn > 1 and not kn.startswith("stream")):
                 continue
