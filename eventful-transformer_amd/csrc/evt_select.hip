@@ -65,6 +65,9 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const float* __restrict
 
 thread_local SelRider g_rider = {{nullptr, nullptr}, {0, 0}, nullptr, 0, 0};   // armed by evt_select_prefetch_next, consumed by the next launch
 
+// a selection that launches nothing must not leave its rider armed for some later launch (the range may be gone by then)
+void drop_rider() { g_rider = {{nullptr, nullptr}, {0, 0}, nullptr, 0, 0}; }
+
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
                   int32_t* rest, void* stream, int parts = 0) {
   const size_t lds = (size_t)evt_select_smem_words(N) * sizeof(uint32_t);
@@ -109,9 +112,9 @@ extern "C" int evt_select_topk(const float* norms, int B, int N, int k, int32_t*
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk: B=%d N=%d", B, N);
   EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk: k=%d out of range for N=%d (topk would raise)", k, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk: N=%d exceeds %d", N, SEL_MAX_N);
-  if (B == 0) return EVT_OK;
+  if (B == 0) { drop_rider(); return EVT_OK; }
   EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk: k == 0 with a complement list");
-  if (k == 0) return EVT_OK;
+  if (k == 0) { drop_rider(); return EVT_OK; }
   return launch_select(norms, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream);
 }
 
@@ -122,7 +125,7 @@ extern "C" int evt_select_threshold(const float* norms, int B, int N, float thre
   EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold: kcap=%d must be >= N=%d", kcap, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold: N=%d exceeds %d", N, SEL_MAX_N);
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold: NaN threshold");
-  if (B == 0) return EVT_OK;
+  if (B == 0) { drop_rider(); return EVT_OK; }
   return launch_select(norms, B, N, 0, threshold, 1, kcap, idx, count, rest, stream);
 }
 
@@ -131,9 +134,9 @@ extern "C" int evt_select_topk_sq(const float* sq_parts, int parts, int B, int N
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk_sq: B=%d N=%d", B, N);
   EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k=%d out of range for N=%d (topk would raise)", k, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk_sq: N=%d exceeds %d", N, SEL_MAX_N);
-  if (B == 0) return EVT_OK;
+  if (B == 0) { drop_rider(); return EVT_OK; }
   EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k == 0 with a complement list");
-  if (k == 0) return EVT_OK;
+  if (k == 0) { drop_rider(); return EVT_OK; }
   return launch_select(sq_parts, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream, parts);
 }
 
@@ -144,6 +147,6 @@ extern "C" int evt_select_threshold_sq(const float* sq_parts, int parts, int B, 
   EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: kcap=%d must be >= N=%d", kcap, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold_sq: N=%d exceeds %d", N, SEL_MAX_N);
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: NaN threshold");
-  if (B == 0) return EVT_OK;
+  if (B == 0) { drop_rider(); return EVT_OK; }
   return launch_select(sq_parts, B, N, 0, threshold, 1, kcap, idx, count, rest, stream, parts);
 }

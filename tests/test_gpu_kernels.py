@@ -92,6 +92,36 @@ def test_gate_select_golden(golden_dir):
         del p_before
 
 
+@pytest.mark.parametrize("N,k", [(197, 128), (1764, 256), (4096, 400)])
+def test_select_prefetch_rider_changes_nothing(N, k):
+    """evt_select_prefetch_next: the next selection launch also reads the armed range(s) with extra workgroups of its grid --
+    same lists with one, two or no riders, the rider is consumed by that launch, and a selection that launches nothing drops it."""
+    n = native()
+    g = torch.Generator(device=DEV).manual_seed(N)
+    norms = torch.rand(2, N, device=DEV, generator=g)
+    planes = [torch.randn(3 << 20, device=DEV, generator=g), torch.randn((1 << 20) + 12, device=DEV, generator=g)]
+    want, rest_w = torch.empty(2, k, dtype=torch.int32, device=DEV), torch.empty(2, N, dtype=torch.int32, device=DEV)
+    n.select_topk(norms, 2, N, k, want, rest_w)
+    for riders in (planes[:1], planes, []):
+        got, rest = torch.full((2, k), -1, dtype=torch.int32, device=DEV), torch.full((2, N), -1, dtype=torch.int32, device=DEV)
+        for t in riders:
+            n.select_prefetch_next(t)
+        n.select_topk(norms, 2, N, k, got, rest)
+        assert torch.equal(got, want) and torch.equal(rest[:, :N - k], rest_w[:, :N - k])
+    cnt_w, cnt = torch.empty(2, dtype=torch.int32, device=DEV), torch.empty(2, dtype=torch.int32, device=DEV)
+    thr_w, thr_g = torch.empty(2, N, dtype=torch.int32, device=DEV), torch.empty(2, N, dtype=torch.int32, device=DEV)
+    n.select_threshold(norms, 2, N, 0.7, N, thr_w, cnt_w, None)
+    n.select_prefetch_next(planes[0])
+    n.select_threshold(norms, 2, N, 0.7, N, thr_g, cnt, None)
+    assert torch.equal(cnt, cnt_w) and all(torch.equal(thr_g[b, :int(cnt[b])], thr_w[b, :int(cnt[b])]) for b in range(2))
+    n.select_prefetch_next(planes[1])
+    n.select_topk(norms, 2, N, 0, got, None)          # k == 0 launches nothing: the rider must not wait for a later launch
+    del planes
+    n.select_topk(norms, 2, N, k, got, None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_select_tie_policy_and_edges():
     """Ties are tie-policy-defined (lowest index first), not reference-pinned."""
     n = native()
