@@ -73,7 +73,9 @@ INDEX_TAP = None
 
 def _PREFETCH_MAP(blk, nxt):
     """gate tag -> the linears whose weight planes its selection launch prefetches.  EVT_PREFETCH_MAP=late: one launch ahead
-    (measured worse: the riders of two linears outlast the selection); default: three to five launches ahead."""
+    (measured worse: the riders of two linears outlast the selection); default: three to five launches ahead.  Also measured
+    worse: a second range with the gate reference the next row pass compares against (5.4 MB, written a frame ago):
+    672^2 1.65 vs 1.62 ms, 1024^2 2.55 vs 2.51."""
     if os.environ.get("EVT_PREFETCH_MAP", "early") == "late":
         return {"projection": (blk.mlp_1,), "mlp": (blk.mlp_2, None if nxt is None else nxt.qkv)}
     return {"qkv": (blk.mlp_1,), "projection": (blk.mlp_2,), "mlp": (None if nxt is None else nxt.qkv,)}

@@ -107,7 +107,7 @@ case $what in
     python scripts/trace_summary.py $(find $OUT/t672 -name "*kernel_trace.csv" | head -1) 6000 | tee $OUT/trace672_${what#vd_trace672=}.txt
     find $OUT -name "*kernel_trace.csv" -delete; rm -rf $OUT/t672 ;;
   vd_rider)    # rider shapes: workgroups x loads in flight
-    for cfg in "EVT_PREFETCH=0" "EVT_RIDER_WGS=128" "EVT_RIDER_WGS=64" "EVT_RIDER_WGS=192" "EVT_RIDER_WGS=128 EVT_RIDER_DEPTH=4" "EVT_PREFETCH=0"; do
+    for cfg in ${RIDER_CFGS:-"EVT_PREFETCH=0" "EVT_PREFETCH=1" "EVT_PREFETCH_REFS=1" "EVT_PREFETCH=1" "EVT_PREFETCH_REFS=1"}; do
       echo "== $cfg" | tee -a $OUT/vd_rider.log
       env $cfg python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c100-200 | tee -a $OUT/vd_rider.log
       env $cfg python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | cut -c110-210 | tee -a $OUT/vd_rider.log
