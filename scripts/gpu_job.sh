@@ -112,6 +112,13 @@ case $what in
       env $cfg python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c100-200 | tee -a $OUT/vd_rider.log
       env $cfg python scripts/bench_vitdet.py --grid 64 --policy threshold --thr 1.0 --cast bfloat16 --frames 8 --graphs 2>&1 | tail -1 | cut -c110-210 | tee -a $OUT/vd_rider.log
     done ;;
+  vd_touch)    # small-GEMM touch loads on / off: cold-weight probe + one-stream latency
+    for t in 1 0; do
+      echo "== EVT_SMALL_TOUCH=$t" | tee -a $OUT/vd_touch.log
+      EVT_SMALL_TOUCH=$t python scripts/probes/gemm_cold_weights.py 2>&1 | grep -v amdgpu | cut -c1-100 | tee -a $OUT/vd_touch.log
+      EVT_SMALL_TOUCH=$t python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c100-200 | tee -a $OUT/vd_touch.log
+      EVT_SMALL_TOUCH=$t python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs 2>&1 | tail -1 | cut -c100-200 | tee -a $OUT/vd_touch.log
+    done ;;
   vd_prefetch) # one-stream latency with / without the weight prefetch on a side stream
     for rep in 1 2; do for pf in 1 0; do
       echo "== EVT_PREFETCH=$pf" | tee -a $OUT/vd_prefetch.log
