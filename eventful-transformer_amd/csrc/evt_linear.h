@@ -23,6 +23,9 @@ struct LinArgs {
 // get (0 = none: run the 128x128 kernel); evt_launch_split_big launches it (false = not taken).
 int evt_big_choice(const LinArgs& a);
 bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
+// evt_linear_pipe.hip: the same tiles on four 512-register waves with a software-pipelined k-tile (round 5); `choice` is
+// evt_big_choice's answer; false = not taken.
+bool evt_launch_split_pipe(const LinArgs& a, hipStream_t s, int choice);
 
 // evt_linear_small.hip: latency-oriented kernel for small gated row counts (one video stream).  Returns the K split it
 // launched with (0 = not taken; > 1 = partial planes in the workspace, the caller runs the finish pass).

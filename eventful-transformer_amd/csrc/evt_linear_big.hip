@@ -555,7 +555,10 @@ int evt_big_choice(const LinArgs& a) {
 }
 
 bool evt_launch_split_big(const LinArgs& a, hipStream_t s) {
-  switch (evt_big_choice(a)) {
+  static const int pipe = getenv("EVT_GEMM_PIPE") ? atoi(getenv("EVT_GEMM_PIPE")) : 1;
+  const int choice = evt_big_choice(a);
+  if (pipe && choice != 0 && evt_launch_split_pipe(a, s, choice)) return true;
+  switch (choice) {
     case 2: launch_big_cfg<256, 256, 4, 2, 1>(a, s); return true;
     case 3: launch_big_cfg<256, 128, 4, 2, 1>(a, s); return true;
     case 4: launch_big_cfg<256, 192, 4, 2, 1>(a, s); return true;   // (a two-deep register prefetch measured the same: kept out)

@@ -126,6 +126,7 @@ class ExtendedModule(nn.Module):
 
     # -- per-clip state --------------------------------------------------------------------------
     def reset(self):
+        self.__dict__.pop("_evt_state_owner", None)   # (graphs.FrameGraphs: the per-clip state is no longer the one it captured)
         for m in self.extended_modules():
             m.reset_self()
 

@@ -14,11 +14,19 @@ graphs per model -- the dense first frame of a clip and the gated incremental fr
             y = frames(x)        # y is a static tensor, overwritten by the next call: clone to keep
 
 Replaying the first-frame graph rewrites every state tensor completely, so `reset()` between clips costs
-nothing and the model's own `reset()` is only needed before the graphs exist.  Schedule on a fresh object:
-frame 0 eager (fills the scratch pool, splits the weights) then captured and replayed; frame 1 eager; frame 2
-captured; everything after is replay only.  The numbers are bit-identical to the eager path (same kernels,
-same order, same buffers).  Weights are read at capture time (the bf16 planes of the split-precision GEMM are
-built then): call `release()` after loading new weights.
+nothing and the model's own `reset()` is only needed before the graphs exist.  Schedule on a fresh object: the
+FIRST call runs one first frame and one incremental frame eagerly on the given input (scratch pools of both paths,
+split weight planes, window maps), resets the model, captures BOTH graphs back to back and replays the first; everything
+after is replay only.  (Until round 5 the incremental graph was warmed and captured lazily on frames 1 and 2: if another
+FrameGraphs of the same model, or an eager `model.reset()`, ran in between, that late capture recorded launches against
+state tensors that were not this object's.)  The numbers are bit-identical to the eager path (same kernels, same order, same
+buffers).
+
+What a capture bakes in, and how it is kept honest: the gate policies (k, threshold, index-list capacity), the weights (the bf16
+planes of the split-precision GEMM are built at capture time) and train / eval mode.  `reset()` -- the start of every clip --
+compares a signature of those (per gate: policy class + scalar parameters; per parameter and buffer: storage address, version,
+dtype, device; plus a flag raised by a `load_state_dict` post-hook, which copies into `.data` without bumping versions) with
+the captured one and re-captures when it differs: `set_policies`, `load_state_dict` and `.to()` between clips are safe.
 
 Frame pipelining (`run_pipelined`): block i of frame t+1 only needs block i of frame t (its temporal state) and block
 i-1 of frame t+1 (its input), so consecutive frames of ONE stream overlap like a wavefront.  With every launch of a
@@ -30,6 +38,8 @@ scatter into that buffer before it has been read).  Same kernels on the same sta
 outputs are bit-identical to frame-by-frame replay; the latency of a frame is unchanged, the throughput of the stream
 approaches P x.
 """
+import weakref
+
 import torch
 
 from eventful_transformer import _native
@@ -50,15 +60,48 @@ class FrameGraphs:
         self._inc = None         # (graph, static output) of an incremental frame
         self._x = None           # static input
         self._t = 0
-        self._inc_warm = False
         self._pipe = None        # (graph, static inputs, static outputs, side streams) of `run_pipelined`
-        self._pipe_warm = 0
         self._keep = []          # weight planes / rel-pos tables / sized encodings the captured graphs read
+        self._sig = None         # signature of what the captures baked in (policies, weights, mode)
+        self._stale = False      # raised by the load_state_dict post-hook
+        me = weakref.ref(self)
+
+        def loaded(_module, _incompatible):
+            obj = me()
+            if obj is not None:
+                obj._stale = True
+        self._hook = model.register_load_state_dict_post_hook(loaded)
+
+    def __del__(self):
+        try:
+            self._hook.remove()
+        except Exception:
+            pass
+
+    def _signature(self):
+        sig = [bool(self.model.training)]
+        for m in self.model.modules():
+            pol = getattr(m, "policy", None)
+            if pol is not None:
+                sig.append((type(pol).__name__,) + tuple(sorted((k, v) for k, v in vars(pol).items()
+                                                                if isinstance(v, (int, float, bool, str, type(None))))))
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            sig.append((t.data_ptr(), t._version, t.dtype, str(t.device)))
+        return tuple(sig)
+
+    def _owns_model_state(self):
+        """True while the model's Python-side state attributes (gate references, accumulators, first-frame flags) are the ones
+        this object's captures created: no other FrameGraphs and no eager reset() has touched the model since."""
+        owner = self.model.__dict__.get("_evt_state_owner")
+        return owner is not None and owner() is self
 
     def reset(self):
         """Start a new clip.  Before the first-frame graph exists this resets the model; afterwards the graph
-        replay re-initialises all state itself."""
+        replay re-initialises all state itself -- unless what the captures baked in has changed (see the module docstring):
+        then the graphs are dropped and the next call captures again."""
         self._t = 0
+        if self._first is not None and (self._stale or self._signature() != self._sig):
+            self.release()
         if self._first is None:
             self.model.reset()
 
@@ -67,8 +110,8 @@ class FrameGraphs:
         self._first = self._inc = self._x = self._pipe = None
         self._keep = []
         self._t = 0
-        self._inc_warm = False
-        self._pipe_warm = 0
+        self._sig = None
+        self._stale = False
         self.model.reset()
 
     def _capture(self):
@@ -86,6 +129,32 @@ class FrameGraphs:
             raise RuntimeError(f"FrameGraphs{what}: frame {tuple(x.shape)} {x.dtype} on {x.device} differs from the captured "
                                f"{tuple(self._x.shape)} {self._x.dtype} on {self._x.device}; call release() to re-capture")
 
+    def _build(self):
+        """Everything that is not a replay, in ONE place and in one call: eager warm-up of both frame kinds, then both captures."""
+        self.model.reset()
+        self._fwd(self._x)               # eager first frame: scratch pool, split weight planes, window maps
+        self._fwd(self._x)               # eager incremental frame: the gated path's scratch buffers
+        self.model.reset()
+        # reset() dropped every cache that is rebuilt lazily: the bf16 weight planes, the rel-pos tables and the
+        # sized position encoding.  Rebuild them OUTSIDE the capture -- the bicubic resize creates host tensors
+        # and copies them to the device, which must not become graph nodes reading freed host memory.
+        # The graphs read these caches at their CAPTURED addresses: keep them alive for as long as this object lives -- a
+        # later eager `model.reset()` (or another FrameGraphs capturing the same model at another shape) drops the
+        # model's own references and would otherwise leave the replays reading freed memory.
+        self._keep = []
+        for m in self.model.modules():
+            if isinstance(m, CountedLinear):
+                self._keep.append(m.split_planes())
+            elif isinstance(m, RelativePositionEmbedding):
+                self._keep.append(m.tables())
+            elif isinstance(m, PositionEncoding):
+                self._keep.append(m.sized())
+        self._first = self._capture()    # allocates the state tensors (graph-private pool), leaves the model "past its first frame"
+        self._inc = self._capture()      # the gated path on those tensors (a capture records, it does not run)
+        self._sig = self._signature()
+        self._stale = False
+        self.model.__dict__["_evt_state_owner"] = weakref.ref(self)
+
     @torch.inference_mode()
     def __call__(self, x):
         self._check_frame(x, "")
@@ -94,37 +163,15 @@ class FrameGraphs:
         self._x.copy_(x)
         if self._t == 0:
             if self._first is None:
-                self.model.reset()
-                self._fwd(self._x)           # eager once: scratch pool, split weight planes, window maps
-                self.model.reset()
-                # reset() dropped every cache that is rebuilt lazily: the bf16 weight planes, the rel-pos tables and the
-                # sized position encoding.  Rebuild them OUTSIDE the capture -- the bicubic resize creates host tensors
-                # and copies them to the device, which must not become graph nodes reading freed host memory.
-                # The graphs read these caches at their CAPTURED addresses: keep them alive for as long as this object lives -- a
-                # later eager `model.reset()` (or another FrameGraphs capturing the same model at another shape) drops the
-                # model's own references and would otherwise leave the replays reading freed memory.
-                self._keep = []
-                for m in self.model.modules():
-                    if isinstance(m, CountedLinear):
-                        self._keep.append(m.split_planes())
-                    elif isinstance(m, RelativePositionEmbedding):
-                        self._keep.append(m.tables())
-                    elif isinstance(m, PositionEncoding):
-                        self._keep.append(m.sized())
-                self._first = self._capture()
+                self._build()
             graph, y = self._first
-            graph.replay()
-        elif self._inc is None and not self._inc_warm:
-            self._inc_warm = True            # eager once: the incremental path's scratch buffers
-            y = self._fwd(self._x)
         else:
             if self._inc is None:
-                self._inc = self._capture()
+                raise RuntimeError("FrameGraphs: the first frame of a clip goes through reset() + __call__")
             graph, y = self._inc
-            graph.replay()
+        graph.replay()
         self._t += 1
         return y
-
 
     # ---------------------------------------------------------------------------------------------
     def _backbones(self):
@@ -162,8 +209,8 @@ class FrameGraphs:
     def run_pipelined(self, xs):
         """xs: (P, ...) = the next P frames of the stream (not the first frame of a clip).  Returns the list of their P
         outputs.  From the second call on these are STATIC tensors that the next call overwrites (clone to keep); the first call
-        per lane count runs the frames one by one (each lane's scratch buffers come into being outside the capture) and returns
-        copies, the second captures, later ones replay.  The clip must have been started through this object (`reset()` then
+        runs the frames one by one (each lane's scratch buffers come into being outside the capture), returns copies and
+        captures the P-lane graph for the later calls.  The clip must have been started through this object (`reset()` then
         `__call__` for its first frame): the temporal state the lanes update is the model's."""
         if self._t == 0 or self._x is None:
             raise RuntimeError("FrameGraphs.run_pipelined: the first frame of a clip goes through __call__")
@@ -173,16 +220,18 @@ class FrameGraphs:
         P = xs.shape[0]
         if self._pipe is not None and (self._pipe[1].shape != xs.shape or self._pipe[1].dtype != xs.dtype or self._pipe[1].device != xs.device):
             raise RuntimeError("FrameGraphs.run_pipelined: frame stack differs from the captured one; call release()")
-        if self._pipe is None and self._pipe_warm != P:
+        if self._pipe is None:
+            if not self._owns_model_state():
+                # The lanes' eager warm-up and their capture run on the model's Python-side state, which another FrameGraphs (or an
+                # eager reset) has taken over since this object captured: replay frame by frame instead (same results).
+                return [_clone_out(self(xs[j])) for j in range(P)]
             ys = []
-            for j in range(P):
+            for j in range(P):           # eager, one by one: each lane's scratch buffers come into being outside the capture
                 with _native.lane(j):
                     ys.append(_clone_out(self._fwd(xs[j].contiguous())))
-            self._pipe_warm = P
             self._t += P
+            self._pipe = self._capture_pipelined(torch.empty_like(xs, memory_format=torch.contiguous_format))   # records, does not run
             return ys
-        if self._pipe is None:
-            self._pipe = self._capture_pipelined(torch.empty_like(xs, memory_format=torch.contiguous_format))
         graph, sx, ys, _ = self._pipe
         sx.copy_(xs)
         graph.replay()

@@ -378,6 +378,11 @@ def gen_vitdet672():
                         pol = getattr(blk, g).policy
                         idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
                         margins.append(topk_margin(pol.last_input, k))
+                # the FULL output rows of the tokens the last block's MLP gate refreshed in this frame: the sparse `y_slice`
+                # mostly sees tokens that no gate touched (their error is the dense first frame's)
+                rows = sorted_idx(ref.blocks[-1].mlp_gate.policy.last_output)[0]
+                pack[f"yrowidx_{t}"] = rows.numpy().astype(np.int16)
+                pack[f"yrow_{t}"] = y[0, rows].numpy()
             print(f"vitdet672 step {t}: {time.time() - t0:.1f}s")
     pack["y_slice"] = torch.stack(outs).numpy()
     pack["idx"] = np.stack(idx_all).reshape(steps - 1, 12, 3, 1, k)
@@ -422,6 +427,9 @@ def gen_vitdet1024(thr=1.0, fname="vitdet_1024.npz", steps=5, seed=93):
                         pack[f"near_{t}_{bi}_{key}"] = pol.last_near[0].numpy().astype(np.int16)
                         pack[f"nearrel_{t}_{bi}_{key}"] = pol.last_near[1].numpy().astype(np.float32)
                         n_near += int(pol.last_near[0].numel())
+                rows = ob.blocks[-1].trace["mlp_index"].reshape(-1).sort()[0]
+                pack[f"yrowidx_{t}"] = rows.numpy().astype(np.int16)
+                pack[f"yrow_{t}"] = y[0, rows].numpy()
             print(f"vitdet1024 thr={thr} step {t}: {time.time() - t0:.1f}s", flush=True)
     pack["y_slice"] = torch.stack(outs).numpy()
     pack["counts"] = np.asarray(counts).reshape(steps - 1, 12, 3)

@@ -31,6 +31,14 @@ case $what in
       echo "== rep $rep $fl" | tee -a $OUT/bench_events.txt
       timeout 900 python bench.py --no-other --no-cpu-baseline --no-check --no-exact $fl 2>/dev/null | tail -1 | cut -c1-330 | tee -a $OUT/bench_events.txt
     done; done ;;
+  envelope)    # bf16-mode free-running agreement with split-precision GEMMs (default) and with exact-fp32 GEMMs (EVT_GEMM=f32):
+               # does the split arithmetic explain the distance from the reference's own self-agreement envelope?
+    for gm in split f32; do
+      echo "== EVT_GEMM=$gm" | tee -a $OUT/envelope_ab.txt
+      rm -f $OUT/env_$gm.txt
+      EVT_GEMM=$gm EVT_PARITY_SUMMARY=$PWD/$OUT/env_$gm.txt timeout 900 python -m pytest tests/test_gpu_blocks.py -m gpu -q -k "vivit_b_full_size and bf16" 2>&1 | tail -3 | tee -a $OUT/envelope_ab.txt
+      cat $OUT/env_$gm.txt | tee -a $OUT/envelope_ab.txt
+    done ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
   kbench)

@@ -80,6 +80,50 @@ def test_vivit_end_to_end_graph_replay_is_bit_identical(golden_dir):
         assert torch.equal(model(clips[0]), want[0]) and not model._frames
 
 
+def test_vivit_graph_replay_follows_policy_and_weight_changes(golden_dir):
+    """The reference's harness sweeps `token_top_k` / thresholds with `set_policies` on ONE model instance
+    (utils/evaluate.py run_evaluations) and loads checkpoints into built models.  In the default (automatic) graph mode the
+    captured graphs bake in the gate policies and the bf16 weight planes: after set_policies(k2), after load_state_dict() and
+    after an in-place weight edit the next clip must give what the EAGER model gives for the new setting (round-4 advisor finding:
+    the graph cache was keyed on the step shape only)."""
+    from eventful_transformer import policies
+    from models.vivit import FactorizedViViT
+    g = H.load_npz(os.path.join(golden_dir, "models.npz"))
+    seed, k = int(g["vivit__seed"]), int(g["vivit__k"])
+    model = FactorizedViViT(**H.VIVIT_B_CONFIG)
+    sd1 = H.seeded_module_params(model, seed)
+    sd2 = H.seeded_module_params(model, seed + 100)
+    model.load_state_dict(sd1, strict=True)
+    model = model.eval().to(DEV)
+    clip = H.synthetic_video(seed + 1).to(DEV)
+
+    def eager(sd, kk):
+        model.use_frame_graphs(0)
+        model.load_state_dict(sd, strict=True)
+        H.set_policies(model, policies.TokenNormTopK, k=kk)
+        return model(clip).clone()
+
+    with torch.inference_mode():
+        want_a, want_b, want_c = eager(sd1, k), eager(sd1, k // 2), eager(sd2, k // 2)
+        assert not torch.equal(want_a, want_b) and not torch.equal(want_b, want_c)
+        model.load_state_dict(sd1, strict=True)
+        H.set_policies(model, policies.TokenNormTopK, k=k)
+        model.use_frame_graphs(None)                                  # automatic: batch 1 replays HIP graphs
+        assert torch.equal(model(clip), want_a) and len(model._frames) == 1
+        assert torch.equal(model(clip), want_a)                       # replay only
+        H.set_policies(model, policies.TokenNormTopK, k=k // 2)      # new policy objects, other k
+        assert torch.equal(model(clip), want_b)
+        for m in model.modules():                                     # the same policy objects, parameter edited in place
+            if hasattr(m, "policy") and m.policy is not None:
+                m.policy.k = k
+        assert torch.equal(model(clip), want_a)
+        H.set_policies(model, policies.TokenNormTopK, k=k // 2)
+        model.load_state_dict(sd2, strict=True)                       # copies into .data: versions and addresses unchanged
+        assert torch.equal(model(clip), want_c)
+        assert torch.equal(model(clip), want_c)
+        model.use_frame_graphs(0)
+
+
 def test_vitdet_pre_backbone_and_pyramid(golden_dir):
     """models/vitdet.py of this package vs the reference's ViTDetPreprocessing + LinearEmbedding (patch GEMM) and
     SimplePyramid (transposed convs as four scatter-GEMMs, 1x1 / 3x3 convs as GEMMs, LayerNorm row passes)."""
