@@ -549,6 +549,11 @@ int evt_big_choice(const LinArgs& a) {
     const int tiles = tiles_m * (a.Nout / tbn), rounds = (tiles + cus - 1) / cus;
     return tiles >= cus && tiles * 100 >= rounds * cus * 85;
   };
+  // Round 5 (evt_linear_pipe.hip, 8 waves): 256x192 first -- QKV (Nout = 2304) is 1536 tiles = 6.0 rounds instead of the 4.5 (-> 5) of
+  // 256x256, and the 192-column instantiations keep every register: 310 vs 346 us for QKV, 441 vs 497 for MLP-1 + GELU, 790 vs 859
+  // for the MLP pair at B = 256 (profiles/r05/gemm_tile_shapes.txt).
+  static const int pipe = getenv("EVT_GEMM_PIPE") ? atoi(getenv("EVT_GEMM_PIPE")) : 1;
+  if (pipe && fills(192)) return 4;
   if (fills(256)) return 2;
   if (fills(192)) return 4;
   return 0;

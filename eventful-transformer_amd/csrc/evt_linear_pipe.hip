@@ -54,6 +54,9 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 #ifndef EVT_PIPE_PRIO     // 1: the second-dispatched half of an 8-wave workgroup (the loser of every age-based arbitration) at s_setprio 1
 #define EVT_PIPE_PRIO 0
 #endif
+#ifndef EVT_PIPE_SKEW     // n > 0: behind every barrier wave w idles (w % 4) * n cycles, so that the waves of a workgroup -- released together, running
+#define EVT_PIPE_SKEW 0     // the same stream -- do not all hand their loads / LDS stores to the CU's single address and LDS paths in the same cycle
+#endif
 #ifndef EVT_PIPE_PIN     // 1: sched_barrier between groups (the source order is the issue order)
 #define EVT_PIPE_PIN 1
 #endif
@@ -311,6 +314,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
   auto barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (EVT_PIPE_SKEW > 0) {
+      for (int i = 0; i < (wave & 3); ++i) asm volatile("s_nop %0" ::"n"(EVT_PIPE_SKEW > 0 ? EVT_PIPE_SKEW - 1 : 0));
+    }
     asm volatile("" ::: "memory");
   };
 

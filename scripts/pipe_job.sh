@@ -20,10 +20,10 @@ case $what in
       env $cfg python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
     done ;;
   kbv=*)   # build variants under scripts/probes/bin/libevt_<v>.so
-    for v in $(echo ${what#kbv=} | tr ',' ' '); do
-      echo "== variant $v" | tee -a $OUT/kb.txt
-      EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
-    done ;;
+    for v in $(echo ${what#kbv=} | tr ',' ' '); do for w in ${KBW:-8}; do
+      echo "== variant $v, $w waves" | tee -a $OUT/kb.txt
+      EVT_PIPE_WAVES=$w EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
+    done; done ;;
   prof=*)  # phase profile of the pipe kernel (variant library built with -DEVT_PROF): prof=<variant>
     for shp in qkv mlp1 mlp2 proj; do
       EVT_LIB=$PWD/scripts/probes/bin/libevt_${what#prof=}.so python scripts/gemm_prof.py --shape $shp 2>&1 | grep -v amdgpu.ids | tee -a $OUT/prof.txt
@@ -52,6 +52,11 @@ case $what in
       find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "p_counter_collection.csv" -delete; rm -rf $OUT/pmc_${tag}_*
     done
     unset EVT_GEMM_PIPE EVT_PIPE_WAVES ;;
+  tiles)   # forced tile shapes on the headline launches (EVT_GEMM_BIG: 2 = 256x256, 4 = 256x192, 3 = 256x128), 8 and 4 waves
+    for w in 8 4; do for mode in 2 4 3; do
+      echo "== EVT_GEMM_BIG=$mode, $w waves" | tee -a $OUT/tiles.txt
+      EVT_PIPE_WAVES=$w EVT_GEMM_BIG=$mode python scripts/kbench.py --clips 256 --only linear_qkv,linear_mlp1_gelu,mlp 2>&1 | grep -v "amdgpu.ids\|^#" | tee -a $OUT/tiles.txt
+    done; done ;;
   gl)      # the kernel-level GEMM tests
     timeout 900 python -m pytest tests -m gpu -q -x -k "gated_linear or gated_mlp or big_tiles or operating_point" 2>&1 | tail -5 | tee -a $OUT/gl.txt ;;
   *) echo "unknown step $what" ;;
