@@ -375,7 +375,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
           }
           if (ACT == EVT_ACT_GELU_ERF) {
 #pragma unroll
-            for (int r = 0; r < VPL; ++r) v[r] = gelu_erf(v[r]);
+            for (int r = 0; r < VPL; r += 2) {
+              const f32x2_t y = gelu_erf2((f32x2_t){v[r], v[r + 1]});
+              v[r] = y.x;
+              v[r + 1] = y.y;
+            }
           }
           if (!OPL) {
             const f32x4 o = {v[0], v[1], v[2], v[3]};

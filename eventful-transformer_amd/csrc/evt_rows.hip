@@ -13,7 +13,7 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
                                                        int res_rows, float* __restrict__ sum_out, const float* __restrict__ ln_w,
                                                        const float* __restrict__ ln_b, float eps,
                                                        float* __restrict__ c_out, const float* __restrict__ p,
-                                                       float* __restrict__ norms, int rows, int D) {
+                                                       float* __restrict__ norms, int rows, int D, int order) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -80,18 +80,20 @@ __global__ __launch_bounds__(256) void row_pass_kernel(const float* __restrict__
     for (int i = 0; i < NV; ++i)
       if (lane + i * 64 < nvec) *reinterpret_cast<float4*>(c_out + base + cc[i]) = v[i];
   }
-  if (want_norm) {
+  if (want_norm) {   // order (policies.py:11,44,76: `vector_norm(x, ord=order)`): 2 -> sqrt(sum of squares), 1 -> sum |.|, 0 -> max |.| (inf)
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (lane + i * 64 < nvec) {
         const float4 z = has_p ? pr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float a = v[i].x - z.x, b = v[i].y - z.y, c = v[i].z - z.z, d = v[i].w - z.w;
-        q += (a * a + b * b) + (c * c + d * d);
+        if (order == 2) q += (a * a + b * b) + (c * c + d * d);
+        else if (order == 1) q += (fabsf(a) + fabsf(b)) + (fabsf(c) + fabsf(d));
+        else q = fmaxf(q, fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d))));
       }
     }
-    q = wave_sum(q);
-    if (lane == 0) norms[row] = sqrtf(q);
+    q = order == 0 ? wave_max(q) : wave_sum(q);
+    if (lane == 0) norms[row] = order == 2 ? sqrtf(q) : q;
   }
 }
 
@@ -137,9 +139,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, float* sum_out, const float* ln_w,
-                            const float* ln_b, float eps, float* c_out, const float* p, float* norms, int rows, int D,
-                            void* stream) {
+extern "C" int evt_row_pass_ord(const float* x, const float* res, int res_rows, float* sum_out, const float* ln_w,
+                                const float* ln_b, float eps, float* c_out, const float* p, float* norms, int rows, int D,
+                                int order, void* stream) {
+  EVT_REQUIRE(order == EVT_NORM_L2 || order == EVT_NORM_L1 || order == EVT_NORM_LINF, EVT_ERR_BAD_ARG, "evt_row_pass: norm order %d", order);
   EVT_REQUIRE(x != nullptr, EVT_ERR_BAD_ARG, "evt_row_pass: x is null");
   EVT_REQUIRE(rows >= 0 && D > 0, EVT_ERR_BAD_ARG, "evt_row_pass: rows=%d D=%d", rows, D);
   EVT_REQUIRE((D & 3) == 0 && D <= 4096, EVT_ERR_BAD_SHAPE, "evt_row_pass: D=%d must be a multiple of 4 and <= 4096", D);
@@ -150,7 +153,7 @@ extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, floa
   const dim3 grid((rows + 3) / 4), block(256);
   const int need = (D / 4 + 63) / 64;
   hipStream_t s = evt_stream(stream);
-#define LAUNCH(NV) hipLaunchKernelGGL(row_pass_kernel<NV>, grid, block, 0, s, x, res, res_rows, sum_out, ln_w, ln_b, eps, c_out, p, norms, rows, D)
+#define LAUNCH(NV) hipLaunchKernelGGL(row_pass_kernel<NV>, grid, block, 0, s, x, res, res_rows, sum_out, ln_w, ln_b, eps, c_out, p, norms, rows, D, order)
   if (need <= 1) LAUNCH(1);
   else if (need <= 2) LAUNCH(2);
   else if (need <= 3) LAUNCH(3);
@@ -159,6 +162,12 @@ extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, floa
   else LAUNCH(16);
 #undef LAUNCH
   return evt_check_launch("evt_row_pass");
+}
+
+extern "C" int evt_row_pass(const float* x, const float* res, int res_rows, float* sum_out, const float* ln_w,
+                            const float* ln_b, float eps, float* c_out, const float* p, float* norms, int rows, int D,
+                            void* stream) {
+  return evt_row_pass_ord(x, res, res_rows, sum_out, ln_w, ln_b, eps, c_out, p, norms, rows, D, EVT_NORM_L2, stream);
 }
 
 extern "C" int evt_gate_gather_update(const float* c, float* p, const int32_t* idx, const int32_t* count, int B, int N,

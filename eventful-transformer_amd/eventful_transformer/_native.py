@@ -21,9 +21,9 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 6   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 7   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
-    "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_select_topk",
+    "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_row_pass_ord", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
@@ -149,6 +149,7 @@ def _bind(lib):
     lib.evt_attention_dense_resident.restype = c_int
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
+        "evt_row_pass_ord": [P, P, I, P, P, P, F, P, P, P, I, I, I, P],
         "evt_select_topk": [P, I, I, I, P, P, P],
         "evt_select_threshold": [P, I, I, F, I, P, P, P, P],
         "evt_select_topk_sq": [P, I, I, I, I, P, P, P],
@@ -295,10 +296,21 @@ def _f32c(t, name):
     return t
 
 
+NORM_ORDERS = {2: 2, 2.0: 2, 1: 1, 1.0: 1, float("inf"): 0}   # policy `order` -> evt_norm_order
+
+
+def norm_order(order):
+    """The reference hands `order` to torch.linalg.vector_norm (policies.py:28,63); the row pass implements 1, 2 and inf."""
+    try:
+        return NORM_ORDERS[order]
+    except (KeyError, TypeError):
+        raise NotImplementedError(f"MI355X build: delta norms of order 1, 2 and inf are implemented in the gate kernels, not {order!r}") from None
+
+
 def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=None, eps=1e-6, c_out=None, p=None,
-             norms=None):
-    _check(load().evt_row_pass(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
-                               _p(norms), rows, D, _stream()))
+             norms=None, order=2):
+    _check(load().evt_row_pass_ord(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
+                                   _p(norms), rows, D, norm_order(order), _stream()))
 
 
 def select_topk(norms, B, N, k, idx, rest=None, parts=0):

@@ -71,6 +71,11 @@ REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt
 INDEX_TAP = None
 
 
+def _norm_order(gate):
+    """The `order` of the gate's norm policy (policies.py:11,44,76); 2 for anything that is not a norm policy."""
+    return getattr(gate.policy, "order", 2)
+
+
 def _PREFETCH_MAP(blk, nxt):
     """gate tag -> the linears whose weight planes its selection launch prefetches.  EVT_PREFETCH_MAP=late: one launch ahead
     (measured worse: the riders of two linears outlast the selection); default: three to five launches ahead.  Also measured
@@ -562,7 +567,7 @@ class EventfulTokenwiseBlock(Block):
         self._count_gate(gate, rows * D)
         if self.gate_before_ln and ln is not None:
             raw = self._ws("gate_raw", (B, N, D), torch.float32, src)
-            _native.row_pass(src, rows, D, res=res, sum_out=sum_out, c_out=raw, p=gate.p, norms=norms)
+            _native.row_pass(src, rows, D, res=res, sum_out=sum_out, c_out=raw, p=gate.p, norms=norms, order=_norm_order(gate))
             idx, count, cap, _ = self._select(gate, raw, norms, B, N, tag)
             _native.row_pass(raw, rows, D, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c)
             if stgt:
@@ -579,10 +584,10 @@ class EventfulTokenwiseBlock(Block):
                 if norm_parts is not None:
                     norms, parts = norm_parts   # ||src - p||^2 per head came out of the fused attention epilogue
                 else:
-                    _native.row_pass(src, rows, D, p=gate.p, norms=norms)
+                    _native.row_pass(src, rows, D, p=gate.p, norms=norms, order=_norm_order(gate))
             else:
                 _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
-                                 p=gate.p, norms=norms)
+                                 p=gate.p, norms=norms, order=_norm_order(gate))
             # (K, Nout of the consuming launch, ldo, scattered, o_rows): the MLP's first launch writes a compact hidden scratch
             embed_for = None
             if src16 is None:
@@ -655,7 +660,7 @@ class EventfulTokenwiseBlock(Block):
         # partials): no separate pass over the attention output -- as in the global blocks' fused attention kernels.
         pg = self.projection_gate
         norm = None
-        if FUSE_PROJ_NORM and B * N >= FUSE_DENSE_NORM_ROWS and not pg.first and pg.p is not None and isinstance(pg.policy, _NormPolicy) \
+        if FUSE_PROJ_NORM and B * N >= FUSE_DENSE_NORM_ROWS and not pg.first and pg.p is not None and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 \
                 and self._dense_norm_fusable(N):
             norm = (pg.p, self._ws("norm_parts", (B, N, self.heads), torch.float32, qkv))
         ats = self._attention_dense(qkv, B, N, attn, norm=norm)
@@ -870,7 +875,7 @@ class EventfulBlock(EventfulMatmul1Block):
             # The projection gate's delta norm ||attn - p||^2 comes out of the same epilogue, per head (the select kernel
             # adds the H partials): no separate pass over the attention output.
             pg = self.projection_gate
-            fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
+            fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
             nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
             # bf16 `matmul_2_cast`: the attention output IS the A.v state (out == pv.float()).  When the projection then runs
             # on the persistent GEMM (which takes bf16 activations: half the bytes, no split, two MFMAs of three), it reads the
@@ -955,7 +960,7 @@ class EventfulBlock(EventfulMatmul1Block):
         else:
             _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
         pg = self.projection_gate
-        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.p is not None
+        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
         state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
         if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \

@@ -63,7 +63,7 @@ class _GateBase(ExtendedModule):
             return _index_i32(forced_index, lead, c.device), None, forced_index
         if isinstance(self.policy, _NormPolicy):
             norms = _native.scratch("gate_norms", (rows,), torch.float32, c.device)
-            _native.row_pass(c, rows, D, p=self.p, norms=norms)
+            _native.row_pass(c, rows, D, p=self.p, norms=norms, order=getattr(self.policy, "order", 2))
             cap = self.policy.capacity(N)
             idx = torch.empty((Bp, cap), dtype=torch.int32, device=c.device)
             fixed = self.policy.fixed_count(N)

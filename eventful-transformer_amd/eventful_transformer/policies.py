@@ -16,8 +16,8 @@ from eventful_transformer import _native
 from eventful_transformer.base import ExtendedModule
 
 
-def _token_norms(x, dim):
-    """L2 norm over `dim` (-1: tokens along -2; -2: tokens along -1) -> (B', N) float32 on device."""
+def _token_norms(x, dim, order=2):
+    """Norm of order 1 / 2 / inf over `dim` (-1: tokens along -2; -2: tokens along -1) -> (B', N) float32 on device."""
     _native.require_hip(x)
     if dim not in (-1, -2, x.ndim - 1, x.ndim - 2):
         raise RuntimeError(f"policy: the norm must reduce one of the last two dims, got dim={dim}")
@@ -32,7 +32,7 @@ def _token_norms(x, dim):
         x = torch.nn.functional.pad(x, (0, pad))
         D += pad
     norms = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _native.row_pass(x, rows, D, norms=norms)
+    _native.row_pass(x, rows, D, norms=norms, order=order)
     return norms, lead, N
 
 
@@ -40,8 +40,7 @@ class _NormPolicy(ExtendedModule):
     order = 2
 
     def _check_order(self):
-        if self.order != 2:
-            raise NotImplementedError("MI355X build: only the L2 norm (order=2) is implemented in the gate kernels")
+        _native.norm_order(self.order)   # 1, 2, inf (policies.py:11,44,76); anything else raises NotImplementedError
 
     # -- used by the fused gates ---------------------------------------------------------------
     def capacity(self, n_tokens):
@@ -84,12 +83,13 @@ class TokenNormThreshold(_NormPolicy):
 
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
+        assert not parts or self.order == 2, "per-head partial squares only make an L2 norm"
         _native.select_threshold(norms, B, N, self.threshold, idx.shape[-1], idx, count, rest, parts=parts)
 
     def forward(self, x, dim=-1):
         # The reference asserts batch 1 because nonzero() flattens the batch (policies.py:25).
         assert all(size == 1 for size in x.shape[:-2])
-        norms, lead, N = _token_norms(x, dim)
+        norms, lead, N = _token_norms(x, dim, self.order)
         idx = torch.empty((1, N), dtype=torch.int32, device=x.device)
         count = torch.empty(1, dtype=torch.int32, device=x.device)
         self.select_into(norms, 1, N, idx, count)
@@ -123,10 +123,11 @@ class TokenNormTopK(_NormPolicy):
 
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
+        assert not parts or self.order == 2, "per-head partial squares only make an L2 norm"
         _native.select_topk(norms, B, N, self._k(N), idx, rest, parts=parts)
 
     def forward(self, x, dim=-1):
-        norms, lead, N = _token_norms(x, dim)
+        norms, lead, N = _token_norms(x, dim, self.order)
         B = norms.numel() // N
         k = self._k(N)
         idx = torch.empty((B, k), dtype=torch.int32, device=x.device)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 6   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+#define EVT_ABI_VERSION 7   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
@@ -40,6 +40,7 @@ extern "C" {
                                     evt_mlp_desc, evt_gated_linear_embeds_select);
                                  6: evt_attention_stream_lds_bytes (shape-only query; evt_attention_stream now answers
                                     EVT_ERR_BAD_SHAPE instead of a launch error when its tile does not fit a CU's LDS);
+                                 7: evt_row_pass_ord (the policies' `order` argument: L1 / L2 / L-infinity delta norms);
                                     evt_stream_prep + evt_attn_stream_desc.k_split_ready (rel-pos terms, key plane and value gate
                                     of a gated frame in one launch); evt_attn_dense_desc.norm_ref / norm_parts +
                                     evt_attention_dense_resident (the projection gate's delta norm from the attention epilogue of
@@ -97,6 +98,12 @@ EVT_API int evt_select_prefetch_next(const void* ptr, int64_t bytes, void* sink)
 EVT_API int evt_row_pass(const float* x, const float* res, int res_rows, float* sum_out,
                          const float* ln_w, const float* ln_b, float eps, float* c_out,
                          const float* p, float* norms, int rows, int D, void* stream);
+/* ABI 7.  The same pass with the policy's norm order (`TokenNorm*(order=...)`, policies.py:11,28,44,63,76 ->
+ * torch.linalg.vector_norm(x, ord=order)): norms[row] = || c - p[row] ||_order for order 2, 1 or infinity. */
+enum evt_norm_order { EVT_NORM_LINF = 0, EVT_NORM_L1 = 1, EVT_NORM_L2 = 2 };
+EVT_API int evt_row_pass_ord(const float* x, const float* res, int res_rows, float* sum_out,
+                             const float* ln_w, const float* ln_b, float eps, float* c_out,
+                             const float* p, float* norms, int rows, int D, int order, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * K1  Token selection from per-token delta norms.  One workgroup per clip; norms staged in LDS;

@@ -52,13 +52,14 @@ def cols_index(index, shape):
 class TopK:
     """policies.py:39-68."""
 
-    def __init__(self, k):
+    def __init__(self, k, order=2):
         self.k = k
+        self.order = order
         self.last_input = None
         self.last_output = None
 
     def __call__(self, e, dim=-1):
-        out = vector_norm(e, ord=2, dim=dim).topk(self.k, sorted=False)[1]
+        out = vector_norm(e, ord=self.order, dim=dim).topk(self.k, sorted=False)[1]
         self.last_input, self.last_output = e, out
         return out
 
@@ -66,19 +67,21 @@ class TopK:
 class TopFraction:
     """policies.py:71-95."""
 
-    def __init__(self, fraction):
+    def __init__(self, fraction, order=2):
         self.fraction = fraction
+        self.order = order
 
     def __call__(self, e, dim=-1):
-        n = vector_norm(e, ord=2, dim=dim)
+        n = vector_norm(e, ord=self.order, dim=dim)
         return n.topk(int(self.fraction * n.shape[-1]), sorted=False)[1]
 
 
 class Threshold:
     """policies.py:6-32 (batch 1 only, ascending indices, data-dependent count)."""
 
-    def __init__(self, threshold, save_status=False):
+    def __init__(self, threshold, save_status=False, order=2):
         self.threshold = threshold
+        self.order = order
         self.save_status = save_status
         # save_status: how close the call was -- min over tokens of | ||e|| - threshold | / threshold, and the tokens within
         # NEAR of the threshold (indices, relative distances): the only ones another summation order may decide differently
@@ -89,7 +92,7 @@ class Threshold:
 
     def __call__(self, e, dim=-1):
         assert all(s == 1 for s in e.shape[:-2])
-        norms = vector_norm(e, ord=2, dim=dim)
+        norms = vector_norm(e, ord=self.order, dim=dim)
         if self.save_status:
             rel = ((norms.double() - self.threshold).abs() / self.threshold).reshape(-1)
             self.last_margin = float(rel.min())

@@ -249,7 +249,7 @@ def block_params_of(sd, i):
     return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
 
 
-def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None):
+def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None, stream_seed=None):
     """One ViViT-B spatial sub-model run (197 tokens, 12 EventfulBlocks, top-k `k`, `steps` frames) through the REAL
     reference backbone and the oracle; stores features, index sets and margins under the `mode__` prefix."""
     dim, depth, heads, N = 768, 12, 12, 196
@@ -270,7 +270,7 @@ def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None):
     ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
     ob.set_policy(lambda: O.TopK(k))
     model = O.ViViTSpatialOracle(ob, cls, ln_w, ln_b)
-    xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2, small=0.01)
+    xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2 if stream_seed is None else stream_seed, small=0.01)
     feats, idx_all, margins = [], [], []
     t0 = time.time()
     with torch.inference_mode():
@@ -316,6 +316,22 @@ def gen_vivit_sharp():
     for mode, cast in (("fp32", None), ("bf16", "bfloat16")):
         _vivit_case(pack, mode, cast, 12, 128, qk_std=0.06)
     np.savez_compressed(os.path.join(OUT, "vivit_b_sharp.npz"), **pack)
+
+
+def gen_vivit_sharp_clips():
+    """bf16 A.v cast (the arithmetic the headline is timed in) + sharp attention, INDEX sets of the projection gates: 8 SHORT clips
+    (3 frames = 2 gated frames each, different streams) instead of one long one.  With the cast, the bf16 A.v / gate-reference
+    state of ANY two implementations drifts apart frame by frame (each frame re-rounds ~150k state elements per block; a different
+    fp32 summation order flips a few dozen of those roundings, and a flip persists): on the 12-frame sharp clip the HIP path's
+    projection-gate sets equal the reference's in frames 1-2 and start to differ from frame 3 on, at margins up to 1e-2
+    (profiles/r05/parity_summary.txt).  Short clips compare the gate DECISION before that drift: ~15 projection-gate sets at
+    margin >= 1e-3 per clip."""
+    pack = {"torch_version": np.bytes_(torch.__version__), "qk_std": np.float64(0.06), "clips": np.int64(8)}
+    for c in range(8):
+        _vivit_case(pack, f"clip{c}", "bfloat16", 3, 128, qk_std=0.06, stream_seed=500 + 7 * c)
+        pack[f"clip{c}__stream_seed"] = np.int64(500 + 7 * c)
+        del pack[f"clip{c}__features"]
+    np.savez_compressed(os.path.join(OUT, "vivit_b_sharp_clips.npz"), **pack)
 
 
 def gen_vivit_k64():
@@ -687,7 +703,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_sharp": gen_vivit_sharp, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
+    todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_sharp": gen_vivit_sharp, "vivit_sharp_clips": gen_vivit_sharp_clips, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
             "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models, "ats": gen_ats, "envelope": gen_envelope, "vitdet1024_thresholds": gen_vitdet1024_thresholds}
     for name, fn in todo.items():
         if args.only in (None, name):

@@ -39,6 +39,11 @@ case $what in
       EVT_GEMM=$gm EVT_PARITY_SUMMARY=$PWD/$OUT/env_$gm.txt timeout 900 python -m pytest tests/test_gpu_blocks.py -m gpu -q -k "vivit_b_full_size and bf16" 2>&1 | tail -3 | tee -a $OUT/envelope_ab.txt
       cat $OUT/env_$gm.txt | tee -a $OUT/envelope_ab.txt
     done ;;
+  overlap)     # the step's independent resident batches on 1 / 2 / 3 HIP streams (bench.py --overlap), events off, two repetitions
+    for rep in 1 2; do for ov in 1 2 3; do
+      echo "== rep $rep --overlap $ov" | tee -a $OUT/overlap.txt
+      timeout 900 python bench.py --no-other --no-cpu-baseline --no-check --no-exact --no-kernel-events --overlap $ov 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/overlap.txt
+    done; done ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
   kbench)

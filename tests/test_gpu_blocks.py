@@ -81,6 +81,35 @@ def test_reset_and_state_attributes():
         assert torch.equal(a, b)  # deterministic (I7)
 
 
+@pytest.mark.parametrize("order", [1, float("inf")])
+@pytest.mark.parametrize("kind,cast", [("EventfulBlock", "bfloat16"), ("EventfulTokenwiseBlock", None)])
+def test_blocks_with_l1_and_linf_norm_policies(kind, cast, order):
+    """`TokenNormTopK(order=...)` (policies.py:44,63): the gates select on the L1 / L-infinity norm of the delta.  The fused projection-gate
+    norm (per-head partial squares out of the attention epilogue) only makes an L2 norm, so these orders take the row pass; outputs and
+    index sets against the CPU oracle with the same `order`."""
+    from eventful_transformer import policies
+    params = O.make_block_params(64, 4, seed=13, std=0.08)
+    kw = dict(matmul_2_cast=cast) if cast else {}
+    blk = H.product_block(kind, params, 64, 4, (6, 6), **kw)
+    H.set_policies(blk, policies.TokenNormTopK, k=12, order=order)
+    ob = O.BlockOracle(kind, params, 64, 4, (6, 6), **kw)
+    ob.set_policy(lambda: O.TopK(12, order=order))
+    xs = O.make_token_stream(2, 36, 64, 4, 12, seed=14, small=0.02)
+    got = []
+    hooks = _grab_index_sets(type("BB", (), {"blocks": [blk]})(), 12, got)
+    with torch.inference_mode():
+        for t in range(4):
+            y = blk(xs[t].to(DEV)).cpu()
+            y_ref = ob.forward(xs[t].clone())
+            assert float((y - y_ref).abs().max()) <= (1e-3 if cast else 2e-4), (t, float((y - y_ref).abs().max()))
+            if t > 0:
+                for gi, key in enumerate(("qkv_index", "projection_index", "mlp_index")):
+                    want = ob.trace[key].sort(dim=-1)[0][0].numpy().astype(np.int64)
+                    assert np.array_equal(got[t][gi], want), (t, key)
+    for h in hooks:
+        h.remove()
+
+
 def test_threshold_zero_selected_freezes_buffers():
     """I6: r = 0 everywhere -> all buffers frozen, output moves only through the residual."""
     from eventful_transformer import policies
@@ -191,9 +220,8 @@ def test_vivit_b_full_size(golden_dir, fixture, k, mode, cast, tol):
     # 1e-3 on features, north_star).  bf16 A.v cast: every flipped bf16 rounding of an A.v state element persists and
     # gates with margins down to 1e-9 fork; the reference then agrees with itself on 74-82 % of all sets (k = 128: 100 %
     # of the sets with margin >= 1e-3; k = 64, 31 gated frames: 86-87 %) with feature gaps of 6.7e-2 / 8.2e-2.  The HIP
-    # path (split-precision GEMMs: 1e-5 instead of 1e-6 relative on top of the reordering) must stay within 0.12 of the
-    # reference's lowest self-agreement over all gates, within 0.06 on the margin >= 1e-3 subset, and within 1.5 x its
-    # largest feature gap; the strict bf16 check is the teacher-forced test below.
+    # path must stay within a measured, arithmetic-mode-dependent distance of the reference's lowest self-agreement (below)
+    # and within 1.5 x its largest feature gap; the strict bf16 check is the teacher-forced test below.
     env = H.load_npz(os.path.join(golden_dir, "envelope.npz"))
     tag = "k128" if k == 128 else "k64"
     ref_all = float(env[f"{tag}__{mode}__agreement_all"].min())
@@ -209,9 +237,29 @@ def test_vivit_b_full_size(golden_dir, fixture, k, mode, cast, tol):
         if qk_std is not None:
             assert proj >= 60, proj
     else:
-        assert agree / total >= ref_all - 0.12, (agree, total, ref_all)
-        assert strict_ok / strict >= ref_strict - 0.06, (strict_ok, strict, ref_strict)
+        # How far below the reference's own self-agreement?  Measured (profiles/r05/envelope_split_vs_f32.txt): with EXACT-fp32 GEMMs
+        # (EVT_GEMM=f32: the fp32-input MFMA, bitwise an fmaf chain) the HIP path lands inside / at the edge of the envelope
+        # (k = 128: 0.8167 vs >= 0.7833; k = 64: 0.7294 vs >= 0.7446, 0.8526 vs >= 0.8581 on the margin subset); with the
+        # split-precision GEMMs (1e-5 instead of 1e-6 relative per product) near-tied gates fork a few frames earlier: 0.7167,
+        # 0.7007 / 0.8426.  The slack is therefore tied to the arithmetic mode: 0.03 / 0.02 for exact fp32 (test_envelope_exact_fp32_gemm
+        # runs this test in that mode), 0.08 / 0.03 for the split mode.
+        from eventful_transformer import _native
+        slack_all, slack_strict = (0.03, 0.02) if _native.GEMM_MODE == "f32" else (0.08, 0.03)
+        assert agree / total >= ref_all - slack_all, (agree, total, ref_all)
+        assert strict_ok / strict >= ref_strict - slack_strict, (strict_ok, strict, ref_strict)
         assert worst <= 1.5 * ref_gap, (mode, worst, ref_gap)
+
+
+def test_envelope_exact_fp32_gemm():
+    """The bf16-mode free-running tests once more with exact-fp32 GEMMs (the library reads EVT_GEMM once per process): the HIP path
+    must then sit within 0.03 / 0.02 of the reference's own self-agreement -- the evidence that the rest of the distance seen in the
+    default mode is the split arithmetic and not a defect of the gated path."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EVT_GEMM="f32")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "vivit_b_full_size and bf16",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_vivit_b_dense_config1():
@@ -257,8 +305,7 @@ class _ForcedPolicy:
 @pytest.mark.parametrize("fixture,k,mode,cast,out_tol,min_margin", [("vivit_b.npz", 128, "fp32", None, 5e-4, 1e-4),
                                                                     ("vivit_b.npz", 128, "bf16", "bfloat16", 1e-3, 1e-3),
                                                                     ("vivit_b_k64.npz", 64, "bf16", "bfloat16", 1e-3, 2e-3),
-                                                                    ("vivit_b_sharp.npz", 128, "fp32", None, 5e-4, 1e-3),
-                                                                    ("vivit_b_sharp.npz", 128, "bf16", "bfloat16", None, 1e-3)])
+                                                                    ("vivit_b_sharp.npz", 128, "fp32", None, 5e-4, 1e-3)])
 def test_vivit_b_teacher_forced(golden_dir, fixture, k, mode, cast, out_tol, min_margin):
     """Full-size ViViT-B, teacher-forced block by block AND gate by gate:
       * every block is fed the ORACLE's input for that block;
@@ -271,22 +318,60 @@ def test_vivit_b_teacher_forced(golden_dir, fixture, k, mode, cast, out_tol, min
         one set that differed in these runs had a reference margin of 1.06e-3: bar 1e-3 at k = 128, 2e-3 at k = 64).
     `vivit_b_sharp.npz` (sharp attention, O.sharpen_qk; all 12 frames; fp32 mode, where north_star's bit-exact bar holds): the
     projection gate's norms are spread out there, so its sets are compared too -- at least 60 projection-gate sets with a
-    reference margin >= 1e-3 must be bit-equal.  With the bf16 A.v cast (the arithmetic the headline is timed in) a sharp
-    attention output of magnitude ~1 carries a 2^-9 rounding step of its own, so the sharp fixture's bf16 mode is an INDEX-ONLY
-    check (out_tol = None: the block-output error is reported, not bounded; the 1e-3 output bar of the cast mode stays tied to
-    the std-0.02 fixtures): all gate sets at reference margin >= 1e-3, at least 60 projection-gate sets among them."""
+    reference margin >= 1e-3 must be bit-equal.  (The bf16 A.v cast with sharp attention: test_vivit_b_sharp_bf16_projection_gates.)"""
     g = H.load_npz(os.path.join(golden_dir, fixture))
     seed = int(g[f"{mode}__seed"])
     sharp = "qk_std" in g.files
     model, sd, cls, ln_w, ln_b = H.vivit_oracle(cast, seed=seed, k=k, qk_std=float(g["qk_std"]) if sharp else None)
     bb = H.product_vivit(sd, cast)
+    steps = g[f"{mode}__features"].shape[0] if sharp else 4
+    checked, mismatched, per_gate, worst = _teacher_forced_clip(model, bb, cls, g, mode, k, steps, seed + 2, out_tol, min_margin, fixture)
+    H.report(f"\n[teacher-forced {fixture} {mode}] {steps} frames: worst block-output error {worst:.3e} (bar {out_tol:.0e}); index sets at "
+             f"reference margin >= {min_margin:.0e}: {checked - mismatched}/{checked} equal; per gate (checked, equal): {per_gate}")
+    assert checked >= 60 and mismatched == 0, (checked, mismatched)
+    if sharp:
+        assert per_gate["projection_gate"][0] >= 60, per_gate
+
+
+def test_vivit_b_sharp_bf16_projection_gates(golden_dir):
+    """The headline's own arithmetic mode (bf16 A.v cast) where it is most fragile: PROJECTION-gate index sets under sharp attention,
+    index-only (no output bar: a sharp attention output of magnitude ~1 carries a 2^-9 rounding step of its own).
+    `vivit_b_sharp_clips.npz` = the REAL reference on 8 short clips (3 frames each): with the cast the bf16 A.v / gate-reference state
+    of any two implementations drifts apart frame by frame (every frame re-rounds the state; another fp32 summation order flips a few
+    dozen roundings per block and a flip persists) -- on the 12-frame sharp clip the sets are equal in frames 1-2 and differ from
+    frame 3 on at margins up to 1e-2 -- so the gate DECISION is compared before the drift, teacher-forced block by block: every
+    gate's set with a reference margin >= 1e-3 must be bit-equal, at least 60 projection-gate sets among them."""
+    g = H.load_npz(os.path.join(golden_dir, "vivit_b_sharp_clips.npz"))
+    k, cast = 128, "bfloat16"
+    tot_checked = tot_mis = 0
+    tot_gate = {}
+    worst_all = 0.0
+    model, sd, cls, ln_w, ln_b = H.vivit_oracle(cast, seed=int(g["clip0__seed"]), k=k, qk_std=float(g["qk_std"]))
+    bb = H.product_vivit(sd, cast)
+    for c in range(int(g["clips"])):
+        model.backbone.reset()
+        bb.reset()
+        checked, mismatched, per_gate, worst = _teacher_forced_clip(model, bb, cls, g, f"clip{c}", k, 3, int(g[f"clip{c}__stream_seed"]),
+                                                                    None, 1e-3, "vivit_b_sharp_clips.npz")
+        tot_checked += checked
+        tot_mis += mismatched
+        worst_all = max(worst_all, worst)
+        for gn, (a, b) in per_gate.items():
+            tot_gate[gn] = [tot_gate.get(gn, [0, 0])[0] + a, tot_gate.get(gn, [0, 0])[1] + b]
+    H.report(f"\n[teacher-forced vivit_b_sharp_clips.npz bf16, {int(g['clips'])} clips x 2 gated frames] index sets at reference margin >= 1e-3: "
+             f"{tot_checked - tot_mis}/{tot_checked} equal; per gate (checked, equal): {tot_gate}; worst block-output error {worst_all:.3e} (not bounded)")
+    assert tot_mis == 0 and tot_gate["projection_gate"][0] >= 60, (tot_mis, tot_gate)
+
+
+def _teacher_forced_clip(model, bb, cls, g, mode, k, steps, stream_seed, out_tol, min_margin, fixture):
+    """One clip, teacher-forced block by block and gate by gate (see test_vivit_b_teacher_forced) -> (sets checked, sets that differ,
+    per gate [checked, equal], worst block-output error)."""
     gate_names = ("qkv_gate", "projection_gate", "mlp_gate")
     trace_keys = ("qkv_index", "projection_index", "mlp_index")
     for blk in bb.blocks:
         for gn in gate_names + ("v_gate", "matmul_gate"):
             getattr(blk, gn).policy = _ForcedPolicy(k)
-    steps = g[f"{mode}__features"].shape[0] if sharp else 4
-    xs = O.make_token_stream(1, 196, 768, steps, k, seed=seed + 2, small=0.01)
+    xs = O.make_token_stream(1, 196, 768, steps, k, seed=stream_seed, small=0.01)
     margins = g[f"{mode}__margins"]
     idx_gold = g[f"{mode}__idx"]
     checked = mismatched = 0
@@ -317,11 +402,7 @@ def test_vivit_b_teacher_forced(golden_dir, fixture, k, mode, cast, out_tol, min
                                 H.report(f"\n[teacher-forced {fixture} {mode}] frame {t} block {bi} {gn}: HIP set differs, "
                                          f"reference margin {margins[t - 1, bi, gi]:.3e}")
                 x = y_ref
-    H.report(f"\n[teacher-forced {fixture} {mode}] {steps} frames: worst block-output error {worst:.3e} (bar {out_tol if out_tol is None else format(out_tol, '.0e')}); index sets at "
-             f"reference margin >= {min_margin:.0e}: {checked - mismatched}/{checked} equal; per gate (checked, equal): {per_gate}")
-    assert checked >= 60 and mismatched == 0, (checked, mismatched)
-    if sharp:
-        assert per_gate["projection_gate"][0] >= 60, per_gate
+    return checked, mismatched, per_gate, worst
 
 
 def _vitdet_run(golden_dir, fixture, grid, policy_cls, policy_kw, cast, stream_fn, stride, tol):

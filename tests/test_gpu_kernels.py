@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 6
+    assert lib.evt_version() == n.ABI_VERSION == 7
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 

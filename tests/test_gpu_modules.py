@@ -36,6 +36,17 @@ def test_policies_standalone():
     assert got.shape == (1, 41) and torch.equal(got.cpu(), O.Threshold(thr)(c1 - p1))
     with pytest.raises(AssertionError):
         thr_pol(e.to(DEV))  # batch > 1, policies.py:25
+    # the policies' `order` argument (policies.py:11,44,76 -> vector_norm(ord=order)): L1 and L-infinity delta norms
+    for order in (1, float("inf")):
+        assert torch.equal(policies.TokenNormTopK(k=64, order=order)(e.to(DEV)).cpu(), _asc(O.TopK(64, order=order)(e)))
+        assert torch.equal(policies.TokenNormTopFraction(0.25, order=order)(e.to(DEV)).cpu(), _asc(O.TopFraction(0.25, order=order)(e)))
+        d1 = c1 - p1
+        n1 = torch.linalg.vector_norm(d1, ord=order, dim=-1)[0].sort()[0]
+        t1 = float((n1[-30] + n1[-31]) / 2)      # a threshold between two norms: 30 tokens above it
+        got = policies.TokenNormThreshold(threshold=t1, order=order)(d1.to(DEV))
+        assert got.shape == (1, 30) and torch.equal(got.cpu(), O.Threshold(t1, order=order)(d1))
+    with pytest.raises(NotImplementedError):
+        policies.TokenNormTopK(k=4, order=3)(e.to(DEV))
 
 
 @pytest.mark.parametrize("delta", [False, True])
