@@ -9,9 +9,9 @@ struct LinArgs {
   const int32_t* count; float* p_upd;
   int B, kcap, K, Nout, act;
   float* ws; int64_t ws_bytes;
-  // evt_linear_big.hip only (set by evt_gated_mlp for its hidden scratch): A / out hold hl32 lines instead of fp32
+  // evt_linear_pipe.hip only (set by evt_gated_mlp for its hidden scratch): A / out hold hl32 lines instead of fp32
   int a_planes, out_planes;
-  // evt_linear_big.hip only: A is ONE bf16 plane (row pitch lda elements) of exactly bf16-representable values (ABI 4: a_bf16)
+  // evt_linear_pipe.hip only: A is ONE bf16 plane (row pitch lda elements) of exactly bf16-representable values (ABI 4: a_bf16)
   int a_bf16;
   // evt_linear_small.hip only (ABI 5): the gate's token selection runs INSIDE the launch -- every workgroup selects for the
   // clip(s) of its rows from the delta norms; a_idx / o_idx only say which sides are indexed, the list is sel_idx
@@ -19,13 +19,10 @@ struct LinArgs {
   int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
 };
 
-// evt_linear_big.hip: 256-row tiles for launches that fill the chip.  evt_big_choice: the tile configuration the launch would
-// get (0 = none: run the 128x128 kernel); evt_launch_split_big launches it (false = not taken).
+// evt_linear_pipe.hip: persistent 256-row tiles, software-pipelined k-tiles, for launches that fill the chip.  evt_big_choice: the
+// tile configuration the launch would get (0 = none: run the 128x128 kernel); evt_launch_split_big launches it (false = not taken).
 int evt_big_choice(const LinArgs& a);
 bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
-// evt_linear_pipe.hip: the same tiles on four 512-register waves with a software-pipelined k-tile (round 5); `choice` is
-// evt_big_choice's answer; false = not taken.
-bool evt_launch_split_pipe(const LinArgs& a, hipStream_t s, int choice);
 
 // evt_linear_small.hip: latency-oriented kernel for small gated row counts (one video stream).  Returns the K split it
 // launched with (0 = not taken; > 1 = partial planes in the workspace, the caller runs the finish pass).

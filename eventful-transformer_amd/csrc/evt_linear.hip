@@ -645,7 +645,7 @@ int forced_tile_variant() {
 void launch_split(const LinArgs& a, hipStream_t s) {
   const int forced = forced_tile_variant();
   const int variant = forced < 0 ? 0 : forced;
-  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_big.hip)
+  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_pipe.hip)
   if (forced < 0) {   // a few hundred gated rows (one video stream): the latency-oriented kernel (evt_linear_small.hip)
     const int ks = evt_launch_split_small(a, s);
     if (ks > 1) launch_finish(a, s, ks, 0, (a.Nout + 127) / 128);

@@ -1,31 +1,44 @@
-// evt_linear_pipe.hip -- K3/K7, split-precision gated linear for launches that fill the chip (round 5).
+// evt_linear_pipe.hip -- K3/K7, split-precision gated linear for launches that fill the chip: persistent 256-row workgroup tiles
+// with a software-pipelined k-tile (round 5; replaces the round-2 kernel evt_linear_big.hip, whose numbers are in profiles/r02-r04).
 //
-// ONE WAVE PER SIMD.  The round-2 kernel (evt_linear_big.hip: 8 waves, two per SIMD, 64x128 per wave) was issue-bound: the two
-// waves of a SIMD share its VALU issue (arbitrated by priority, then age -- MI355X_MICROARCH.md "Two waves per SIMD"), so the
-// staging wave's conversions starved beside its partner's MFMA stream, and the multiplying wave had no registers for a
-// second fragment set, i.e. the matrix pipe idled during every fragment read (0.47 busy on QKV, 0.60 at best).  Here a
-// workgroup is FOUR waves of 512 registers, 128 x (TBN / 2) per wave, and each wave runs one software-pipelined instruction
-// stream per k-tile whose order is pinned in the source (sched_barrier between "groups" of three MFMAs):
+// Why tiles of 256 rows: a 128x128 tile moves 1024 operand bytes L2 -> CU per k for 32768 FLOP (32 FLOP/B, ~11 TB/s at 340 TF);
+// 256x256 halves the bytes per FLOP (64 FLOP/B; 256x192: 55) and the per-element staging work.  ONE persistent workgroup per CU; the
+// workgroups of an XCD walk a contiguous run of tiles side by side.  fp32 operands are bf16 hi + lo, three v_mfma_f32_32x32x16_bf16
+// per product (lo.hi, hi.lo, hi.hi), fp32 accumulate; weights come pre-split as hl32 lines, activations are split while staged.
 //
-//   k-tile t, groups 0 .. G-1   : MFMAs on fragment set F0 (k-half 0 of t) | fillers: the G..2G-1 fragment reads of k-half 1
-//                                 (-> F1), split + LDS stores of k-tile t+1 (registers R -> the other stage), the global
-//                                 loads of k-tile t+2 into the registers just freed
-//   one s_barrier per k-tile
-//   groups G .. 2G-1            : MFMAs on F1 | fillers: fragment reads of k-half 0 of k-tile t+1 (-> F0)
+// What was wrong with the round-2 kernel (8 waves, 64x128 per wave, stage / multiply as two phases per k-tile, ONE fragment set):
+// the matrix pipe idled during every fragment read, and the staging wave's conversions starved beside its partner's MFMA stream
+// (0.47 matrix-pipe busy on QKV, 0.60 at best).  Here every wave runs ONE software-pipelined instruction stream per k-tile whose
+// order is pinned in the source (a sched_barrier behind every "slot" = one MFMA + its share of the fillers):
 //
-// so nothing in the stream waits for LDS or HBM except at the barrier, and there are ~3 non-MFMA instructions per MFMA in
-// the staging half (the budget beside a 32-cycle v_mfma_f32_32x32x16_bf16 is 5, MI355X_MICROARCH.md).  256 accumulator
-// registers (a 128x128 wave tile: half the LDS fragment bytes per MFMA of the 64x128 tile), 128 for the two fragment sets, 64
-// staging registers.
+//   slots 0 .. Z-1   : MFMAs of k-tile t (fragment set F0, then F1) | fillers: the fragment reads of its second k-half (-> F1),
+//                      split + LDS stores of k-tile t+1 (registers R -> the other LDS stage), the global loads of k-tile t+2 into
+//                      the registers just freed (a load has a whole k-tile to arrive)
+//   ONE s_barrier per k-tile, at 3/4 of it (so the staging spreads over 3/4 of the MFMAs, ~2.5 fillers per MFMA)
+//   slots Z .. end   : MFMAs on F1 | fillers: fragment reads of the first k-half of k-tile t+1 (-> F0), offset bumps
 //
-// MFMA operand roles are SWAPPED with respect to evt_linear_big.hip: the weight fragment is the A operand, the activation
-// fragment the B operand, so a lane of the accumulator holds ONE output row (token) and FOUR CONSECUTIVE output columns per
-// register quad: the epilogue stores 16 bytes per lane and instruction (fp32) instead of 4, bias values come as one LDS quad.
-// Sums are formed in the same order (k ascending, per accumulator lo.hi, hi.lo, hi.hi): results are bit-identical to the
-// other split-precision kernels (tests/big_tile_check.py compares them).
+// so nothing in the stream waits for LDS or HBM except at the barrier.  Consecutive MFMAs write DIFFERENT accumulators (an instruction
+// between two MFMAs on the same accumulator costs +43 cycles, MI355X_MICROARCH.md).  What was measured on the way (profiles/r05/,
+// DESIGN.md section 6): one wave per SIMD (four 512-register waves, 128x128 per wave) is 3-10 % slower than two 256-register waves
+// -- an in-order wave that is held up ISSUING a global load or an LDS store (~40 cycles each with four waves of a CU doing it at
+// once) has nobody beside it to feed the matrix pipe; a load instruction must address whole 128-byte runs (8 lanes per row), not 64
+// separate 16-byte pieces; 64-bit VALU address arithmetic is replaced by SGPR base + 32-bit running offsets; tile descriptions (gather
+// indices -> byte offsets) are prepared two tiles ahead inside the previous epilogue and parked in LDS, so the k loop has no branchy
+// bookkeeping; 256x192 tiles (QKV: 6.0 rounds of 256 CUs instead of 4.5 -> 5, no register spills) beat 256x256.
 //
-// Operands, gather / scatter / gate-reference refresh and formats (FMT bits: 1 activations pre-split hl32, 2 output hl32,
-// 4 activations one bf16 plane) are those of evt_linear_big.hip.
+// MFMA operand roles: the weight fragment is the A operand, the activation fragment the B operand, so a lane of the accumulator holds
+// ONE output row (token) and FOUR CONSECUTIVE output columns per register quad; the epilogue sends 32-row sub-tiles through a
+// wave-private LDS buffer and stores whole contiguous 16-byte pieces of 8 rows per instruction (16 bytes per lane into 64 different
+// 32-byte segments measured 29k cycles per tile; 4-byte stores, the round-2 form, 12k; this form ~9k for fp32 output).  Sums are formed
+// in the same order as in the 128x128 and small-row kernels (k ascending; per accumulator lo.hi, hi.lo, hi.hi): results are
+// bit-identical to theirs (tests/big_tile_check.py compares them).
+//
+// Formats (FMT bits): 1 = activations pre-split hl32 lines (the MLP's hidden scratch: staging is a copy), 2 = output written as
+// hl32 lines (first half of evt_gated_mlp: GELU(x) is split once per element, in the epilogue), 4 = activations are ONE bf16
+// plane of exactly bf16-representable values (the A.v state of a bf16 matmul_2_cast, blocks.py:183-189, which IS the attention
+// output: hi = the value, lo = 0, the lo.hi MFMA is skipped, the gate reference is refreshed with the widened values).
+// Gather through a_idx while staging, scatter through o_idx in the epilogue, gate reference refresh p[idx] = c[idx] (modules.py:151)
+// from the staged fp32 registers, dealt over the column tiles.
 #include "evt_linear.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -51,20 +64,11 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 #ifndef EVT_PIPE_PINEVERY   // a sched_barrier behind every n-th slot
 #define EVT_PIPE_PINEVERY 1
 #endif
-#ifndef EVT_PIPE_PRIO     // 1: the second-dispatched half of an 8-wave workgroup (the loser of every age-based arbitration) at s_setprio 1
-#define EVT_PIPE_PRIO 0
-#endif
-#ifndef EVT_PIPE_SKEW     // n > 0: behind every barrier wave w idles (w % 4) * n cycles, so that the waves of a workgroup -- released together, running
-#define EVT_PIPE_SKEW 0     // the same stream -- do not all hand their loads / LDS stores to the CU's single address and LDS paths in the same cycle
-#endif
 #ifndef EVT_PIPE_PIN     // 1: sched_barrier between groups (the source order is the issue order)
 #define EVT_PIPE_PIN 1
 #endif
 
 #define PIPE_PIN() do { if (EVT_PIPE_PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
-#ifndef EVT_PIPE_ABLATE  // timing experiments only (results are wrong): 1 no global loads in the k loop, 2 no split arithmetic,
-#define EVT_PIPE_ABLATE 0   // 4 no LDS stores, 8 no fragment reads, 16 no barrier, 32 no MFMA
-#endif
 #ifdef EVT_PROF   // phase timing of wave 0 of one workgroup (scripts/gemm_prof.py): s_memtime at the phase boundaries
 __device__ unsigned long long evt_prof_pipe_buf[8];
 #define PIPE_TICK(slot) do { if (prof_on) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[slot] += now_ - prof_t; prof_t = now_; } } while (0)
@@ -84,9 +88,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 template <int ACT, int TBN, int FMT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kernel(const LinArgs g, int tiles_n, int tiles_total) {
-  // WAVES = 4: one 512-register wave per SIMD, 128 x (TBN / 2) per wave.  WAVES = 8: two 256-register waves per SIMD, 64 x (TBN / 2) per
-  // wave, the same pipelined stream in each -- while one wave of a SIMD is held up ISSUING a global load or an LDS store (measured: ~40
-  // cycles each with four waves of a CU doing it at once; an in-order wave issues no MFMA meanwhile) the other one feeds the matrix pipe.
+  // WAVES = 8 (shipped): two 256-register waves per SIMD, 64 x (TBN / 2) per wave, the same pipelined stream in each.  WAVES = 4 (kept
+  // compilable, not instantiated): one 512-register wave per SIMD, 128 x (TBN / 2) per wave.
   constexpr int TBM = 256, TBK = 32, NT = WAVES * 64;
   static_assert(WAVES == 4 || WAVES == 8, "waves per workgroup");
   constexpr bool APL = (FMT & 1) != 0, OPL = (FMT & 2) != 0, ABF = (FMT & 4) != 0;
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
   float* const bias_tab = reinterpret_cast<float*>(orow_tab + 3 * TBM);       // 3 x TBN
   uint32_t* const stash = reinterpret_cast<uint32_t*>(bias_tab + 3 * TBN);    // NAO x NT: the next tile's activation row offsets of every thread
 
-  // Persistent workgroups, XCD-aware (as evt_linear_big.hip): XCD x owns a contiguous run of row-major tiles.
+  // Persistent workgroups, XCD-aware (workgroup w runs on XCD w % 8): XCD x owns a contiguous run of row-major tiles and its
+  // workgroups walk it side by side, so at any time one L2 serves neighbouring column tiles of a few row tiles.
   const int x8 = blockIdx.x % 8, c8 = blockIdx.x / 8;
   const int cx = gridDim.x / 8 + (x8 < (int)(gridDim.x % 8) ? 1 : 0);
   const int q8 = tiles_total / 8, r8 = tiles_total % 8;
@@ -121,7 +125,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
   const int wm = wave >> 1, wn = wave & 1;
   const int M = g.B * g.kcap;
   const int lr = lane & 31, lh = lane >> 5;
-  if (EVT_PIPE_PRIO == 1 && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #ifdef EVT_PROF
   const bool prof_on = blockIdx.x == 8 && wave == 0;
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
@@ -314,9 +317,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
   auto barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (EVT_PIPE_SKEW > 0) {
-      for (int i = 0; i < (wave & 3); ++i) asm volatile("s_nop %0" ::"n"(EVT_PIPE_SKEW > 0 ? EVT_PIPE_SKEW - 1 : 0));
-    }
     asm volatile("" ::: "memory");
   };
 
@@ -447,22 +447,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
       constexpr int m = decltype(mc)::value;
       if constexpr (m == NS) PIPE_TICK(2);
       if constexpr (m == Z) {
-        if constexpr (!(EVT_PIPE_ABLATE & 16)) barrier();
+        barrier();
         PIPE_TICK(3);
         PIPE_PIN();
       }
-      if constexpr (!(EVT_PIPE_ABLATE & 32)) { if constexpr (m < NS) mfma_slot(F0, m); else mfma_slot(F1, m - NS); }
+      if constexpr (m < NS) mfma_slot(F0, m); else mfma_slot(F1, m - NS);
       // fragment reads: k-half 1 of this k-tile during its first half; k-half 0 of the next k-tile behind the barrier
       if constexpr (m < ZF) {
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
           constexpr int r = decltype(rc)::value;
-          if constexpr (r * ZF / NR == m && !(EVT_PIPE_ABLATE & 8)) read_frag(F1, r, sb, fr1);
+          if constexpr (r * ZF / NR == m) read_frag(F1, r, sb, fr1);
         });
       }
       if constexpr (m >= Z) {
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
           constexpr int r = decltype(rc)::value;
-          if constexpr (r * ZR / NR == m - Z && !(EVT_PIPE_ABLATE & 8)) read_frag(F0, r, so, fr0);
+          if constexpr (r * ZR / NR == m - Z) read_frag(F0, r, so, fr0);
         });
       }
       if constexpr (m < ZS) {
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gated_linear_pipe_kerne
           constexpr int n = decltype(nc)::value;
           if constexpr (n * ZS / SCH.n == m) {
             constexpr int kind = SCH.a[n].kind, idx = SCH.a[n].idx;
-            if constexpr (kind == 0) { if constexpr (!(EVT_PIPE_ABLATE & 2)) split_unit(idx); }
+            if constexpr (kind == 0) split_unit(idx);
             else if constexpr (kind == 1) {
-              if constexpr (!(EVT_PIPE_ABLATE & 4)) store_a(idx, so);
-              if constexpr (!(EVT_PIPE_ABLATE & 1)) fetch_a(idx);
+              store_a(idx, so);
+              fetch_a(idx);
             } else {
-              if constexpr (!(EVT_PIPE_ABLATE & 4)) store_w(idx, so);
-              if constexpr (!(EVT_PIPE_ABLATE & 1)) fetch_w(idx);
+              store_w(idx, so);
+              fetch_w(idx);
             }
           }
         });
@@ -568,11 +568,12 @@ void launch_pipe_waves(const LinArgs& a, hipStream_t s, dim3 grid, int tiles_n, 
   hipLaunchKernelGGL((gated_linear_pipe_kernel<ACT, TBN, FMT, WAVES>), grid, dim3(WAVES * 64), lds_bytes, s, a, tiles_n, tiles_total);
 }
 
+// Eight waves.  (The kernel is written for 4 or 8; four 512-register waves -- one per SIMD, 128 x 128 per wave, half the LDS fragment
+// traffic -- measured 3-10 % slower on every headline launch: an in-order wave that is held up issuing a load or an LDS store has
+// nobody beside it to feed the matrix pipe.  profiles/r05/gemm_tile_shapes.txt.)
 template <int ACT, int TBN, int FMT>
 void launch_pipe_one(const LinArgs& a, hipStream_t s, dim3 grid, int tiles_n, int tiles_total) {
-  static const int waves = getenv("EVT_PIPE_WAVES") ? atoi(getenv("EVT_PIPE_WAVES")) : 8;
-  if (waves == 4) launch_pipe_waves<ACT, TBN, FMT, 4>(a, s, grid, tiles_n, tiles_total);
-  else launch_pipe_waves<ACT, TBN, FMT, 8>(a, s, grid, tiles_n, tiles_total);
+  launch_pipe_waves<ACT, TBN, FMT, 8>(a, s, grid, tiles_n, tiles_total);
 }
 
 template <int TBN>
@@ -590,10 +591,39 @@ void launch_pipe_cfg(const LinArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// choice: evt_big_choice's answer (2: 256x256, 3: 256x128, 4: 256x192).  false = not taken (the caller runs evt_linear_big.hip).
-bool evt_launch_split_pipe(const LinArgs& a, hipStream_t s, int choice) {
-  if ((a.Nout & 3) != 0 || (a.ldo & 3) != 0) return false;   // 16-byte output quads
-  switch (choice) {
+// Picks a 256-row tile when the launch has enough of them to fill the chip; 0 when the 128x128 kernel (or its split-K form, or the
+// small-row-count kernel) should run instead.  EVT_GEMM_BIG: 0 never, 1 (default) automatic, 2 always 256x256, 3 always 256x128,
+// 4 always 256x192 (tests/test_gpu_big_tiles.py forces each one).
+int evt_big_choice(const LinArgs& a) {
+  static const int mode = getenv("EVT_GEMM_BIG") ? atoi(getenv("EVT_GEMM_BIG")) : 1;
+  // whole 32-k tiles, at least two of them; top-k gating only (the threshold policy's masked rows stay with the 128x128 kernel,
+  // which skips dead tiles); 16-byte output pieces
+  if (mode == 0 || a.Wsplit == nullptr || (a.K & 31) != 0 || a.K < 64 || a.count != nullptr || (a.Nout & 3) != 0 || (a.ldo & 3) != 0) return 0;
+  // 32-bit byte offsets inside the kernel: activations (and the gate reference, same shape), weight planes and output below 4 GB
+  // (the activation bound is taken at 4 bytes per element also for a bf16 launch: it then covers the fp32 gate reference)
+  if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 32) ||
+      (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 32) ||
+      (int64_t)a.B * a.o_rows * a.ldo * 4 >= ((int64_t)1 << 32))
+    return 0;
+  if (mode >= 2 && mode <= 4) return mode;
+  // One persistent workgroup per CU: a launch of T tiles runs in ceil(T / CUs) rounds.  Take a tile whose columns divide Nout (no
+  // wasted edge columns) and whose last round is at least 85 % full.  256x192 first: QKV (Nout = 2304) is 1536 tiles = 6.0 rounds
+  // instead of the 4.5 (-> 5) of 256x256, and the 192-column instantiations keep every register: 310 vs 346 us for QKV, 441 vs 497
+  // for MLP-1 + GELU, 790 vs 859 for the MLP pair at B = 256 (profiles/r05/gemm_tile_shapes.txt).
+  const int cus = evt_cu_count(), M = a.B * a.kcap;
+  const int tiles_m = (M + 255) / 256;
+  auto fills = [&](int tbn) {
+    if (a.Nout % tbn != 0) return false;
+    const int tiles = tiles_m * (a.Nout / tbn), rounds = (tiles + cus - 1) / cus;
+    return tiles >= cus && tiles * 100 >= rounds * cus * 85;
+  };
+  if (fills(192)) return 4;
+  if (fills(256)) return 2;
+  return 0;
+}
+
+bool evt_launch_split_big(const LinArgs& a, hipStream_t s) {
+  switch (evt_big_choice(a)) {
     case 2: launch_pipe_cfg<256>(a, s); return true;
     case 3: launch_pipe_cfg<128>(a, s); return true;
     case 4: launch_pipe_cfg<192>(a, s); return true;

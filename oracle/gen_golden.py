@@ -249,10 +249,10 @@ def block_params_of(sd, i):
     return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
 
 
-def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None, stream_seed=None):
+def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None, stream_seed=None, grid=14):
     """One ViViT-B spatial sub-model run (197 tokens, 12 EventfulBlocks, top-k `k`, `steps` frames) through the REAL
     reference backbone and the oracle; stores features, index sets and margins under the `mode__` prefix."""
-    dim, depth, heads, N = 768, 12, 12, 196
+    dim, depth, heads, N = 768, 12, 12, grid * grid
     sd = backbone_params(depth, dim, 4, seed, N + 1, qk_std=qk_std)
     rs = np.random.RandomState(seed + 1)
     cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
@@ -261,13 +261,13 @@ def _vivit_case(pack, mode, cast, steps, k, seed=77, qk_std=None, stream_seed=No
     cfg = dict(dim=dim, heads=heads, mlp_ratio=4)
     if cast:
         cfg["matmul_2_cast"] = cast
-    ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(14, 14),
+    ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(grid, grid), input_size=(grid, grid),
                       block_class="EventfulBlock", has_class_token=True).eval()
     ref.load_state_dict(sd, strict=True)
     ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
-    blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast=cast)
+    blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (grid, grid), matmul_2_cast=cast)
               for i in range(depth)]
-    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
+    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (grid, grid), (grid, grid), True)
     ob.set_policy(lambda: O.TopK(k))
     model = O.ViViTSpatialOracle(ob, cls, ln_w, ln_b)
     xs = O.make_token_stream(1, N, dim, steps, k, seed=seed + 2 if stream_seed is None else stream_seed, small=0.01)
@@ -318,19 +318,105 @@ def gen_vivit_sharp():
     np.savez_compressed(os.path.join(OUT, "vivit_b_sharp.npz"), **pack)
 
 
-def gen_vivit_sharp_clips():
-    """bf16 A.v cast (the arithmetic the headline is timed in) + sharp attention, INDEX sets of the projection gates: 8 SHORT clips
-    (3 frames = 2 gated frames each, different streams) instead of one long one.  With the cast, the bf16 A.v / gate-reference
-    state of ANY two implementations drifts apart frame by frame (each frame re-rounds ~150k state elements per block; a different
-    fp32 summation order flips a few dozen of those roundings, and a flip persists): on the 12-frame sharp clip the HIP path's
-    projection-gate sets equal the reference's in frames 1-2 and start to differ from frame 3 on, at margins up to 1e-2
-    (profiles/r05/parity_summary.txt).  Short clips compare the gate DECISION before that drift: ~15 projection-gate sets at
-    margin >= 1e-3 per clip."""
-    pack = {"torch_version": np.bytes_(torch.__version__), "qk_std": np.float64(0.06), "clips": np.int64(8)}
-    for c in range(8):
-        _vivit_case(pack, f"clip{c}", "bfloat16", 3, 128, qk_std=0.06, stream_seed=500 + 7 * c)
-        pack[f"clip{c}__stream_seed"] = np.int64(500 + 7 * c)
-        del pack[f"clip{c}__features"]
+class _ReplayTopK:
+    """Oracle policy for a teacher-forced replay: records its OWN top-k selection (ascending) on the delta it is given and hands
+    the block the forced set instead."""
+
+    def __init__(self, k):
+        self.k, self.forced, self.own = k, None, None
+
+    def __call__(self, e, dim=-1):
+        self.own = torch.linalg.vector_norm(e, ord=2, dim=dim).topk(self.k, sorted=False)[1].sort(dim=-1)[0]
+        return self.forced
+
+
+def gen_vivit_sharp_clips(n_clips=192):
+    """bf16 A.v cast (the arithmetic the headline is timed in) + sharp attention: INDEX sets of all gates on `n_clips` SHORT clips
+    (3 frames = 2 gated frames each, different streams) from the REAL reference -- and the reference arithmetic's OWN noise floor on
+    them.  With the cast, the projection gate's input is the bf16 A.v state: its frame-to-frame delta is a handful of bf16 steps
+    in a handful of elements, so ONE rounding decided the other way by another fp32 summation order moves a token's delta norm by
+    several per cent; reference margins of a few 1e-3 do not protect a decision there.  How large a margin does?  The restatement
+    (bit-identical to the reference at the same thread count) is replayed teacher-forced -- block inputs and forced index sets of
+    the 8-thread run -- at 1 ATen thread (another summation order inside the same arithmetic), and every gate where that replay
+    selects a different set is flagged (`selfdiff`).  The GPU test holds the HIP path to exactly that bar: bit-equal sets wherever the
+    reference margin exceeds the largest margin at which the reference arithmetic disagrees with itself."""
+    dim, depth, heads, N, k, steps = 768, 12, 12, 196, 128, 3
+    seed = 77
+    sd = backbone_params(depth, dim, 4, seed, N + 1, qk_std=0.06)
+    rs = np.random.RandomState(seed + 1)
+    cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
+    cfg = dict(dim=dim, heads=heads, mlp_ratio=4, matmul_2_cast="bfloat16")
+    ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(14, 14),
+                      block_class="EventfulBlock", has_class_token=True).eval()
+    ref.load_state_dict(sd, strict=True)
+    ref_set_policies(ref, lambda: rpolicies.TokenNormTopK(k, save_status=True))
+
+    def oracle_blocks():
+        return [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast="bfloat16") for i in range(depth)]
+
+    gates = ("qkv_gate", "projection_gate", "mlp_gate")
+    keys = ("qkv_index", "projection_index", "mlp_index")
+    idx_all = np.zeros((n_clips, steps - 1, depth, 3, k), np.int16)
+    margins = np.zeros((n_clips, steps - 1, depth, 3))
+    selfdiff = np.zeros((n_clips, steps - 1, depth, 3), bool)
+    t0 = time.time()
+    enc = sd["position_encoding.encoding"]
+    for c in range(n_clips):
+        stream_seed = 500 + 7 * c
+        xs = O.make_token_stream(1, N, dim, steps, k, seed=stream_seed, small=0.01)
+        torch.set_num_threads(8)
+        ref.reset()
+        blocks = oracle_blocks()
+        for b in blocks:
+            b.set_policy(lambda: O.TopK(k))
+        inputs, forced = [], []
+        with torch.inference_mode():
+            for t in range(steps):
+                x0 = torch.concat([cls.expand(1, 1, dim), xs[t]], dim=1)
+                y_ref = ref(x0)
+                x = x0 + enc
+                row_in, row_f = [], []
+                for bi, ob in enumerate(blocks):
+                    row_in.append(x.clone())
+                    x = ob.forward(x)
+                    if t > 0:
+                        sets = [ob.trace[kk].sort(dim=-1)[0] for kk in keys]
+                        row_f.append(sets)
+                        for gi, g in enumerate(gates):
+                            pol = getattr(ref.blocks[bi], g).policy
+                            assert torch.equal(sorted_idx(pol.last_output), sets[gi]), (c, t, bi, g)
+                            idx_all[c, t - 1, bi, gi] = sets[gi][0].numpy().astype(np.int16)
+                            margins[c, t - 1, bi, gi] = topk_margin(pol.last_input, k)
+                assert torch.equal(x, y_ref), (c, t)
+                inputs.append(row_in)
+                forced.append(row_f)
+            for threads in (1,):         # the same arithmetic in another summation order, teacher-forced on the 8-thread run
+                torch.set_num_threads(threads)
+                blocks_b = oracle_blocks()
+                for b in blocks_b:
+                    b.policy = {g: _ReplayTopK(k) for g in b.GATES}
+                for t in range(steps):
+                    for bi, ob in enumerate(blocks_b):
+                        if t > 0:
+                            for gi, g in enumerate(gates):
+                                ob.policy[g].forced = forced[t][bi][gi]
+                        ob.forward(inputs[t][bi])
+                        if t > 0:
+                            for gi, g in enumerate(gates):
+                                if not torch.equal(ob.policy[g].own, forced[t][bi][gi]):
+                                    selfdiff[c, t - 1, bi, gi] = True
+        torch.set_num_threads(8)
+        if c % 8 == 7:
+            print(f"sharp clips: {c + 1}/{n_clips} in {time.time() - t0:.0f}s; self-disagreeing gates so far (qkv, projection, mlp): "
+                  f"{selfdiff[:c + 1].sum(axis=(0, 1, 2)).tolist()}", flush=True)
+    pm, pd = margins[..., 1], selfdiff[..., 1]
+    floor = float(pm[pd].max()) if pd.any() else 0.0
+    print(f"sharp clips: projection gates: {int(pd.sum())} of {pd.size} decided differently by the reference arithmetic at 1 thread, "
+          f"largest reference margin among them {floor:.3e}; gates above it: {int((pm > floor).sum())}; qkv / mlp self-disagreements: "
+          f"{int(selfdiff[..., 0].sum())} / {int(selfdiff[..., 2].sum())}")
+    pack = {"torch_version": np.bytes_(torch.__version__), "qk_std": np.float64(0.06), "clips": np.int64(n_clips), "seed": np.int64(seed),
+            "k": np.int64(k), "steps": np.int64(steps), "stream_seeds": np.asarray([500 + 7 * c for c in range(n_clips)], np.int64),
+            "idx": idx_all, "margins": margins, "selfdiff": selfdiff}
     np.savez_compressed(os.path.join(OUT, "vivit_b_sharp_clips.npz"), **pack)
 
 
@@ -343,7 +429,7 @@ def gen_vivit_k64():
     np.savez_compressed(os.path.join(OUT, "vivit_b_k64.npz"), **pack)
 
 
-def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed, qk_std=None):
+def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed, qk_std=None, pool_size=None):
     dim, depth, heads = 768, 12, 12
     window_indices = (0, 1, 3, 4, 6, 7, 9, 10)  # configs/models/vitdet_b_coco.yml:13
     N = grid * grid
@@ -355,10 +441,16 @@ def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed, qk_st
     cfg = dict(dim=dim, heads=heads, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14))
     if cast_global:
         cfg["matmul_2_cast"] = cast_global
+    overrides = {}
+    if cast_global:
+        overrides["matmul_2_cast"] = None     # configs/time/vitdet_vid/_cuda.yml:6-7
+    if pool_size is not None:
+        cfg["pool_size"] = pool_size          # configs/evaluate/vitdet_vid/_spatial.yml:4-6 (global blocks only)
+        overrides["pool_size"] = None
     ref = RefBackbone(block_config=cfg, depth=depth, position_encoding_size=(14, 14), input_size=(grid, grid),
                       block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
                       window_indices=window_indices,
-                      windowed_overrides=(dict(matmul_2_cast=None) if cast_global else None)).eval()
+                      windowed_overrides=(overrides or None)).eval()
     ref.load_state_dict(sd, strict=True)
     ref_set_policies(ref, policy_ref)
     blocks = []
@@ -368,7 +460,7 @@ def vitdet_ref_and_oracle(grid, policy_ref, policy_ora, cast_global, seed, qk_st
                                         window_size=(14, 14), relative_embedding_size=(64, 64)))
         else:
             blocks.append(O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (grid, grid),
-                                        relative_embedding_size=(64, 64), matmul_2_cast=cast_global))
+                                        relative_embedding_size=(64, 64), matmul_2_cast=cast_global, pool_size=pool_size))
     ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (grid, grid), False)
     ob.set_policy(policy_ora)
     return ref, ob, sd, N
@@ -405,6 +497,59 @@ def gen_vitdet672():
     pack["margins"] = np.asarray(margins).reshape(steps - 1, 12, 3)
     print("vitdet672 min margin", min(margins))
     np.savez_compressed(os.path.join(OUT, "vitdet_672.npz"), **pack)
+
+
+def _vitdet_topk_case(pack, tag, grid, k, cast, steps, seed, pool_size=None, stride=16):
+    """One ViTDet-B top-k case from the REAL reference into `pack` under the `tag__` prefix: output slices, the full rows of the tokens
+    the last block's MLP gate refreshed, all gate index sets and margins."""
+    ref, ob, sd, N = vitdet_ref_and_oracle(grid, lambda: rpolicies.TokenNormTopK(k, save_status=True), lambda: O.TopK(k), cast, seed,
+                                           pool_size=pool_size)
+    xs = O.make_token_stream(1, N, 768, steps, k, seed=seed + 2, small=0.01)
+    outs, idx_all, margins = [], [], []
+    with torch.inference_mode():
+        for t in range(steps):
+            t0 = time.time()
+            y = ref(xs[t].clone())
+            y_o = ob.forward(xs[t].clone())
+            assert torch.equal(y, y_o), (tag, t, float((y - y_o).abs().max()))
+            outs.append(y[:, ::stride].clone())
+            if t > 0:
+                for blk in ref.blocks:
+                    for g in ("qkv_gate", "projection_gate", "mlp_gate"):
+                        pol = getattr(blk, g).policy
+                        idx_all.append(sorted_idx(pol.last_output).numpy().astype(np.int16))
+                        margins.append(topk_margin(pol.last_input, k))
+                rows = sorted_idx(ref.blocks[-1].mlp_gate.policy.last_output)[0]
+                pack[f"{tag}__yrowidx_{t}"] = rows.numpy().astype(np.int16)
+                pack[f"{tag}__yrow_{t}"] = y[0, rows].numpy()
+            print(f"{tag} step {t}: {time.time() - t0:.1f}s", flush=True)
+    pack[f"{tag}__y_slice"] = torch.stack(outs).numpy()
+    pack[f"{tag}__idx"] = np.stack(idx_all).reshape(steps - 1, 12, 3, 1, k)
+    pack[f"{tag}__margins"] = np.asarray(margins).reshape(steps - 1, 12, 3)
+    pack[f"{tag}__seed"] = np.int64(seed)
+    pack[f"{tag}__k"] = np.int64(k)
+    pack[f"{tag}__grid"] = np.int64(grid)
+    pack[f"{tag}__stride"] = np.int64(stride)
+    print(f"{tag}: min margin {min(margins):.2e}, {int((np.asarray(margins) >= 1e-3).sum())} of {len(margins)} sets at margin >= 1e-3", flush=True)
+
+
+def gen_timing_configs():
+    """The reference's own GPU timing / evaluation configurations at FULL size (VERDICT r04 'missing' 2-3), from the REAL reference:
+      vivit_fp16       ViViT-B 197 tokens, k = 128, matmul_2_cast float16      (configs/time/vivit_epic_kitchens/_cuda.yml:5 on config 2's model)
+      vivit401_fp16    ViViT-B EPIC-Kitchens: 20 x 20 + class token = 401 tokens, k = 50, float16
+                       (configs/models/vivit_b_epic_kitchens.yml:5-8, configs/time/vivit_epic_kitchens/temporal_cuda.yml:5)
+      vitdet672_fp16   ViTDet-B 672^2 top-k 256, float16 in the global blocks  (configs/time/vitdet_vid/_cuda.yml:5-7)
+      vitdet1024_k512  ViTDet-B 1024^2 top-k 512, float16                       (configs/time/vitdet_vid/temporal_1024_cuda.yml:5)
+      vitdet672_pool2  'spatiotemporal' 672^2: K / V pooled 2 x 2 in the global blocks, top-k 256, float16
+                       (configs/evaluate/vitdet_vid/_spatial.yml:4-6, spatiotemporal_672.yml, blocks.py:303-326,525-540)
+    Small stores: output slices + refreshed rows + index sets."""
+    pack = {"torch_version": np.bytes_(torch.__version__)}
+    _vivit_case(pack, "vivit_fp16", "float16", 4, 128)
+    _vivit_case(pack, "vivit401_fp16", "float16", 4, 50, seed=79, grid=20)
+    _vitdet_topk_case(pack, "vitdet672_fp16", 42, 256, "float16", 3, 95)
+    _vitdet_topk_case(pack, "vitdet672_pool2", 42, 256, "float16", 3, 97, pool_size=2)
+    _vitdet_topk_case(pack, "vitdet1024_k512", 64, 512, "float16", 3, 99, stride=64)
+    np.savez_compressed(os.path.join(OUT, "timing_configs.npz"), **pack)
 
 
 def gen_vitdet1024(thr=1.0, fname="vitdet_1024.npz", steps=5, seed=93):
@@ -704,7 +849,7 @@ if __name__ == "__main__":
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     todo = {"gates": gen_gates, "blocks": gen_blocks, "vivit": gen_vivit, "vivit_sharp": gen_vivit_sharp, "vivit_sharp_clips": gen_vivit_sharp_clips, "vivit_k64": gen_vivit_k64, "vitdet672": gen_vitdet672,
-            "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models, "ats": gen_ats, "envelope": gen_envelope, "vitdet1024_thresholds": gen_vitdet1024_thresholds}
+            "vitdet1024": gen_vitdet1024, "counts": gen_counts, "models": gen_models, "ats": gen_ats, "envelope": gen_envelope, "vitdet1024_thresholds": gen_vitdet1024_thresholds, "timing_configs": gen_timing_configs}
     for name, fn in todo.items():
         if args.only in (None, name):
             fn()

@@ -44,6 +44,13 @@ case $what in
       echo "== rep $rep --overlap $ov" | tee -a $OUT/overlap.txt
       timeout 900 python bench.py --no-other --no-cpu-baseline --no-check --no-exact --no-kernel-events --overlap $ov 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/overlap.txt
     done; done ;;
+  sharp_ab)    # bf16 cast + sharp attention, projection-gate agreement: split-precision q.k^T (default) vs exact fp32 q.k^T vs all-fp32 GEMMs
+    for cfg in "EVT_QK_SPLIT=1" "EVT_QK_SPLIT=0" "EVT_GEMM=f32"; do
+      echo "== $cfg" | tee -a $OUT/sharp_ab.txt
+      rm -f $OUT/sharp_tmp.txt
+      env $cfg EVT_PARITY_SUMMARY=$PWD/$OUT/sharp_tmp.txt timeout 900 python -m pytest tests/test_gpu_blocks.py -m gpu -q -k "sharp_bf16_projection" 2>&1 | tail -2 | tee -a $OUT/sharp_ab.txt
+      cat $OUT/sharp_tmp.txt | tee -a $OUT/sharp_ab.txt
+    done ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
   kbench)

@@ -133,17 +133,17 @@ def block_params_of(sd, i):
     return {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
 
 
-def vivit_oracle(mode_cast, seed=77, k=128, qk_std=None):
-    """ViViT-B spatial oracle + its parameters, as in gen_golden.gen_vivit (qk_std: gen_vivit_sharp)."""
-    dim, depth, heads, N = 768, 12, 12, 196
+def vivit_oracle(mode_cast, seed=77, k=128, qk_std=None, grid=14):
+    """ViViT-B spatial oracle + its parameters, as in gen_golden.gen_vivit (qk_std: gen_vivit_sharp; grid 20: the EPIC-Kitchens model)."""
+    dim, depth, heads, N = 768, 12, 12, grid * grid
     sd = backbone_params(depth, dim, 4, seed, N + 1, qk_std=qk_std)
     rs = np.random.RandomState(seed + 1)
     cls = torch.from_numpy((rs.standard_normal((1, 1, dim)) * 0.02).astype(np.float32))
     ln_w = torch.from_numpy((1 + rs.standard_normal(dim) * 0.05).astype(np.float32))
     ln_b = torch.from_numpy((rs.standard_normal(dim) * 0.05).astype(np.float32))
-    blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (14, 14), matmul_2_cast=mode_cast)
+    blocks = [O.BlockOracle("EventfulBlock", block_params_of(sd, i), dim, heads, (grid, grid), matmul_2_cast=mode_cast)
               for i in range(depth)]
-    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (14, 14), True)
+    ob = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (grid, grid), (grid, grid), True)
     ob.set_policy(lambda: O.TopK(k))
     return O.ViViTSpatialOracle(ob, cls, ln_w, ln_b), sd, cls, ln_w, ln_b
 
@@ -171,28 +171,33 @@ def vitdet_oracle(grid, policy_factory, cast_global, seed, qk_std=None):
     return ob, sd
 
 
-def product_vitdet(grid, sd, cast_global, device="cuda"):
+def product_vitdet(grid, sd, cast_global, device="cuda", pool_size=None):
     from eventful_transformer.backbones import ViTBackbone
 
     cfg = dict(dim=768, heads=12, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14))
+    overrides = {}
     if cast_global:
         cfg["matmul_2_cast"] = cast_global
+        overrides["matmul_2_cast"] = None
+    if pool_size is not None:      # configs/evaluate/vitdet_vid/_spatial.yml:4-6: K / V pooling in the global blocks only
+        cfg["pool_size"] = pool_size
+        overrides["pool_size"] = None
     bb = ViTBackbone(block_config=cfg, depth=12, position_encoding_size=(14, 14), input_size=(grid, grid),
                      block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
                      window_indices=VITDET_WINDOWED,
-                     windowed_overrides=(dict(matmul_2_cast=None) if cast_global else None))
+                     windowed_overrides=(overrides or None))
     res = bb.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     return bb.eval().to(device)
 
 
-def product_vivit(sd, cast, device="cuda"):
+def product_vivit(sd, cast, device="cuda", grid=14):
     from eventful_transformer.backbones import ViTBackbone
 
     cfg = dict(dim=768, heads=12, mlp_ratio=4)
     if cast:
         cfg["matmul_2_cast"] = cast
-    bb = ViTBackbone(block_config=cfg, depth=12, position_encoding_size=(14, 14), input_size=(14, 14),
+    bb = ViTBackbone(block_config=cfg, depth=12, position_encoding_size=(grid, grid), input_size=(grid, grid),
                      block_class="EventfulBlock", has_class_token=True)
     res = bb.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
