@@ -65,9 +65,6 @@ template <> struct Quad<float> { union { float4 v; float t[4]; }; };
 
 constexpr int SDH = 64;   // head dim
 
-#ifndef EVT_K9_ABLATE   // timing experiments only (results are wrong), a bit mask: 1 no reference stores, 2 no old-reference loads,
-#define EVT_K9_ABLATE 0 // 4 no V piece loads, 8 no rel-pos terms in the selected-column pass, 16 no statistics pass, 32 no key loads in it
-#endif
 
 // 16 rows x 16 channels += A-tile rows (16 x k) . V^T-tile rows (16 channels x k) over the k range [KB, KB + KLEN) of a chunk.
 // a: first element of this lane's tile row (row l15 of the group), b: of this lane's channel row; kg = lane >> 4.
@@ -481,21 +478,13 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
   {
-#if EVT_K9_ABLATE & 16
-    const int NS = 128;
-#else
     const int NS = (QK == 2 && rel) ? NKB * 16 : a.N;   // slots to stream (the key plane's, with a rel-pos grid)
-#endif
     int c0 = 0;
     for (; c0 + 128 <= NS; c0 += 128) {   // whole chunk pairs: no masks
       stats(c0, kA, false);
-#if !(EVT_K9_ABLATE & 32)   // (32: the key fragments of the first two chunks again and again)
       load_chunk(c0 + 128, kA);
-#endif
       stats(c0 + 64, kB, false);
-#if !(EVT_K9_ABLATE & 32)
       load_chunk(c0 + 192, kB);
-#endif
     }
     if (c0 < NS) stats(c0, kA, true);          // the last (partial) pair: its fragments were requested above / in the prologue
     if (c0 + 64 < NS) stats(c0 + 64, kB, true);
@@ -554,11 +543,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       const int i = rok[hr] ? i0 + 16 * hr + l15 : 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#if EVT_K9_ABLATE & 2
-        Store<T>::store(&old[hr][r], (float)(co[r] + i) * 1e-9f);
-#else
         old[hr][r] = *st_at(co[r], i);
-#endif
       }
     }
   };
@@ -569,11 +554,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kv = k0 + jj;
       const bool in = kv < a.kcap;
       const int64_t o = (int64_t)d * a.kcap + (in ? kv : 0);
-#if EVT_K9_ABLATE & 4
-      const uint4 xd = make_uint4((unsigned)o, 0, 0, 0), xo = xd;
-#else
       const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
-#endif
       pd[it] = in ? xd : make_uint4(0, 0, 0, 0);
       po[it] = in ? xo : make_uint4(0, 0, 0, 0);
     }
@@ -784,11 +765,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
     int js[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) js[r] = q.g[r] >= 0 ? q.g[r] : 0;
-#if EVT_K9_ABLATE & 8
-    scores(kf, sacc);
-#else
     scores_rel(kf, sacc, js);
-#endif
     const bool full = tile_full && k0 + FKC <= cnt;
     uint32_t co[4];
 #pragma unroll
@@ -805,23 +782,15 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[r] = an[r] - Store<T>::load(&old[hr][r]);
       Store<T>::round4(d, dl.t, nullptr);
-#if EVT_K9_ABLATE & 1
-      if (a.N < 0) {   // never
-#else
       if (full) {
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) *st_at(co[r], i0 + 16 * hr + l15) = nw.t[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool ok = rok[hr] && q.g[r] >= 0;
-#if EVT_K9_ABLATE & 1
-          if (!ok) { nw.t[r] = zero_t; dl.t[r] = zero_t; }
-#else
           if (ok) *st_at(co[r], i0 + 16 * hr + l15) = nw.t[r];
           else { nw.t[r] = zero_t; dl.t[r] = zero_t; }
-#endif
         }
       }
       *reinterpret_cast<decltype(nw.v)*>(An + (16 * hr + l15) * P + wave * 16 + 4 * kg) = nw.v;
@@ -980,8 +949,6 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
 // fragments are split once per workgroup, everything else is per row group).  EVT_STREAM_NHR forces 2 or 3.
 template <typename T>
 int stream_pick_nhr(const StreamArgs& a) {
-  static const int forced = getenv("EVT_STREAM_NHR") ? atoi(getenv("EVT_STREAM_NHR")) : 0;
-  if (forced >= 2 && forced <= 3) return forced;
   const int cus = evt_cu_count();
   const size_t lds[2] = {stream_lds_bytes<T, 2>(a.gh, a.gw), stream_lds_bytes<T, 3>(a.gh, a.gw)};
   int best = 2;

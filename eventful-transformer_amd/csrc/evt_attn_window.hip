@@ -540,9 +540,8 @@ void launch_window_t(const DenseArgs& a, int split, hipStream_t s) {
   const int waves = (a.N + 31) / 32;
   // Eight waves (two per SIMD) cover up to 256 query rows in one workgroup; groups of up to 128 tokens need four.  (Splitting a
   // pair's query rows over two 4-wave workgroups when there are few pairs -- ViTDet 672^2: 108 on 256 CUs -- was measured
-  // slower, 32.0 vs 28.6 us: each workgroup stages the pair's K / V and all rel-pos items itself.  EVT_WINDOW_NW forces a shape.)
-  static const int forced = getenv("EVT_WINDOW_NW") ? atoi(getenv("EVT_WINDOW_NW")) : 0;
-  const bool four = forced ? forced == 4 : waves <= 4;
+  // slower, 32.0 vs 28.6 us: each workgroup stages the pair's K / V and all rel-pos items itself.)
+  const bool four = waves <= 4;
   if (split) {
     if (four) launch_window_inst<T, true, 4>(a, lds, s); else launch_window_inst<T, true, 8>(a, lds, s);
   } else {

@@ -195,9 +195,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gated_linear_kernel(const LinArg
         if (ncol[j] < g.Nout) {
           float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
           if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf_exact(v);
-#ifdef EVT_ABLATE_STORE   // timing experiment only: keep the arithmetic, drop (almost) every store
-          if (v == 12345.678f)
-#endif
           orow[ncol[j]] = v;
         }
       }
@@ -241,18 +238,9 @@ __device__ __forceinline__ int splitk_dynamic(const int32_t* count, int B, int t
 // Tile configuration: TBM x TBN output tile, TBK k-tile, WM x WN waves each owning a 64x64 sub-tile
 // (2x2 MFMA accumulators).  Workgroups are numbered so that one XCD (private L2) walks consecutive
 // column tiles of the same row tile: the gathered A rows are fetched into that L2 once.
-// WDMA (128x128x32 tile only): the weight tile is not staged through registers but streamed global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: 16 rows x 64 B of one plane per wave instruction, lane-linear destination, the chunk swizzle
-// applied to the SOURCE chunk each lane fetches) into one of TWO weight buffers, one k-tile ahead; a counted
-// s_waitcnt leaves the next tile's loads in flight across the (raw) barriers.  Removes the weight ds_write_b128 (52 of
-// the ~164 LDS-pipe cycles a wave spends per k-tile) and 16 staging registers.
-#ifndef EVT_ABLATE   // timing experiments only (results are wrong): 1 no in-loop global loads, 2 + no staging, 3 + no fragment reads, 4 + no barriers
-#define EVT_ABLATE 0
-#endif
-template <int ACT, int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
+template <int ACT, int TBM, int TBN, int TBK, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM_MIN_BLOCKS : 1)) void gated_linear_split_kernel(const LinArgs g, int tiles_n, int tiles_total, int tile_map, int ksplit, int dyn) {
   constexpr int NT = WM * WN * 64;
-  static_assert(!WDMA || (TBK == 32 && TBN == 128 && NT == 256), "LDS-DMA weight path: 128-wide tiles, 4 waves");
   // bf16 LDS tile layout.  TBK == 32: unpadded 64-byte rows with the 16-byte chunk c of row r stored at chunk
   // c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 lane group touches cover all 16 slots of a 256-byte bank row, and the
   // two rows a 16-lane ds_write_b64 group / 8-lane ds_write_b128 group writes occupy disjoint halves of the 32 write
@@ -269,7 +257,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   // in the kernel hipcc waits vmcnt(0) -- i.e. for the LDS-DMA just issued -- before the fragment reads of every k-tile.
   extern __shared__ __attribute__((aligned(16))) unsigned char evt_gemm_smem[];
   __bf16* lds = reinterpret_cast<__bf16*>(evt_gemm_smem);
-  int64_t* orow_off = reinterpret_cast<int64_t*>(lds + 2 * TBM * TSP + (WDMA ? 2 : 1) * BBUF);  // output row offset (elements) of each tile row, -1 = masked row
+  int64_t* orow_off = reinterpret_cast<int64_t*>(lds + 2 * TBM * TSP + BBUF);  // output row offset (elements) of each tile row, -1 = masked row
   __bf16* Ahi = lds;
   __bf16* Alo = lds + TBM * TSP;
   __bf16* Bhi = lds + 2 * TBM * TSP;
@@ -355,43 +343,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
     const int n = n0 + wr0 + WROWS * j;
     w_off[j] = (int64_t)(n < g.Nout ? n : g.Nout - 1) * wpitch;
   }
-  // LDS-DMA weight path: wave w moves row blocks 2w, 2w + 1 (16 rows x 64 B each) of the hi and of the lo plane.
-  // lane -> (row lane >> 2 of the block, physical chunk lane & 3); it fetches the logical chunk that belongs there.
-  const uint16_t* dma_src[2];
-  if (WDMA) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 16 * (2 * wave + j) + (lane >> 2);
-      dma_src[j] = g.Wsplit + (int64_t)(n < g.Nout ? n : g.Nout - 1) * wpitch + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
-    }
-  }
-  auto issue_w = [&](int t, int buf) {   // k-tile t (a whole hl32 group: always readable, zero past K) -> weight buffer buf
-    typedef __attribute__((address_space(3))) void lds_void_t;
-    typedef const __attribute__((address_space(1))) void gbl_void_t;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __bf16* dst = Bhi + buf * BBUF + (2 * wave + j) * 16 * TSP;
-      const uint16_t* src = dma_src[j] + (int64_t)t * 64;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + 32), (lds_void_t*)(dst + TBN * TSP), 16, 0, 0);
-    }
-  };
   float4 ra[AJ];
   uint4 rwh[WJ], rwl[WJ];
   auto fetch = [&](int k0) {
     const int kc = k0 + ac4 * 4;
     const int kw = hl32_hi(k0 + wc8);
-    if (WDMA) {   // activations only
-      if (k0 + TBK <= g.K) {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const float4*>(a_ptr[j] + kc);
-      } else {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j)
-          ra[j] = (a_ok[j] && kc < g.K) ? *reinterpret_cast<const float4*>(a_ptr[j] + kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      return;
-    }
     if (k0 + TBK <= g.K) {
       // Whole k-tile inside K (always, when K % TBK == 0): unconditional loads, no per-load branch.  Masked rows
       // (a_ptr = A) and weight rows past Nout (clamped) contribute to accumulators that the epilogue never stores.
@@ -422,12 +378,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       *reinterpret_cast<bf16x4_t*>(Ahi + lds_off(ar0 + AROWS * j, ac4 * 4)) = h;
       *reinterpret_cast<bf16x4_t*>(Alo + lds_off(ar0 + AROWS * j, ac4 * 4)) = l;
     }
-    if (!WDMA) {
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        *reinterpret_cast<uint4*>(Bhi + lds_off(wr0 + WROWS * j, wc8)) = rwh[j];
-        *reinterpret_cast<uint4*>(Blo + lds_off(wr0 + WROWS * j, wc8)) = rwl[j];
-      }
+    for (int j = 0; j < WJ; ++j) {
+      *reinterpret_cast<uint4*>(Bhi + lds_off(wr0 + WROWS * j, wc8)) = rwh[j];
+      *reinterpret_cast<uint4*>(Blo + lds_off(wr0 + WROWS * j, wc8)) = rwl[j];
     }
   };
 
@@ -453,19 +407,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
   const int nk_all = (g.K + TBK - 1) / TBK, kps = (nk_all + ksplit - 1) / ksplit;
   const int t0 = split * kps, nk = min(nk_all, t0 + kps);
   const int lr = lane & 31, lh = lane >> 5;
-  if (WDMA) issue_w(t0, 0);
   fetch(t0 * TBK);
-#if EVT_ABLATE >= 3 && EVT_ABLATE != 5   // timing experiment: loop-invariant fragments (read once from the staged first tile)
-  stage();
-  __syncthreads();
-  bf16x8_t abl_f[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) abl_f[i] = *reinterpret_cast<const bf16x8_t*>(lds + (i * 64 + lane) * 8);
-#endif
   for (int t = t0; t < nk; ++t) {
-#if EVT_ABLATE < 2 || EVT_ABLATE == 5
     stage();
-#endif
     const bool upd_now = do_upd && (t % tiles_n) == bn;
     if (upd_now) {
       const int kc = t * TBK + ac4 * 4;
@@ -473,45 +417,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
       for (int j = 0; j < AJ; ++j)
         if (a_ok[j] && kc < g.K) *reinterpret_cast<float4*>(u_ptr[j] + kc) = ra[j];
     }
-#if EVT_ABLATE < 1 || EVT_ABLATE == 5
     if (t + 1 < nk) fetch((t + 1) * TBK);   // before the barrier: the requests do not wait for the slowest wave's staging
-#endif
-    const int wbuf = WDMA ? ((t - t0) & 1) * BBUF : 0;
-    if (WDMA) {
-      // k-tile t + 1 goes into the other weight buffer: its last readers (k-tile t - 1) passed the barrier that ended
-      // the previous iteration.  Then wait for THIS tile's weights only: the AJ activation loads and the 4 LDS-DMA
-      // instructions just issued stay in flight across both barriers (raw s_barrier: __syncthreads() would drain them).
-      if (t + 1 < nk) issue_w(t + 1, ((t - t0) & 1) ^ 1);
-      if (t + 1 < nk && !upd_now) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AJ + 4) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // last tile, or stores of the p refresh in the queue
-      __builtin_amdgcn_s_barrier();
-    } else {
-#if EVT_ABLATE < 4 || EVT_ABLATE == 5
-      __syncthreads();
-#endif
-    }
+    __syncthreads();
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < TBK; ks += 16) {
       bf16x8_t ah[2], al[2], bh[2], bl[2];
-#if EVT_ABLATE >= 3 && EVT_ABLATE != 5
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { ah[i] = abl_f[0 + i]; al[i] = abl_f[2 + i]; bh[i] = abl_f[4 + i]; bl[i] = abl_f[6 + i]; }
-#else
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ao = lds_off(wm * 64 + i * 32 + lr, ks + 8 * lh);
-        const int bo = lds_off(wn * 64 + i * 32 + lr, ks + 8 * lh) + wbuf;
+        const int bo = lds_off(wn * 64 + i * 32 + lr, ks + 8 * lh);
         ah[i] = *reinterpret_cast<const bf16x8_t*>(Ahi + ao);
         al[i] = *reinterpret_cast<const bf16x8_t*>(Alo + ao);
         bh[i] = *reinterpret_cast<const bf16x8_t*>(Bhi + bo);
         bl[i] = *reinterpret_cast<const bf16x8_t*>(Blo + bo);
       }
-#endif
-#if EVT_ABLATE == 5   // no MFMA: the fragments are only pinned
-#pragma unroll
-      for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
-#else
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -520,13 +440,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-#endif
     }
     if (EVT_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
-    if (WDMA) __builtin_amdgcn_s_barrier();   // every wave's fragment reads are complete (their MFMAs consumed them)
-#if EVT_ABLATE < 4 || EVT_ABLATE == 5
-    else __syncthreads();
-#endif
+    __syncthreads();
   }
 
   int ncol[2];
@@ -566,9 +482,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TBK == 32 ? EVT_GEMM
         if (ncol[j] < g.Nout) {
           float v = acc[i][j][r] + bv[j];   // (activation per element here: doing all 64 up front costs 268 VGPRs -> 1 workgroup/CU)
           if (ACT == EVT_ACT_GELU_ERF) v = gelu_erf(v);
-#ifdef EVT_ABLATE_STORE   // timing experiment only: keep the arithmetic, drop (almost) every store
-          if (v == 12345.678f)
-#endif
           orow[ncol[j]] = v;
         }
       }
@@ -617,42 +530,33 @@ void launch_finish(const LinArgs& a, hipStream_t s, int ksplit, int dyn, int til
   else hipLaunchKernelGGL(splitk_finish_kernel<EVT_ACT_NONE>, fg, dim3(256), 0, s, a, ksplit, dyn, tiles_n);
 }
 
-template <int TBM, int TBN, int TBK, int WM, int WN, bool WDMA = false>
+template <int TBM, int TBN, int TBK, int WM, int WN>
 void launch_split_cfg(const LinArgs& a, hipStream_t s, int ksplit = 1, int dyn = 0) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (a.Nout + TBN - 1) / TBN;
   const dim3 grid(tiles_m * tiles_n * ksplit), block(WM * WN * 64);
   constexpr int TSP_ = (TBK == 32) ? TBK : TBK + 8;
-  constexpr size_t lds_bytes = (size_t)(2 * TBM * TSP_ + (WDMA ? 2 : 1) * 2 * TBN * TSP_) * 2 + (size_t)TBM * 8;
-  EVT_ALLOW_LDS((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN, WDMA>), lds_bytes);
-  EVT_ALLOW_LDS((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN, WDMA>), lds_bytes);
-  static const int want_map = getenv("EVT_GEMM_MAP") ? atoi(getenv("EVT_GEMM_MAP")) : 0;
-  const int tile_map = (want_map == 1 && (tiles_n % 2) == 0 && (tiles_m % 4) == 0) ? 1 : 0;
+  constexpr size_t lds_bytes = (size_t)(2 * TBM * TSP_ + 2 * TBN * TSP_) * 2 + (size_t)TBM * 8;
+  EVT_ALLOW_LDS((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), lds_bytes);
+  EVT_ALLOW_LDS((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), lds_bytes);
+  const int tile_map = 0;   // (1: 4 x 2 tile blocks per XCD -- measured no better than the row-major walk)
   if (a.act == EVT_ACT_GELU_ERF)
-    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN, WDMA>), grid, block, lds_bytes, s, a,
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_GELU_ERF, TBM, TBN, TBK, WM, WN>), grid, block, lds_bytes, s, a,
                        tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   else
-    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN, WDMA>), grid, block, lds_bytes, s, a,
+    hipLaunchKernelGGL((gated_linear_split_kernel<EVT_ACT_NONE, TBM, TBN, TBK, WM, WN>), grid, block, lds_bytes, s, a,
                        tiles_n, tiles_m * tiles_n, tile_map, ksplit, dyn);
   if (ksplit > 1) launch_finish(a, s, ksplit, dyn, tiles_n);
 }
 
-int forced_tile_variant() {
-  static const int forced = getenv("EVT_GEMM_TILE") ? atoi(getenv("EVT_GEMM_TILE")) : -1;
-  return forced;
-}
-
 void launch_split(const LinArgs& a, hipStream_t s) {
-  const int forced = forced_tile_variant();
-  const int variant = forced < 0 ? 0 : forced;
-  if (forced < 0 && evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_pipe.hip)
-  if (forced < 0) {   // a few hundred gated rows (one video stream): the latency-oriented kernel (evt_linear_small.hip)
+  if (evt_launch_split_big(a, s)) return;   // 256-row tiles when the launch fills the chip (evt_linear_pipe.hip)
+  {   // a few hundred gated rows (one video stream): the latency-oriented kernel (evt_linear_small.hip)
     const int ks = evt_launch_split_small(a, s);
     if (ks > 1) launch_finish(a, s, ks, 0, (a.Nout + 127) / 128);
     if (ks >= 1) return;
   }
-  static const int splitk_on = getenv("EVT_GEMM_SPLITK") ? atoi(getenv("EVT_GEMM_SPLITK")) : 1;
-  if (variant == 0 && splitk_on && a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {
+  if (a.ws != nullptr && (a.Nout & 3) == 0 && (a.ldo & 3) == 0) {   // split-K when the tile count leaves most CUs idle
     const int M = a.B * a.kcap;
     const bool dyn = a.count != nullptr && a.B <= EVT_SPLITK_DYN_MAX_CLIPS;
     const int ks = dyn ? splitk_factor_max(a.K, a.Nout) : splitk_factor(M, a.K, a.Nout);
@@ -661,20 +565,7 @@ void launch_split(const LinArgs& a, hipStream_t s) {
       return;
     }
   }
-  switch (variant) {
-    case 1: launch_split_cfg<128, 128, 64, 2, 2>(a, s); break;
-    case 2: launch_split_cfg<256, 128, 32, 4, 2>(a, s); break;
-    case 3: launch_split_cfg<256, 128, 64, 4, 2>(a, s); break;
-    case 4: launch_split_cfg<128, 256, 32, 2, 4>(a, s); break;
-    case 5: launch_split_cfg<256, 256, 32, 4, 4>(a, s); break;
-    case 6: launch_split_cfg<64, 64, 32, 1, 1>(a, s); break;
-    default: {
-      static const int wdma = getenv("EVT_GEMM_WDMA") ? atoi(getenv("EVT_GEMM_WDMA")) : 0;
-      if (wdma) launch_split_cfg<128, 128, 32, 2, 2, true>(a, s);
-      else launch_split_cfg<128, 128, 32, 2, 2>(a, s);
-      break;
-    }
-  }
+  launch_split_cfg<128, 128, 32, 2, 2>(a, s);
 }
 
 // fp32 (rows, cols) -> hl32 planes (evt_linear.h): one thread per 4 consecutive columns of a row; groups past `cols`
@@ -751,13 +642,13 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
     const int rc = set_selection(a, d->sel_norms, d->sel_parts, d->sel_N, d->sel_k, d->sel_mode, d->sel_thr, d->sel_idx, d->sel_count, d->sel_rest);
     if (rc != EVT_OK) return rc;
     EVT_REQUIRE(d->a_idx != nullptr && !d->a_bf16, EVT_ERR_BAD_ARG, "evt_gated_linear: an embedded selection needs gathered fp32 rows (a_idx)");
-    EVT_REQUIRE(forced_tile_variant() < 0 && evt_small_accepts(a), EVT_ERR_BAD_SHAPE,
+    EVT_REQUIRE(evt_small_accepts(a), EVT_ERR_BAD_SHAPE,
                 "evt_gated_linear: this launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select): "
                 "B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
   }
   if (d->a_bf16) {
     a.a_bf16 = 1;
-    EVT_REQUIRE(d->act == EVT_ACT_NONE && forced_tile_variant() < 0 && evt_big_choice(a) != 0, EVT_ERR_BAD_SHAPE,
+    EVT_REQUIRE(d->act == EVT_ACT_NONE && evt_big_choice(a) != 0, EVT_ERR_BAD_SHAPE,
                 "evt_gated_linear: bf16 activations only on the persistent 256-row kernel without activation (query "
                 "evt_gated_linear_big_tile first): B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
   }
@@ -765,7 +656,7 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
 }
 
 extern "C" int evt_gated_linear_embeds_select(const evt_linear_desc* d) {
-  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || d->a_idx == nullptr || d->a_bf16 || forced_tile_variant() >= 0) return 0;
+  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || d->a_idx == nullptr || d->a_bf16) return 0;
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
   a.sel_norms = d->sel_norms != nullptr ? d->sel_norms : reinterpret_cast<const float*>(d);   // shape-only: any non-null value
@@ -775,7 +666,7 @@ extern "C" int evt_gated_linear_embeds_select(const evt_linear_desc* d) {
 }
 
 extern "C" int evt_gated_linear_big_tile(const evt_linear_desc* d) {
-  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || forced_tile_variant() >= 0) return 0;
+  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0) return 0;
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
   return evt_big_choice(a);
@@ -805,12 +696,12 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
   if (d->sel_norms != nullptr) {   // the MLP gate's selection inside the first launch; the second reads the list it wrote
     const int rc_sel = set_selection(fc1, d->sel_norms, d->sel_parts, d->sel_N, d->sel_k, d->sel_mode, d->sel_thr, d->sel_idx, d->sel_count, d->sel_rest);
     if (rc_sel != EVT_OK) return rc_sel;
-    EVT_REQUIRE(d->idx != nullptr && forced_tile_variant() < 0 && evt_small_accepts(fc1), EVT_ERR_BAD_SHAPE,
+    EVT_REQUIRE(d->idx != nullptr && evt_small_accepts(fc1), EVT_ERR_BAD_SHAPE,
                 "evt_gated_mlp: the first launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select)");
   }
   // Both launches on the 256-row kernel: the hidden scratch holds hl32 lines (same bytes as fp32) -- GELU(x) is split once,
   // in the first launch's epilogue, and the second launch stages it without conversion.
-  if (fc1.Wsplit != nullptr && forced_tile_variant() < 0 && (d->Dh & 31) == 0 && evt_big_choice(fc1) != 0 && evt_big_choice(fc2) != 0) {
+  if (fc1.Wsplit != nullptr && (d->Dh & 31) == 0 && evt_big_choice(fc1) != 0 && evt_big_choice(fc2) != 0) {
     fc1.out_planes = 1;
     fc2.a_planes = 1;
   }

@@ -336,9 +336,7 @@ void launch_small_tile(const LinArgs& a, hipStream_t s, int ksplit) {
   const bool looped = (a.count != nullptr || (a.sel_norms != nullptr && a.sel_mode == 1)) && a.B == 1;
   // row tiles launched under a device-side count: enough for 512 rows, but not more (column, row) pairs than CUs when that
   // still covers 256 rows -- a 9th workgroup on a 32-CU XCD is a second round
-  static const int gm_env = getenv("EVT_SMALL_GM") ? atoi(getenv("EVT_SMALL_GM")) : 0;
-  int gm_l = std::min(tiles_m, 512 / BM);
-  if (gm_env > 0) gm_l = std::min(tiles_m, gm_env);
+  const int gm_l = std::min(tiles_m, 512 / BM);
   const int gm = looped ? gm_l : tiles_m;
   if (a.sel_norms != nullptr) {
     if (looped) launch_small_inst<ACT, BM, BN, 4, true, true>(a, s, ksplit, tiles_n, gm);
@@ -384,10 +382,6 @@ int evt_launch_split_small(const LinArgs& a, hipStream_t s) {
   // waves = 4 waves per CU; with eight waves it spills) -- at count = 409 of 4096 rows QKV 28.4 us / MLP-1 28.3 us against
   // 20.4 / 22.2 us on 32x32 tiles (146 + 16 registers, three workgroups per CU).
   if (counted_ && a.B == 1) bm = 32;
-  static const int force_tile = getenv("EVT_SMALL_TILE") ? atoi(getenv("EVT_SMALL_TILE")) : 0;
-  static const int force_ks = getenv("EVT_SMALL_KS") ? atoi(getenv("EVT_SMALL_KS")) : 0;
-  if (force_tile == 32 || force_tile == 64) bm = force_tile;
-  if (force_ks > 1 && a.ws != nullptr && (int64_t)force_ks * M * a.Nout * 4 <= a.ws_bytes && a.K / 32 >= force_ks) { bm = 64; ks = force_ks; }
   const bool gelu = a.act == EVT_ACT_GELU_ERF;
   if (bm == 64) {
     if (gelu) launch_small_tile<EVT_ACT_GELU_ERF, 64, 64>(a, s, ks);

@@ -67,6 +67,9 @@ thread_local SelRider g_rider = {{nullptr, nullptr}, {0, 0}, nullptr, 0, 0};   /
 
 // a selection that launches nothing must not leave its rider armed for some later launch (the range may be gone by then)
 void drop_rider() { g_rider = {{nullptr, nullptr}, {0, 0}, nullptr, 0, 0}; }
+// Every evt_select_* entry point holds one of these: whichever way it returns (a launch, an early return, a failed
+// EVT_REQUIRE), the rider armed for it is gone afterwards -- a stale pointer must never ride on some later, unrelated launch.
+struct RiderScope { ~RiderScope() { drop_rider(); } };
 
 int launch_select(const float* norms, int B, int N, int k, float thr, int mode, int kcap, int32_t* idx, int32_t* count,
                   int32_t* rest, void* stream, int parts = 0) {
@@ -77,8 +80,7 @@ int launch_select(const float* norms, int B, int N, int k, float thr, int mode, 
   const int64_t n16 = rider.n16[0] + rider.n16[1];
   // Rider workgroups: at most 128 -- half the CUs, so that none of them shares a CU with the selection's own workgroup(s), which
   // set the launch's length (672^2 frame: 1.62 ms with 128 riders of 256 threads, 1.67 with 256; 1.69 without riders).
-  // EVT_RIDER_WGS overrides.
-  static const int rider_wgs = getenv("EVT_RIDER_WGS") ? atoi(getenv("EVT_RIDER_WGS")) : 128;
+  constexpr int rider_wgs = 128;
   const int per = rider.deep ? 8 : 4;
   const int extra = n16 == 0 ? 0 : (int)std::min<int64_t>((n16 + per * threads - 1) / (per * threads), std::max(1, rider_wgs));
   if (N <= 2048) {
@@ -102,51 +104,54 @@ extern "C" int evt_select_prefetch_next(const void* ptr, int64_t bytes, void* si
   g_rider.n16[q] = bytes / 16;
   g_rider.sink = reinterpret_cast<uint32_t*>(sink);
   g_rider.magic = 0x9e3779b9u;
-  static const int deep = getenv("EVT_RIDER_DEPTH") ? atoi(getenv("EVT_RIDER_DEPTH")) >= 8 : 1;
-  g_rider.deep = deep;
+  g_rider.deep = 1;   // 8 x 16-byte loads in flight per thread (4: measured slower, profiles/r04/prefetch_rider_shapes.txt)
   return EVT_OK;
 }
 
 extern "C" int evt_select_topk(const float* norms, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream) {
+  RiderScope rider_scope;
   EVT_REQUIRE(norms != nullptr && idx != nullptr, EVT_ERR_BAD_ARG, "evt_select_topk: null pointer");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk: B=%d N=%d", B, N);
   EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk: k=%d out of range for N=%d (topk would raise)", k, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk: N=%d exceeds %d", N, SEL_MAX_N);
-  if (B == 0) { drop_rider(); return EVT_OK; }
+  if (B == 0) return EVT_OK;
   EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk: k == 0 with a complement list");
-  if (k == 0) { drop_rider(); return EVT_OK; }
+  if (k == 0) return EVT_OK;
   return launch_select(norms, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream);
 }
 
 extern "C" int evt_select_threshold(const float* norms, int B, int N, float threshold, int kcap, int32_t* idx,
                                     int32_t* count, int32_t* rest, void* stream) {
+  RiderScope rider_scope;
   EVT_REQUIRE(norms != nullptr && idx != nullptr && count != nullptr, EVT_ERR_BAD_ARG, "evt_select_threshold: null pointer");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_threshold: B=%d N=%d", B, N);
   EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold: kcap=%d must be >= N=%d", kcap, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold: N=%d exceeds %d", N, SEL_MAX_N);
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold: NaN threshold");
-  if (B == 0) { drop_rider(); return EVT_OK; }
+  if (B == 0) return EVT_OK;
   return launch_select(norms, B, N, 0, threshold, 1, kcap, idx, count, rest, stream);
 }
 
 extern "C" int evt_select_topk_sq(const float* sq_parts, int parts, int B, int N, int k, int32_t* idx, int32_t* rest, void* stream) {
+  RiderScope rider_scope;
   EVT_REQUIRE(sq_parts != nullptr && idx != nullptr && parts > 0, EVT_ERR_BAD_ARG, "evt_select_topk_sq: null pointer / parts");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_topk_sq: B=%d N=%d", B, N);
   EVT_REQUIRE(k >= 0 && k <= N, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k=%d out of range for N=%d (topk would raise)", k, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_topk_sq: N=%d exceeds %d", N, SEL_MAX_N);
-  if (B == 0) { drop_rider(); return EVT_OK; }
+  if (B == 0) return EVT_OK;
   EVT_REQUIRE(k > 0 || rest == nullptr, EVT_ERR_BAD_ARG, "evt_select_topk_sq: k == 0 with a complement list");
-  if (k == 0) { drop_rider(); return EVT_OK; }
+  if (k == 0) return EVT_OK;
   return launch_select(sq_parts, B, N, k, 0.f, 0, k, idx, nullptr, rest, stream, parts);
 }
 
 extern "C" int evt_select_threshold_sq(const float* sq_parts, int parts, int B, int N, float threshold, int kcap, int32_t* idx,
                                        int32_t* count, int32_t* rest, void* stream) {
+  RiderScope rider_scope;
   EVT_REQUIRE(sq_parts != nullptr && idx != nullptr && count != nullptr && parts > 0, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: null pointer / parts");
   EVT_REQUIRE(B >= 0 && N > 0, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: B=%d N=%d", B, N);
   EVT_REQUIRE(kcap >= N, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: kcap=%d must be >= N=%d", kcap, N);
   EVT_REQUIRE(N <= SEL_MAX_N, EVT_ERR_BAD_SHAPE, "evt_select_threshold_sq: N=%d exceeds %d", N, SEL_MAX_N);
   EVT_REQUIRE(threshold == threshold, EVT_ERR_BAD_ARG, "evt_select_threshold_sq: NaN threshold");
-  if (B == 0) { drop_rider(); return EVT_OK; }
+  if (B == 0) return EVT_OK;
   return launch_select(sq_parts, B, N, 0, threshold, 1, kcap, idx, count, rest, stream, parts);
 }

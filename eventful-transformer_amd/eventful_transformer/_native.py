@@ -219,7 +219,7 @@ def _stream():
     switch is only recorded: torch synchronises the device before a capture begins, and a captured stream runs nothing."""
     st = torch.cuda.current_stream()
     h = st.cuda_stream
-    key = (threading.get_ident(), st.device_index, _lane)
+    key = (threading.get_ident(), st.device_index, _current_lane())
     last = _lane_stream.get(key)
     if last is None or last[0] != h:
         if last is not None and not torch.cuda.is_current_stream_capturing() and not last[2]:
@@ -254,27 +254,33 @@ def store_code(dtype):
 # and is what `lane` is for when they should overlap; every host thread has its own buffers.
 # --------------------------------------------------------------------------------------------------
 _pool = {}
-_lane = 0   # frames of one stream captured side by side on several HIP streams (graphs.FrameGraphs.run_pipelined) each
-            # get their own set of work buffers: the lane is part of the pool key
+# Frames of one stream captured side by side on several HIP streams (graphs.FrameGraphs.run_pipelined), or independent batches
+# overlapped on two streams (bench.py --overlap), each get their own set of work buffers: the lane is part of the pool key.  The
+# current lane is per HOST THREAD (two threads inside `with lane(i)` must not overwrite each other's lane mid-call).
+_lane_local = threading.local()
+
+
+def _current_lane():
+    return getattr(_lane_local, "index", 0)
 
 
 class lane:
-    """Context manager: scratch buffers requested inside belong to work lane `index`."""
+    """Context manager: scratch buffers requested inside belong to work lane `index` (of the calling host thread)."""
 
     def __init__(self, index):
-        self.index = index
+        self.index = int(index)
 
     def __enter__(self):
-        global _lane
-        self._saved, _lane = _lane, self.index
+        self._saved = _current_lane()
+        _lane_local.index = self.index
+        return self
 
     def __exit__(self, *exc):
-        global _lane
-        _lane = self._saved
+        _lane_local.index = self._saved
 
 
 def scratch(name, shape, dtype, device):
-    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device(), _lane,
+    key = (name, tuple(shape), dtype, device.index if device.index is not None else torch.cuda.current_device(), _current_lane(),
            threading.get_ident())
     t = _pool.get(key)
     if t is None:

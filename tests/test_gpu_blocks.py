@@ -604,7 +604,8 @@ def test_vitdet_1024_threshold(golden_dir, thr, fixture):
     from eventful_transformer import blocks as evt_blocks
     g = H.load_npz(os.path.join(golden_dir, fixture))
     keys = {"qkv": "qkv_index", "projection": "projection_index", "mlp": "mlp_index"}
-    state = {"n": 0, "equal": 0, "near_only": 0, "worst_rel": 0.0, "bad": []}
+    state = {"n": 0, "equal": 0, "near_only": 0, "worst_rel": 0.0, "bad": [], "strict": 0, "strict_bad": []}
+    gate_col = {"qkv": 0, "projection": 1, "mlp": 2}
     counts = []
 
     def tap(_blk, tag, idx, count):
@@ -614,6 +615,12 @@ def test_vitdet_1024_threshold(golden_dir, thr, fixture):
         want = torch.from_numpy(g[f"idx_{t}_{bi}_{keys[tag]}"].reshape(-1).astype(np.int64))
         mine = idx[0, : int(count[0])].cpu().long()
         counts.append(int(mine.numel()))
+        # a gate none of whose tokens sits within 1e-3 (relative) of the threshold leaves no room for another summation order:
+        # its list (and so its count) must be EXACTLY the reference's
+        if float(g["margins"][t - 1, bi, gate_col[tag]]) >= 1e-3:
+            state["strict"] += 1
+            if not torch.equal(mine, want):
+                state["strict_bad"].append((t, bi, tag))
         if torch.equal(mine, want):
             state["equal"] += 1
         else:
@@ -644,7 +651,10 @@ def test_vitdet_1024_threshold(golden_dir, thr, fixture):
              f"{[(int(a[0, 0]), int(a[2, 1]), int(a[11, 2])) for a in ref_counts]}; closest token to the threshold {float(g['margins'].min()):.1e}; "
              f"HIP lists equal to the reference's: {state['equal']}/{state['n']}, differing in NEAR tokens only: {state['near_only']} "
              f"(largest relative distance of a flipped token {state['worst_rel']:.1e}), otherwise: {len(state['bad'])}")
+    H.report(f"    gates with every token at least 1e-3 (relative) away from the threshold: {state['strict']}, all of them with exactly the reference's list: "
+             f"{not state['strict_bad']}")
     assert not state["bad"], state["bad"]
+    assert not state["strict_bad"] and state["strict"] >= 20, (state["strict"], state["strict_bad"])
     assert state["equal"] >= 0.9 * state["n"], state
     assert len(set(ref_counts.reshape(-1).tolist())) >= 6          # r really varies with the frame (and, mildly, with the gate)
     got = np.asarray(counts).reshape(frames, 12, 3)
