@@ -16,8 +16,9 @@ graphs per model -- the dense first frame of a clip and the gated incremental fr
 Replaying the first-frame graph rewrites every state tensor completely, so `reset()` between clips costs
 nothing and the model's own `reset()` is only needed before the graphs exist.  Schedule on a fresh object: the
 FIRST call runs one first frame and one incremental frame eagerly on the given input (scratch pools of both paths,
-split weight planes, window maps), resets the model, captures BOTH graphs back to back and replays the first; everything
-after is replay only.  (Until round 5 the incremental graph was warmed and captured lazily on frames 1 and 2: if another
+split weight planes, window maps), resets the model, captures the first-frame graph, replays it and runs one eager gated
+frame (lazily created gated-path state comes into being OUTSIDE a capture), captures the incremental graph and replays the
+first-frame graph for the caller's frame; everything after is replay only.  (Until round 5 the incremental graph was warmed and captured lazily on frames 1 and 2: if another
 FrameGraphs of the same model, or an eager `model.reset()`, ran in between, that late capture recorded launches against
 state tensors that were not this object's.)  The numbers are bit-identical to the eager path (same kernels, same order, same
 buffers).
@@ -150,7 +151,14 @@ class FrameGraphs:
             elif isinstance(m, PositionEncoding):
                 self._keep.append(m.sized())
         self._first = self._capture()    # allocates the state tensors (graph-private pool), leaves the model "past its first frame"
-        self._inc = self._capture()      # the gated path on those tensors (a capture records, it does not run)
+        # The gated path creates some of its state lazily on the first gated frame (zero-filled accumulators, transposed gate
+        # references): created INSIDE a capture, that zero fill would become a node of the incremental graph and wipe the state on
+        # every replay.  So the state is brought to life for real first -- replay the first-frame graph, run ONE eager gated frame --
+        # and only then is the gated path captured (it now finds everything in place: no creation inside the capture).  The caller
+        # replays the first-frame graph right after this, which re-initialises the clip.
+        self._first[0].replay()
+        self._fwd(self._x)
+        self._inc = self._capture()
         self._sig = self._signature()
         self._stale = False
         self.model.__dict__["_evt_state_owner"] = weakref.ref(self)

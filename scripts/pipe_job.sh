@@ -15,10 +15,7 @@ case $what in
       EVT_PIPE_WAVES=$waves EVT_GEMM_BIG=$mode EVT_GEMM=split EVT_GEMM_SMALL=0 timeout 600 python tests/big_tile_check.py 2>&1 | tail -4 | grep -v amdgpu.ids | tee -a $OUT/check.txt
     done; done ;;
   kb)
-    for cfg in "EVT_GEMM_PIPE=0" "EVT_GEMM_PIPE=1 EVT_PIPE_WAVES=4" "EVT_GEMM_PIPE=1 EVT_PIPE_WAVES=8"; do
-      echo "== $cfg" | tee -a $OUT/kb.txt
-      env $cfg python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
-    done ;;
+    python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt ;;
   kbv=*)   # build variants under scripts/probes/bin/libevt_<v>.so
     for v in $(echo ${what#kbv=} | tr ',' ' '); do for w in ${KBW:-8}; do
       echo "== variant $v, $w waves" | tee -a $OUT/kb.txt
@@ -32,9 +29,8 @@ case $what in
     (cd /tmp && rocprofv3 -L > $GRAFT_REPO_ROOT/$OUT/counters_available.txt 2>&1)
     grep -o "^\s*[A-Z][A-Za-z0-9_]*" $OUT/counters_available.txt | sort -u | tr -d ' \t' | tr '\n' ' ' > $OUT/counter_names.txt
     SHAPE=${SHAPE:-"32768 768 2304 12 0"}
-    for cfg in "0 8" "1 4" "1 8"; do
-      set -- $cfg; export EVT_GEMM_PIPE=$1 EVT_PIPE_WAVES=$2
-      tag=pipe$1w$2
+    for cfg in "pipe"; do
+      tag=$cfg
       i=0
       for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" \
                "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
@@ -51,7 +47,7 @@ case $what in
       python scripts/pmc_kernel.py $OUT gated_linear 2>&1 | tee -a $OUT/pmc.txt
       find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "p_counter_collection.csv" -delete; rm -rf $OUT/pmc_${tag}_*
     done
-    unset EVT_GEMM_PIPE EVT_PIPE_WAVES ;;
+    ;;
   tiles)   # forced tile shapes on the headline launches (EVT_GEMM_BIG: 2 = 256x256, 4 = 256x192, 3 = 256x128), 8 and 4 waves
     for w in 8 4; do for mode in 2 4 3; do
       echo "== EVT_GEMM_BIG=$mode, $w waves" | tee -a $OUT/tiles.txt

@@ -124,6 +124,43 @@ def test_vivit_graph_replay_follows_policy_and_weight_changes(golden_dir):
         model.use_frame_graphs(0)
 
 
+def test_vitdet_whole_frame_graph_replay_is_bit_identical():
+    """`FrameGraphs(ViTDet)`: the whole frame (uint8 image -> pyramid features) replayed as HIP graphs gives bit for bit the eager
+    model's features on EVERY frame of a stream -- including the first replayed incremental frame (until round 5 that frame ran
+    eagerly, so a capture that re-created lazily initialised gated-path state inside the incremental graph would have gone unseen)
+    -- and over a second clip."""
+    from eventful_transformer import policies
+    from eventful_transformer.graphs import FrameGraphs
+    from models.vitdet import ViTDet
+    bcfg = dict(block_config=dict(dim=768, heads=12, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14)),
+                depth=12, position_encoding_size=(14, 14), block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
+                window_indices=H.VITDET_WINDOWED)
+    det = ViTDet(bcfg, (3, 448, 448), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], 256, (16, 16), [4.0, 2.0, 1.0, 0.5])
+    det.load_state_dict(H.seeded_module_params(det, 6), strict=True)
+    det = det.eval().to(DEV)
+    H.set_policies(det, policies.TokenNormTopK, k=128)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    base = torch.randint(0, 256, (1, 3, 448, 448), dtype=torch.uint8, device=DEV, generator=g)
+    frames = []
+    for t in range(5):     # a stream: a moving 96 x 96 patch of fresh pixels per frame
+        f = base.clone()
+        f[..., 40 * t:40 * t + 96, 60 * t:60 * t + 96] = torch.randint(0, 256, (1, 3, 96, 96), dtype=torch.uint8, device=DEV, generator=g)
+        frames.append(f)
+    with torch.inference_mode():
+        want = []
+        for clip in range(2):
+            det.reset()
+            want.append([{k_: v.clone() for k_, v in det(f).items()} for f in (frames if clip == 0 else frames[::-1])])
+        runner = FrameGraphs(det)
+        for clip in range(2):
+            runner.reset()
+            for t, f in enumerate(frames if clip == 0 else frames[::-1]):
+                got = runner(f)
+                for k_ in want[clip][t]:
+                    assert torch.equal(got[k_], want[clip][t][k_]), (clip, t, k_, float((got[k_] - want[clip][t][k_]).abs().max()))
+        runner.release()
+
+
 def test_vitdet_pre_backbone_and_pyramid(golden_dir):
     """models/vitdet.py of this package vs the reference's ViTDetPreprocessing + LinearEmbedding (patch GEMM) and
     SimplePyramid (transposed convs as four scatter-GEMMs, 1x1 / 3x3 convs as GEMMs, LayerNorm row passes)."""
