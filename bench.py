@@ -30,6 +30,8 @@ stream), `check` (clip 0 of the timed model against the CPU oracle, after the ti
 """
 import argparse
 import glob
+import re
+import threading
 import hashlib
 import json
 import os
@@ -724,6 +726,53 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
     return None, None, {}
 
 
+def gpu_clock_mhz():
+    """Current shader clock of GPU 0 from rocm-smi (None when the tool or the reading is unavailable): read right before and right
+    behind the timed region so that a box that clocks lower shows up in the line (run-to-run spread across boxes is +-3 %)."""
+    import shutil
+    import subprocess
+    tool = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([tool, "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for key, val in card.items():
+            if "sclk" in key.lower():
+                m = re.search(r"(\d+)\s*mhz", str(val).lower())
+                if m:
+                    return int(m.group(1))
+    except Exception:
+        pass
+    return None
+
+
+class ClockSampler:
+    """Samples the shader clock (rocm-smi) from a host thread while the timed region runs: rank 0 only, a reading every ~0.7 s."""
+
+    def __init__(self):
+        self.samples, self._stop, self._thread = [], threading.Event(), None
+
+    def __enter__(self):
+        def run():
+            while not self._stop.is_set():
+                v = gpu_clock_mhz()
+                if v is not None:
+                    self.samples.append(v)
+                self._stop.wait(0.7)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=30)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "rocm-smi --showclocks (sclk) during the timed region"}
+
+
 _T0 = time.perf_counter()
 
 
@@ -1344,7 +1393,14 @@ def main():
     kind, block_class, frames, k, cast, grid = w["kind"], w["block_class"], w["frames"], w["k"], w["cast"], w["grid"]
     model, data, sd, policy = w["model"], w["data"], w["sd"], w["policy"]
     log(f"model + {len(data)} resident batch(es) of synthetic clips ready")
-    elapsed, roofline = time_workload(w, args.steps, args.warmup, world, device, events_on=not args.no_kernel_events, graphs=args.graphs)
+    sampler = ClockSampler() if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
+    try:
+        elapsed, roofline = time_workload(w, args.steps, args.warmup, world, device, events_on=not args.no_kernel_events, graphs=args.graphs)
+    finally:
+        if sampler is not None:
+            sampler.__exit__()
     log(f"timed region: {args.steps} step(s) in {elapsed:.2f}s")
 
     clips_per_step = w["total"]
@@ -1373,6 +1429,7 @@ def main():
                        "launch": ("hip-graph replay" if args.graphs else "eager") +
                                  (f", {len(w['lanes'])} resident batches in flight on {len(w['lanes'])} HIP streams" if w.get("lanes") else "")},
             "roofline": roofline,
+            "gpu_clock_mhz": sampler.summary() if sampler is not None else None,
         }
         if w.get("lanes"):
             line["overlap"] = {"batches_in_flight": len(w["lanes"]), "bit_identical_to_serial": w.get("overlap_bit_identical"),

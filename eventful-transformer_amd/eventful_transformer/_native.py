@@ -380,7 +380,7 @@ def event_work(entry):
 
 
 def gemm_kernel_name():
-    return "gated_linear_split_kernel" if GEMM_MODE == "split" else "gated_linear_kernel"
+    return "gated_linear_pipe_kernel" if GEMM_MODE == "split" else "gated_linear_kernel"
 
 
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate

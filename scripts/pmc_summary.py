@@ -10,14 +10,14 @@ NAMES = ["gated_linear_split_kernel<0", "gated_linear_split_kernel<1", "gated_li
          "av_kernel", "softmax_gate_kernel", "split_weights_kernel", "attn_dense_kernel", "splitk_finish_kernel"]
 
 
-BIG = re.compile(r"gated_linear_split_big_kernel<(\d), 256, (\d+), \d, \d, \d, (\d)>")
+BIG = re.compile(r"gated_linear_pipe_kernel<(\d), (\d+), (\d), \d>")   # <ACT, TBN, FMT, WAVES> (evt_linear_pipe.hip)
 FMT = {"0": "fp32", "1": "presplit_A", "2": "hl32_out", "4": "bf16_A"}
 
 
 def key(n):
     m = BIG.search(n)   # the persistent 256-row kernel: one row per (activation, tile width, operand format)
     if m:
-        k = f"gated_linear_big_kernel<{m.group(1)}|256x{m.group(2)}|{FMT.get(m.group(3), m.group(3))}"
+        k = f"gated_linear_pipe_kernel<{m.group(1)}|256x{m.group(2)}|{FMT.get(m.group(3), m.group(3))}"
         if k not in NAMES:
             NAMES.insert(0, k)
         return k
