@@ -386,6 +386,32 @@ def usable_cores():
     return n
 
 
+def pin_rank_cores(world, local_rank):
+    """One process per GPU, each an eager Python launch loop: on a box whose cgroup grants 16 cores to 8 ranks, unpinned ranks
+    migrate over each other's cores.  Rank r takes the r-th contiguous slice of the cores this process group may use (at least one
+    core each; with fewer cores than ranks the slices wrap and the pinning is skipped).  Returns the sorted core list, or None."""
+    if world <= 1:
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return None
+    budget = min(len(allowed), max(1, usable_cores()))
+    per = budget // world
+    if per < 1:
+        return None
+    # spread the slices over the whole allowed set (a quota of 16 cores on a 256-core mask: every 16th block), so that the ranks
+    # do not crowd one NUMA node
+    stride = len(allowed) // world
+    mine = allowed[local_rank * stride: local_rank * stride + per]
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, per))
+    except Exception:
+        return None
+    return mine
+
+
 def _cpu_sample(sd, cast, k, frames, model_kind, threads, budget_s):
     """Whole single clips (B=1, T frames, dense first frame included) through the oracle for ~budget_s."""
     torch.set_num_threads(threads)
@@ -1382,6 +1408,7 @@ def main():
         dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    rank_cores = pin_rank_cores(world, local_rank)   # one eager launch loop per GPU: a disjoint slice of the host cores each
 
     from eventful_transformer import _native
 
@@ -1425,7 +1452,8 @@ def main():
             "data": "synthetic", "per_gpu": round(value / world, 2),
             "config": {"workload": wl, "clips_per_step": clips_per_step, "resident_clips_per_gpu": w["resident"],
                        "batches_per_gpu_per_step": len(w["batches"]), "frames_per_step": clips_per_step * frames,
-                       "parallelism": f"clip-sharded x{world} (clip i -> rank i mod {world})",
+                       "parallelism": f"clip-sharded x{world} (clip i -> rank i mod {world})" +
+                                      (f", rank 0 pinned to {len(rank_cores)} host core(s)" if rank_cores else ""),
                        "launch": ("hip-graph replay" if args.graphs else "eager") +
                                  (f", {len(w['lanes'])} resident batches in flight on {len(w['lanes'])} HIP streams" if w.get("lanes") else "")},
             "roofline": roofline,
@@ -1527,6 +1555,7 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.init_process_group(args.backend)
     dev = torch.device("cpu")
+    cores = pin_rank_cores(world, int(os.environ.get("LOCAL_RANK", rank)))
     # rank 0 generates the weights, every other rank only allocates the shapes and receives them (as build_workload does)
     sd = {"w": torch.full((4,), 1.0)} if rank == 0 else {"w": torch.zeros(4)}
     if world > 1:
@@ -1547,13 +1576,19 @@ def dry_run(args, world, rank):
         dist.all_gather_object(counts, sum(len(b) for b in mine))
         dist.all_gather_object(batches, [len(b) for b in mine])
         dist.all_gather_object(covers, [c for b in mine for c in b])
+        pinned = [None] * world
+        dist.all_gather_object(pinned, cores)
     else:
         counts, batches, covers = [sum(len(b) for b in mine)], [[len(b) for b in mine]], [[c for b in mine for c in b]]
+        pinned = [cores]
     if rank == 0:
         print(json.dumps({"metric": "dry-run", "value": round(total * args.steps / elapsed, 2), "unit": "clips/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling,
                           "clips_per_rank": counts, "batches_per_rank": batches,
                           "disjoint_cover": sorted(c for cv in covers for c in cv) == list(range(total)),
+                          "cores_per_rank": pinned,
+                          "cores_disjoint": (all(p is not None for p in pinned) and
+                                             len({c for p in pinned for c in p}) == sum(len(p) for p in pinned)) if world > 1 else None,
                           "config": {"clips_per_step": total, "resident_clips_per_gpu": args.clips},
                           "weights_from_rank0": bool(float(sd["w"][0]) == 1.0),
                           "collectives_in_timed_region": int(inside), "collectives_total": _collective_calls[0],

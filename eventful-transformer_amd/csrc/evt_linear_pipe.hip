@@ -607,7 +607,8 @@ int evt_big_choice(const LinArgs& a) {
     return 0;
   if (mode >= 2 && mode <= 4) return mode;
   // One persistent workgroup per CU: a launch of T tiles runs in ceil(T / CUs) rounds.  Take a tile whose columns divide Nout (no
-  // wasted edge columns) and whose last round is at least 85 % full.  256x192 first: QKV (Nout = 2304) is 1536 tiles = 6.0 rounds
+  // wasted edge columns) and whose rounds are at least 75 % full on average (the dense first frame of B = 256 clips: projection / MLP-2 are
+  // 788 tiles of 256x192 = 3.08 rounds -- 77 % -- and still beat the 128x128 kernel, which took them until round 5).  256x192 first: QKV (Nout = 2304) is 1536 tiles = 6.0 rounds
   // instead of the 4.5 (-> 5) of 256x256, and the 192-column instantiations keep every register: 310 vs 346 us for QKV, 441 vs 497
   // for MLP-1 + GELU, 790 vs 859 for the MLP pair at B = 256 (profiles/r05/gemm_tile_shapes.txt).
   const int cus = evt_cu_count(), M = a.B * a.kcap;
@@ -615,7 +616,7 @@ int evt_big_choice(const LinArgs& a) {
   auto fills = [&](int tbn) {
     if (a.Nout % tbn != 0) return false;
     const int tiles = tiles_m * (a.Nout / tbn), rounds = (tiles + cus - 1) / cus;
-    return tiles >= cus && tiles * 100 >= rounds * cus * 85;
+    return tiles >= cus && tiles * 100 >= rounds * cus * 75;
   };
   if (fills(192)) return 4;
   if (fills(256)) return 2;

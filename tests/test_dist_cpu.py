@@ -109,6 +109,12 @@ def test_eight_rank_dry_run_is_the_strong_scaling_split_of_the_one_rank_run():
     # barriers (max over ranks); the collectives that do exist (weight broadcast, the barriers, the max-reduce) are outside.
     assert eight["collectives_in_timed_region"] == 0 and eight["collectives_total"] >= 4
     assert one["collectives_in_timed_region"] == 0 and one["collectives_total"] == 0
+    # one eager Python launch loop per GPU: every rank pins itself to its own slice of the host cores (bench.pin_rank_cores); with
+    # at least as many usable cores as ranks the slices are disjoint (this container: 8 cores for 8 ranks)
+    import bench
+    if bench.usable_cores() >= 8:
+        assert eight["cores_disjoint"] is True and all(len(c) >= 1 for c in eight["cores_per_rank"]), eight["cores_per_rank"]
+    assert one["cores_disjoint"] is None
 
 
 def test_timed_region_counts_collectives():
