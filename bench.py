@@ -68,6 +68,13 @@ WORKLOADS = {
     "vivit_dense": ("vivit", "Block",         16,     0,    None,       14),
     "vitdet672":   ("vitdet", "EventfulBlock", 12,    256,  None,       42),
     "vitdet1024":  ("vitdet", "EventfulBlock", 8,     0,    "bfloat16", 64),
+    # the reference's own GPU timing / evaluation settings (configs/time/*/_cuda.yml:5: matmul_2_cast "float16"):
+    "vivit16_fp16":    ("vivit", "EventfulBlock", 16,  128,  "float16", 14),   # config 2's model in that setting
+    "vivit401_fp16":   ("vivit", "EventfulBlock", 32,  50,   "float16", 20),   # EPIC-Kitchens: 32 x 320^2 -> 20 x 20 + class token = 401 tokens,
+                                                                             # k = 50 (configs/models/vivit_b_epic_kitchens.yml:5-8, time/.../temporal_cuda.yml:5)
+    "vitdet672_fp16":  ("vitdet", "EventfulBlock", 12, 256,  "float16", 42),   # configs/time/vitdet_vid/_cuda.yml:5-7
+    "vitdet1024_k512": ("vitdet", "EventfulBlock", 8,  512,  "float16", 64),   # configs/time/vitdet_vid/temporal_1024_cuda.yml:5 (top-k 512)
+    "vitdet672_pool2": ("vitdet", "EventfulBlock", 12, 256,  "float16", 42, {"pool": 2}),   # 'spatiotemporal': configs/evaluate/vitdet_vid/_spatial.yml:4-6
 }
 
 
@@ -102,20 +109,20 @@ def _sharpen_qk(sd, prefix, qk_std, std):
     return sd
 
 
-def seeded_state_dict(seed=77, std=0.02, qk_std=None):
+def seeded_state_dict(seed=77, std=0.02, qk_std=None, tokens=TOKENS):
     """ViViT-B spatial sub-model parameters under the reference's state_dict names (ViViTSubModel,
     vivit.py:272-291).  Version-stable generator (numpy RandomState), as in the parity tests."""
-    sd = _seeded_state_dict(seed, std)
+    sd = _seeded_state_dict(seed, std, tokens)
     return sd if qk_std is None else _sharpen_qk(sd, "backbone.", qk_std, std)
 
 
-def _seeded_state_dict(seed, std):
+def _seeded_state_dict(seed, std, tokens=TOKENS):
     rs = np.random.RandomState(seed)
 
     def n(*shape, s=std):
         return torch.from_numpy((rs.standard_normal(shape) * s).astype(np.float32))
 
-    sd = {"backbone.position_encoding.encoding": n(1, TOKENS + 1, DIM)}
+    sd = {"backbone.position_encoding.encoding": n(1, tokens + 1, DIM)}
     for i in range(DEPTH):
         p = f"backbone.blocks.{i}."
         sd[p + "input_layer_norm.weight"] = 1.0 + n(DIM, s=0.05)
@@ -131,9 +138,9 @@ def _seeded_state_dict(seed, std):
     return sd
 
 
-def seeded_state_dict_shapes():
+def seeded_state_dict_shapes(tokens=TOKENS):
     """Names and shapes of seeded_state_dict() without generating the values (ranks other than 0 receive them by broadcast)."""
-    sd = {"backbone.position_encoding.encoding": torch.empty(1, TOKENS + 1, DIM)}
+    sd = {"backbone.position_encoding.encoding": torch.empty(1, tokens + 1, DIM)}
     for i in range(DEPTH):
         p = f"backbone.blocks.{i}."
         for nm, shape in (("input_layer_norm.weight", (DIM,)), ("input_layer_norm.bias", (DIM,)), ("qkv.weight", (3 * DIM, DIM)),
@@ -236,15 +243,15 @@ class SpatialModel:
     """The ViViT spatial sub-model (models/vivit.py::ViViTSubModel of this package) stepped through a clip the way
     `FactorizedViViT._forward_view` does (vivit.py:146-147)."""
 
-    def __init__(self, sd, cast, k, device, block_class="EventfulBlock"):
+    def __init__(self, sd, cast, k, device, block_class="EventfulBlock", grid=14):
         from eventful_transformer import policies
         from models.vivit import ViViTSubModel
 
         cfg = dict(dim=DIM, heads=HEADS, mlp_ratio=4)
         if cast:
             cfg["matmul_2_cast"] = cast
-        net = ViViTSubModel((14, 14), dict(block_config=cfg, depth=DEPTH, position_encoding_size=(14, 14),
-                                           block_class=block_class))
+        net = ViViTSubModel((grid, grid), dict(block_config=cfg, depth=DEPTH, position_encoding_size=(grid, grid),
+                                               block_class=block_class))
         net.load_state_dict(sd, strict=True)
         self.net = net.eval().to(device)
         self.backbone = self.net.backbone
@@ -276,15 +283,20 @@ class DetModel:
     """ViTDet-B backbone on one video stream: `model.reset()` then `backbone(x)` per frame
     (scripts/time/vitdet_vid.py:27-38)."""
 
-    def __init__(self, sd, cast, policy_factory, grid, device):
+    def __init__(self, sd, cast, policy_factory, grid, device, pool=None):
         from eventful_transformer.backbones import ViTBackbone
 
         cfg = dict(dim=DIM, heads=HEADS, mlp_ratio=4, relative_embedding_size=(64, 64), window_size=(14, 14))
+        overrides = {}
         if cast:
             cfg["matmul_2_cast"] = cast
+            overrides["matmul_2_cast"] = None
+        if pool is not None:      # K / V token pooling in the global blocks only (configs/evaluate/vitdet_vid/_spatial.yml:4-6)
+            cfg["pool_size"] = pool
+            overrides["pool_size"] = None
         bb = ViTBackbone(block_config=cfg, depth=DEPTH, position_encoding_size=(14, 14), input_size=(grid, grid),
                          block_class="EventfulBlock", windowed_class="EventfulTokenwiseBlock",
-                         window_indices=VITDET_WINDOWED, windowed_overrides=(dict(matmul_2_cast=None) if cast else None))
+                         window_indices=VITDET_WINDOWED, windowed_overrides=(overrides or None))
         bb.load_state_dict(sd, strict=True)
         self.net = self.backbone = bb.eval().to(device)
         set_policies(bb, policy_factory)
@@ -325,17 +337,18 @@ def _oracle():
 def vivit_oracle_model(sd, cast, k, kind="EventfulBlock"):
     O = _oracle()
     blocks = []
+    grid = int(round((sd["backbone.position_encoding.encoding"].shape[1] - 1) ** 0.5))   # 14 (197 tokens) or 20 (401)
     for i in range(DEPTH):
         pre = f"backbone.blocks.{i}."
         params = {key[len(pre):]: v for key, v in sd.items() if key.startswith(pre)}
-        blocks.append(O.BlockOracle(kind, params, DIM, HEADS, (14, 14), matmul_2_cast=cast))
-    bb = O.BackboneOracle(blocks, sd["backbone.position_encoding.encoding"], (14, 14), (14, 14), True)
+        blocks.append(O.BlockOracle(kind, params, DIM, HEADS, (grid, grid), matmul_2_cast=cast))
+    bb = O.BackboneOracle(blocks, sd["backbone.position_encoding.encoding"], (grid, grid), (grid, grid), True)
     if k > 0:
         bb.set_policy(lambda: O.TopK(k))
     return O.ViViTSpatialOracle(bb, sd["class_token"], sd["layer_norm.weight"], sd["layer_norm.bias"]), blocks
 
 
-def vitdet_oracle_model(sd, cast, policy, grid):
+def vitdet_oracle_model(sd, cast, policy, grid, pool=None):
     O = _oracle()
     blocks = []
     for i in range(DEPTH):
@@ -346,7 +359,7 @@ def vitdet_oracle_model(sd, cast, policy, grid):
                                         relative_embedding_size=(64, 64)))
         else:
             blocks.append(O.BlockOracle("EventfulBlock", params, DIM, HEADS, (grid, grid),
-                                        relative_embedding_size=(64, 64), matmul_2_cast=cast))
+                                        relative_embedding_size=(64, 64), matmul_2_cast=cast, pool_size=pool))
     bb = O.BackboneOracle(blocks, sd["position_encoding.encoding"], (14, 14), (grid, grid), False)
     bb.set_policy((lambda: O.TopK(policy[1])) if policy[0] == "topk" else (lambda: O.Threshold(policy[1])))
     return bb, blocks
@@ -415,7 +428,7 @@ def pin_rank_cores(world, local_rank):
 def _cpu_sample(sd, cast, k, frames, model_kind, threads, budget_s):
     """Whole single clips (B=1, T frames, dense first frame included) through the oracle for ~budget_s."""
     torch.set_num_threads(threads)
-    clip = synthetic_clips(1, frames, k, 1234, torch.device("cpu"))
+    clip = synthetic_clips(1, frames, k, 1234, torch.device("cpu"), tokens=sd["backbone.position_encoding.encoding"].shape[1] - 1)
     model, _ = vivit_oracle_model(sd, cast if model_kind != "Block" else None, k if model_kind != "Block" else 0, model_kind)
 
     def run():
@@ -429,7 +442,7 @@ def _cpu_sample(sd, cast, k, frames, model_kind, threads, budget_s):
 
 def cpu_worker(args):
     """`bench.py --cpu-worker`: one 8-thread oracle process of the all-cores CPU sample (never touches the GPU)."""
-    kind, block_class, frames, k, cast, _ = WORKLOADS[args.workload]
+    kind, block_class, frames, k, cast = WORKLOADS[args.workload][:5]
     frames = args.frames if args.frames is not None else frames
     k = args.k if args.k is not None else k
     n, el = _cpu_sample(seeded_state_dict(), cast, k, frames, block_class, args.cpu_threads, args.cpu_budget)
@@ -479,12 +492,12 @@ def cpu_baseline_vivit(sd, cast, k, frames, workload, kind="EventfulBlock", budg
     return out
 
 
-def cpu_baseline_vitdet(sd, cast, policy, grid, stream_cpu):
+def cpu_baseline_vitdet(sd, cast, policy, grid, stream_cpu, pool=None):
     """One first frame + the incremental frames of `stream_cpu` (bounded) through the oracle, 8 threads."""
     cores = usable_cores()
     t8 = min(8, cores)
     torch.set_num_threads(t8)
-    bb, _ = vitdet_oracle_model(sd, cast, policy, grid)
+    bb, _ = vitdet_oracle_model(sd, cast, policy, grid, pool)
     times = []
     with torch.inference_mode():
         for t in range(stream_cpu.shape[0]):
@@ -811,7 +824,9 @@ def log(msg):
 def build_workload(name, device, world, rank, clips=256, total_clips=None, frames=None, k=None, cast_arg=None, threshold=1.0,
                    streams=1, qk_std=None, overlap=1):
     """Model + resident synthetic data of one workload on this rank -> dict (model, data, sd, policy, ...)."""
-    kind, block_class, wl_frames, wl_k, cast, grid = WORKLOADS[name]
+    kind, block_class, wl_frames, wl_k, cast, grid = WORKLOADS[name][:6]
+    extra = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else {}
+    pool = extra.get("pool")
     frames = frames if frames is not None else wl_frames
     k = k if k is not None else wl_k
     if cast_arg is not None:
@@ -830,27 +845,28 @@ def build_workload(name, device, world, rank, clips=256, total_clips=None, frame
     # weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective); the other ranks only
     # allocate the same shapes
     if kind == "vivit":
-        sd = seeded_state_dict(qk_std=qk_std) if rank == 0 else {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes().items()}
+        sd = (seeded_state_dict(qk_std=qk_std, tokens=grid * grid) if rank == 0 else
+              {k_: torch.zeros_like(v) for k_, v in seeded_state_dict_shapes(grid * grid).items()})
     else:
         sd = vitdet_state_dict() if rank == 0 else {k_: torch.zeros_like(v) for k_, v in vitdet_state_dict_shapes().items()}
     if world > 1:
         broadcast_weights(sd, {}, device, rank)
     lanes = None
     if kind == "vivit":
-        model = SpatialModel(sd, cast, k, device, block_class=block_class)
-        data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device) for b in my_batches]
+        model = SpatialModel(sd, cast, k, device, block_class=block_class, grid=grid)
+        data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device, tokens=grid * grid) for b in my_batches]
         policy = ("topk", k)
         if overlap > 1:
             # `overlap` resident batches in flight: one model replica (own per-clip state; weights are copies of the same
             # values), one HIP stream and one scratch lane each.  The batches of a step are independent (utils/evaluate.py:29-32).
             lanes = [(model, torch.cuda.Stream(device=device))]
             for _ in range(overlap - 1):
-                lanes.append((SpatialModel(sd, cast, k, device, block_class=block_class), torch.cuda.Stream(device=device)))
+                lanes.append((SpatialModel(sd, cast, k, device, block_class=block_class, grid=grid), torch.cuda.Stream(device=device)))
     else:
         from eventful_transformer import policies
-        if name == "vitdet672":
+        if k > 0:
             policy = ("topk", k)
-            model = DetModel(sd, cast, lambda: policies.TokenNormTopK(k=k), grid, device)
+            model = DetModel(sd, cast, lambda: policies.TokenNormTopK(k=k), grid, device, pool=pool)
             data = [synthetic_clips(len(b), frames, k, 1000 + b[0], device, tokens=grid * grid) for b in my_batches]
         else:
             assert streams == 1, "the threshold policy is batch-1 (policies.py:25)"
@@ -858,7 +874,7 @@ def build_workload(name, device, world, rank, clips=256, total_clips=None, frame
             model = DetModel(sd, cast, lambda: policies.TokenNormThreshold(threshold=threshold), grid, device)
             data = [threshold_stream(frames, 1000 + b[0], device, grid * grid) for b in my_batches]
     return dict(name=name, kind=kind, block_class=block_class, frames=frames, k=k, cast=cast, grid=grid, resident=resident,
-                total=total, scaling=scaling, batches=my_batches, sd=sd, model=model, data=data, policy=policy, lanes=lanes)
+                total=total, scaling=scaling, batches=my_batches, sd=sd, model=model, data=data, policy=policy, lanes=lanes, pool=pool)
 
 
 def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False):
@@ -1017,7 +1033,7 @@ def other_workload_leg(name, device, budget_s=12.0, cpu=True, **kw):
                 n8, el8 = _cpu_sample(w["sd"], w["cast"], w["k"], w["frames"], w["block_class"], min(8, usable_cores()), budget_s * 0.4)
                 leg["cpu_frames_s"] = round(n8 * w["frames"] / el8, 3)
             else:
-                leg["cpu_frames_s"] = cpu_baseline_vitdet(w["sd"], w["cast"], w["policy"], w["grid"], w["data"][0][:2, :1].cpu())["value"]
+                leg["cpu_frames_s"] = cpu_baseline_vitdet(w["sd"], w["cast"], w["policy"], w["grid"], w["data"][0][:2, :1].cpu(), w.get("pool"))["value"]
         leg["leg_seconds"] = round(time.perf_counter() - t_start, 1)
         return leg
     finally:
@@ -1176,7 +1192,7 @@ def self_check_vitdet(w, frames=3):
     finally:
         evt_blocks.INDEX_TAP = None
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    bb, oblocks = vitdet_oracle_model(w["sd"], w["cast"], w["policy"], w["grid"])
+    bb, oblocks = vitdet_oracle_model(w["sd"], w["cast"], w["policy"], w["grid"], w.get("pool"))
     topk = w["policy"][0] == "topk"
     gates = ("qkv_gate", "projection_gate", "mlp_gate")
     for ob in oblocks:
@@ -1498,7 +1514,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_vivit(sd, cast, k, frames, args.workload, kind=block_class)
             else:
                 n_cpu = 3 if grid <= 42 else 2
-                line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu, :1].cpu())
+                line["cpu_baseline"] = cpu_baseline_vitdet(sd, cast, policy, grid, data[0][:n_cpu, :1].cpu(), w.get("pool"))
         if not args.no_other and args.workload == "vivit16" and not args.graphs:
             release_workload(w)
             legs = {}
@@ -1507,7 +1523,13 @@ def main():
                              ("vivit32", dict(clips=128, total_clips=128, steps=2)),
                              ("vitdet672", dict(steps=5, graphs=True)),
                              ("vitdet672_S8", dict(workload="vitdet672", streams=8, steps=3)),
-                             ("vitdet1024", dict(steps=3, graphs=True))):
+                             ("vitdet1024", dict(steps=3, graphs=True)),
+                             # the reference's own GPU timing / evaluation settings at full size (float16 cast)
+                             ("vivit16_fp16", dict(clips=64, total_clips=64, steps=2)),
+                             ("vivit401_fp16", dict(clips=32, total_clips=32, steps=2)),
+                             ("vitdet672_fp16", dict(steps=5, graphs=True)),
+                             ("vitdet1024_k512", dict(steps=3, graphs=True)),
+                             ("vitdet672_pool2", dict(steps=3, graphs=True))):
                 wl_name = kw.pop("workload", name)
                 try:
                     legs[name] = other_workload_leg(wl_name, device, cpu=not args.no_cpu_baseline, **kw)
