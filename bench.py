@@ -1023,7 +1023,7 @@ def other_workload_leg(name, device, budget_s=12.0, cpu=True, **kw):
         if w["kind"] == "vitdet":
             # per-frame latency protocol of scripts/time/vitdet_vid.py:28-55 (synchronised per frame), first / non-first
             leg.update(vitdet_latency(w))
-            leg["check"] = self_check_vitdet(w)
+            leg["check"] = self_check_vitdet(w, frames=2 if w["grid"] * w["grid"] * max(w["k"], 1) > 4096 * 256 else 3)   # (1024^2 top-k 512: the CPU oracle needs ~25 s per frame)
         else:
             if graphs and w["resident"] == 1 and w["k"] > 0:
                 leg.update(vivit_pipelined(w))
