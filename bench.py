@@ -766,10 +766,21 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
 
 
 def gpu_clock_mhz():
-    """Current shader clock of GPU 0 from rocm-smi (None when the tool or the reading is unavailable): read right before and right
-    behind the timed region so that a box that clocks lower shows up in the line (run-to-run spread across boxes is +-3 %)."""
+    """Current shader clock of GPU 0 (None when no reading is available): sysfs first (`pp_dpm_sclk`, the level marked `*`: a file
+    read, no child process), rocm-smi otherwise -- but never under a profiler: its preloaded library initialises the GPU in every
+    child, and a child that then execs (rocm-smi is a `#!/usr/bin/env python3` script) is refused on this pool."""
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(path).read().splitlines():
+                if ln.strip().endswith("*"):
+                    m = re.search(r"(\d+)\s*mhz", ln.lower())
+                    if m:
+                        return int(m.group(1))
+        except Exception:
+            pass
+    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     import shutil
-    import subprocess
     tool = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     try:
         out = subprocess.run([tool, "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
@@ -809,7 +820,7 @@ class ClockSampler:
         if not self.samples:
             return None
         v = sorted(self.samples)
-        return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "rocm-smi --showclocks (sclk) during the timed region"}
+        return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "shader clock (sysfs pp_dpm_sclk, else rocm-smi) sampled during warm-up + timed region"}
 
 
 _T0 = time.perf_counter()

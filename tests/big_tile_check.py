@@ -15,6 +15,10 @@ CASES = [  # B, N, K, Nout, k, act
     (2, 70, 64, 192, 64, 0),        # two k-tiles (the minimum), one row tile
     (64, 197, 768, 2304, 128, 0),   # M = 8192: 288 ... 576 tiles, several per persistent workgroup
     (40, 197, 256, 768, 131, 1),    # M = 5240: ragged last row tile, every workgroup crosses tile boundaries
+    (1, 50, 64, 64, 20, 0),         # one ragged tile, fewer columns than the narrowest tile, two k-tiles
+    (5, 197, 3072, 768, 128, 0),    # the MLP-2 shape at a small batch: 96 k-tiles per tile
+    (130, 197, 96, 1536, 128, 1),   # M = 16640: 520 .. 780 tiles -> two or three tiles per persistent workgroup, three k-tiles each,
+                                    # ragged last row tile: the tile descriptions prepared two tiles ahead are all in use
 ]
 
 
