@@ -774,7 +774,7 @@ def gpu_clock_mhz():
             for ln in open(path).read().splitlines():
                 if ln.strip().endswith("*"):
                     m = re.search(r"(\d+)\s*mhz", ln.lower())
-                    if m:
+                    if m and int(m.group(1)) >= 500:   # (some boxes list a 95 MHz level as current whatever the load: not a reading)
                         return int(m.group(1))
         except Exception:
             pass

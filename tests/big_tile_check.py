@@ -56,7 +56,10 @@ def main():
         buf2 = buf0.to(DEV)
         count = torch.full((B,), k, dtype=torch.int32, device=DEV)
         n.gated_linear(Ad, K, idxd, N, Wd, bd, buf2, Nout, idxd, N, count, None, B, k, K, Nout, act, W_split=Ws)
-        assert torch.equal(buf2.cpu(), outs[0]), "256-row tiles and 128x128 tiles differ"
+        if n.load().evt_gated_linear_workspace_bytes(B, k, K, Nout, 1) == 0:
+            assert torch.equal(buf2.cpu(), outs[0]), "256-row tiles and 128x128 tiles differ"
+        else:   # few tiles: the 128x128 kernel runs split-K (partial sums over K slices, another summation order)
+            assert torch.allclose(buf2.cpu(), outs[0], atol=2e-5, rtol=2e-5), float((buf2.cpu() - outs[0]).abs().max())
         # dense mode (first frame of a clip)
         out = torch.empty(B * N, Nout, device=DEV)
         n.gated_linear(Ad, K, None, B * N, Wd, bd, out, Nout, None, B * N, None, None, 1, B * N, K, Nout, act, W_split=Ws)
