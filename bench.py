@@ -765,11 +765,14 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
     return None, None, {}
 
 
+_CLOCK_SOURCE = {"sysfs": None}   # sysfs path that gave a plausible reading (False: none does)
+
+
 def gpu_clock_mhz():
     """Current shader clock of GPU 0 (None when no reading is available): sysfs first (`pp_dpm_sclk`, the level marked `*`: a file
     read, no child process), rocm-smi otherwise -- but never under a profiler: its preloaded library initialises the GPU in every
     child, and a child that then execs (rocm-smi is a `#!/usr/bin/env python3` script) is refused on this pool."""
-    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    def read(path):
         try:
             for ln in open(path).read().splitlines():
                 if ln.strip().endswith("*"):
@@ -778,6 +781,15 @@ def gpu_clock_mhz():
                         return int(m.group(1))
         except Exception:
             pass
+        return None
+
+    if _CLOCK_SOURCE["sysfs"] is None:
+        _CLOCK_SOURCE["sysfs"] = False
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]:
+            if read(path) is not None:
+                _CLOCK_SOURCE["sysfs"] = path
+    if _CLOCK_SOURCE["sysfs"]:
+        return read(_CLOCK_SOURCE["sysfs"])
     if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None
     import shutil
@@ -796,7 +808,7 @@ def gpu_clock_mhz():
 
 
 class ClockSampler:
-    """Samples the shader clock (rocm-smi) from a host thread while the timed region runs: rank 0 only, a reading every ~0.7 s."""
+    """Samples the shader clock (rocm-smi) from a host thread while the timed region runs: rank 0 only, a reading every ~2 s."""
 
     def __init__(self):
         self.samples, self._stop, self._thread = [], threading.Event(), None
@@ -807,7 +819,7 @@ class ClockSampler:
                 v = gpu_clock_mhz()
                 if v is not None:
                     self.samples.append(v)
-                self._stop.wait(0.7)
+                self._stop.wait(2.0)
         self._thread = threading.Thread(target=run, daemon=True)
         self._thread.start()
         return self
