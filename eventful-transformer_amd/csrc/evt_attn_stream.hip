@@ -48,6 +48,9 @@ struct StreamArgs {
   int B, H, N, D, kcap, gh, gw;
   float scale;
   int k_split_ready;   // the key plane has been written by evt_stream_prep: no pre-kernel
+  // Keys (and values): Nk rows of `ksrc`, row stride k_rs floats, key channels at k_off.  Un-pooled: the packed token buffer
+  // (Nk = N, k_rs = 3 D, k_off = D); pooled (blocks.py:303-326): the (B,Nk,2D) buffer of evt_pool_kv (k_rs = 2 D, k_off = 0).
+  const float* ksrc; int Nk, k_rs, k_off;
 };
 
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
@@ -158,9 +161,9 @@ __device__ __forceinline__ void sweep_split_f32(const float* a, int a_step, cons
 // (one thread per 8 channels with two scattered 16-byte stores each: 11.2 us at 1024^2; one workgroup for all 12 heads of a
 // block: 111 workgroups at 672^2, 7.5 us).
 constexpr int SKH = 4;   // heads per workgroup
-__global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D, int NKB, int gw) {
+__global__ __launch_bounds__(256) void split_keys_kernel(const float* __restrict__ ksrc, int64_t k_rs, int k_off, uint4* __restrict__ out, int B, int H, int Nk, int NKB, int gw) {
   __shared__ __attribute__((aligned(16))) uint4 tile[SKH * 256];   // [head][256]: a head's 4 KB block in its final order
-  evt_split_keys_role(qkv, out, B, H, N, D, NKB, gw, (int)blockIdx.x, (int)blockIdx.y, tile);   // evt_prep_roles.h
+  evt_split_keys_role(ksrc, k_rs, k_off, out, B, H, Nk, NKB, gw, (int)blockIdx.x, (int)blockIdx.y, tile);   // evt_prep_roles.h
 }
 
 // Rel-pos terms of a tile's rows in LDS, per row: [0, gh) row terms ty, -inf up to TYP = (gh + 4) & ~3 (slot gh is what
@@ -215,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   const int l15 = lane & 15, kg = lane >> 4;
   const int64_t rs = 3 * (int64_t)a.D;
   const float* clip = a.qkv + (int64_t)b * a.N * rs;
-  T* stT = reinterpret_cast<T*>(a.a_state_t) + (int64_t)bh * a.N * a.N;   // [key j][row i]
+  const float* kclip = a.ksrc + (int64_t)b * a.Nk * a.k_rs + a.k_off;
+  T* stT = reinterpret_cast<T*>(a.a_state_t) + (int64_t)bh * a.Nk * a.N;   // [key j][row i]
 
   // channel of float4 piece p (0..3) of this lane (see evt_attn_fused.hip): QK == 1, 16x16x4 fp32 tiles with k
   // permuted, 16 contiguous channels 16 kg + 4 p; QK == 2, 16x16x32 bf16 tiles, k-block p >> 1 holds 32 (p >> 1) + 8 kg .. + 8
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   }
   // Key fragments -> 4 pieces.  QK == 1: fp32 channels of key row j from the token buffer.  QK == 2: pieces 2m, 2m + 1 = hi,
   // lo of k-block m from the fragment-major plane (split_keys_kernel).
-  const int NKB = evt_key_blocks(a.N, a.gh, a.gw);
+  const int NKB = evt_key_blocks(a.Nk, a.gh, a.gw);
   const uint4* ksp = reinterpret_cast<const uint4*>(a.k_split) + (int64_t)bh * NKB * 256;
   auto load_kf = [&](int j, float4* kf) __attribute__((always_inline)) {   // key row j (caller clamps): a gather
     if (QK == 2) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
     } else {
-      const float* kp = clip + (int64_t)j * rs + a.D + h * SDH;
+      const float* kp = kclip + (int64_t)j * a.k_rs + h * SDH;
 #pragma unroll
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kp + chan(p_));
     }
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       for (int p_ = 0; p_ < 4; ++p_) kf[p_] = __builtin_bit_cast(float4, kp[64 * p_]);
     } else {
       const int j = c0 + wave * 16 + l15;
-      load_kf(j < a.N ? j : a.N - 1, kf);
+      load_kf(j < a.Nk ? j : a.Nk - 1, kf);
     }
   };
   float4 kA[4], kB[4];
@@ -472,13 +476,13 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
 #pragma unroll
     for (int hr = 0; hr < NHR; ++hr)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[hr][r] = (!mask || jb + r < a.N) ? sacc[hr][r] : -INFINITY;
+      for (int r = 0; r < 4; ++r) x[hr][r] = (!mask || jb + r < a.Nk) ? sacc[hr][r] : -INFINITY;
     update(x);
   };
   // two fragment register sets used alternately, every load unconditional (clamped key): the waits can then count on the
   // younger requests being in flight (a copy kf = kn at the loop's back edge makes hipcc wait for the prefetch just issued)
   {
-    const int NS = (QK == 2 && rel) ? NKB * 16 : a.N;   // slots to stream (the key plane's, with a rel-pos grid)
+    const int NS = (QK == 2 && rel) ? NKB * 16 : a.Nk;  // slots to stream (the key plane's, with a rel-pos grid)
     int c0 = 0;
     for (; c0 + 128 <= NS; c0 += 128) {   // whole chunk pairs: no masks
       stats(c0, kA, false);
@@ -659,9 +663,9 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
   };
 
   if (FIRST) {
-    const T* vst = reinterpret_cast<const T*>(a.v_state) + (int64_t)b * a.N * a.D + h * SDH;
+    const T* vst = reinterpret_cast<const T*>(a.v_state) + (int64_t)b * a.Nk * a.D + h * SDH;
     // keys in index order here (the state columns and value rows are): key c0 + 16 wave + l15, gathered from the plane
-    auto load_keys = [&](int c0, float4* kf) __attribute__((always_inline)) { const int j = c0 + wave * 16 + l15; load_kf(j < a.N ? j : a.N - 1, kf); };
+    auto load_keys = [&](int c0, float4* kf) __attribute__((always_inline)) { const int j = c0 + wave * 16 + l15; load_kf(j < a.Nk ? j : a.Nk - 1, kf); };
     load_keys(0, kA);
     load_keys(64, kB);
     auto first_chunk = [&](int c0, const float4* kf) __attribute__((always_inline)) {
@@ -670,19 +674,19 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       union { uint4 u[(16 * sizeof(T)) / 16]; T t[16]; } vv;
 #pragma unroll
       for (int q = 0; q < (int)((16 * sizeof(T)) / 16); ++q)
-        vv.u[q] = reinterpret_cast<const uint4*>(vst + (int64_t)(vj < a.N ? vj : a.N - 1) * a.D + vc0)[q];
+        vv.u[q] = reinterpret_cast<const uint4*>(vst + (int64_t)(vj < a.Nk ? vj : a.Nk - 1) * a.D + vc0)[q];
       f32x4_acc sacc[NHR];
       const int jb = c0 + wave * 16 + 4 * kg;
       int js[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) js[r] = jb + r < a.N ? jb + r : a.N - 1;
+      for (int r = 0; r < 4; ++r) js[r] = jb + r < a.Nk ? jb + r : a.Nk - 1;
       scores_rel(kf, sacc, js);
 #pragma unroll
       for (int hr = 0; hr < NHR; ++hr) {
         QuadT nw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = rok[hr] && jb + r < a.N;
+          const bool ok = rok[hr] && jb + r < a.Nk;
           const float an = Store<T>::round(fast_exp(sacc[hr][r] - fm[hr]) * fi[hr]);
           Store<T>::store(&nw.t[r], ok ? an : 0.f);
           if (ok) Store<T>::store(stT + (int64_t)(jb + r) * a.N + i0 + 16 * hr + l15, an);
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
       T z;
       Store<T>::store(&z, 0.f);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) Vd[(vc0 + q) * P + vkey] = vj < a.N ? vv.t[q] : z;
+      for (int q = 0; q < 16; ++q) Vd[(vc0 + q) * P + vkey] = vj < a.Nk ? vv.t[q] : z;
       __syncthreads();
       // keys 0..31 of the chunk on waves 0, 1, keys 32..63 on waves 2, 3 (summed unrounded in the epilogue)
       if constexpr (SWEEP_SPLIT) {
@@ -712,10 +716,10 @@ __global__ __launch_bounds__(256, 2) void attn_stream_kernel(const StreamArgs a,
         }
       __syncthreads();
     };
-    for (int c0 = 0; c0 < a.N; c0 += 128) {
+    for (int c0 = 0; c0 < a.Nk; c0 += 128) {
       first_chunk(c0, kA);
       load_keys(c0 + 128, kA);
-      if (c0 + 64 < a.N) first_chunk(c0 + 64, kB);
+      if (c0 + 64 < a.Nk) first_chunk(c0 + 64, kB);
       load_keys(c0 + 192, kB);
     }
     STR_TICK(3);   // pass B (first frame: all keys)
@@ -937,9 +941,9 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
   const int tiles_x = (a.N + FRT - 1) / FRT, total = tiles_x * a.B * a.H;
   EVT_ALLOW_LDS((attn_stream_kernel<T, FIRST, QK, NHR>), lds);
   if (QK == 2 && !a.k_split_ready) {
-    const int nkb = evt_key_blocks(a.N, a.gh, a.gw);
-    hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb), (unsigned)((a.H + SKH - 1) / SKH)), dim3(256), 0, s, a.qkv,
-                       reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.N, a.D, nkb, a.gw);
+    const int nkb = evt_key_blocks(a.Nk, a.gh, a.gw);
+    hipLaunchKernelGGL(split_keys_kernel, dim3((unsigned)(a.B * nkb), (unsigned)((a.H + SKH - 1) / SKH)), dim3(256), 0, s, a.ksrc,
+                       (int64_t)a.k_rs, a.k_off, reinterpret_cast<uint4*>(a.k_split), a.B, a.H, a.Nk, nkb, a.gw);
   }
   hipLaunchKernelGGL((attn_stream_kernel<T, FIRST, QK, NHR>), dim3(total), dim3(256), lds, s, a, tiles_x, total);
 }
@@ -998,8 +1002,11 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
               "evt_attention_stream: head dim 64 required (B=%d H=%d N=%d D=%d)", d->B, d->H, d->N, d->D);
   EVT_REQUIRE(d->scale > 0.f, EVT_ERR_BAD_ARG, "evt_attention_stream: scale must be positive");
   EVT_REQUIRE(d->N <= 32767, EVT_ERR_BAD_SHAPE, "evt_attention_stream: N=%d (32-bit byte offsets into a head's N x N reference: N <= 32767)", d->N);
-  EVT_REQUIRE(d->rel_terms == nullptr || (d->gh > 0 && d->gw > 0 && d->gh * d->gw == d->N), EVT_ERR_BAD_SHAPE,
-              "evt_attention_stream: rel-pos key grid %dx%d does not match N=%d", d->gh, d->gw, d->N);
+  EVT_REQUIRE((d->kv == nullptr) == (d->Nk == 0), EVT_ERR_BAD_ARG, "evt_attention_stream: kv and Nk come together (pooled keys), or neither");
+  EVT_REQUIRE(d->Nk >= 0 && d->Nk <= d->N, EVT_ERR_BAD_SHAPE, "evt_attention_stream: Nk=%d pooled keys of N=%d tokens", d->Nk, d->N);
+  const int Nk = d->kv ? d->Nk : d->N;
+  EVT_REQUIRE(d->rel_terms == nullptr || (d->gh > 0 && d->gw > 0 && d->gh * d->gw == Nk), EVT_ERR_BAD_SHAPE,
+              "evt_attention_stream: rel-pos key grid %dx%d does not match the %d keys", d->gh, d->gw, Nk);
   EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_attention_stream: norm_ref / norm_parts come together");
   if (d->first) {
     EVT_REQUIRE(d->v_state != nullptr, EVT_ERR_BAD_ARG, "evt_attention_stream: first frame needs v_state");
@@ -1020,7 +1027,9 @@ extern "C" int evt_attention_stream(const evt_attn_stream_desc* d, void* stream)
                 "evt_softmax_av_gated for this shape", d->gh, d->gw, (long long)need, EVT_LDS_PER_CU);
   }
   StreamArgs a{d->qkv, d->rel_terms, d->a_state_t, d->idx, d->count, d->v_delta_t, d->v_old_t, d->v_state, d->pv, d->out_f32,
-               d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale, d->k_split_ready};
+               d->norm_ref, d->norm_parts, d->k_split, d->B, d->H, d->N, d->D, d->kcap, rel ? d->gh : 0, rel ? d->gw : 0, d->scale, d->k_split_ready,
+               d->kv ? d->kv : d->qkv, Nk, d->kv ? 2 * d->D : 3 * d->D, d->kv ? 0 : d->D};
+
   hipStream_t s = evt_stream(stream);
   EVT_DISPATCH_STORE(d->store, T, {
     if (d->first) launch_stream<T, true>(a, d->qk_split, s);

@@ -90,7 +90,9 @@ __device__ __forceinline__ void evt_rel_terms_mfma_role(const float* __restrict_
 __host__ __device__ inline int evt_key_blocks(int N, int gh, int gw) { return gw > 0 ? gh * ((gw + 15) >> 4) : (N + 15) >> 4; }
 
 // block (bx, by) of a (B NKB) x ceil(H / 4) grid, NKB = evt_key_blocks(N, gh, gw); `tile`: EVT_KEY_PLANE_LDS bytes
-__device__ __forceinline__ void evt_split_keys_role(const float* __restrict__ qkv, uint4* __restrict__ out, int B, int H, int N, int D,
+// Key rows: N rows per clip of `ksrc`, row stride k_rs floats, key channels at k_off (the packed token buffer: 3 D, D; the pooled
+// (B,Nk,2D) buffer of evt_pool_kv: 2 D, 0).
+__device__ __forceinline__ void evt_split_keys_role(const float* __restrict__ ksrc, int64_t k_rs, int k_off, uint4* __restrict__ out, int B, int H, int N,
                                                     int NKB, int gw, int bx, int by, uint4* tile) {
   constexpr int SKH = EVT_SKH, SDH = 64;
   const int b = bx / NKB, kb = bx - b * NKB;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void evt_split_keys_role(const float* __restrict__ qk
     const int key = gw > 0 ? ky * gw + kx0 + i : kb * 16 + i;
     bf16x8_t hi = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
     if (key < N && (gw == 0 || kx0 + i < gw)) {
-      const float* src = qkv + ((int64_t)b * N + key) * 3 * (int64_t)D + D + (h0 + hh) * SDH + c8 * 8;
+      const float* src = ksrc + ((int64_t)b * N + key) * k_rs + k_off + (h0 + hh) * SDH + c8 * 8;
       const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
       bf16x4_t hx, lx, hy, ly;
       split4(x, &hx, &lx);

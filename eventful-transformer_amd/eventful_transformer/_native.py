@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 7   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 8   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_row_pass_ord", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
@@ -116,6 +116,7 @@ class AttnStreamDesc(Structure):
         ("v_state", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("store", c_int32), ("scale", c_float),
         ("qk_split", c_int32), ("first", c_int32), ("k_split", c_void_p), ("k_split_ready", c_int32),
+        ("kv", c_void_p), ("Nk", c_int32),
     ]
 
 
@@ -124,6 +125,7 @@ class StreamPrepDesc(Structure):
         ("qkv", c_void_p), ("rel_y", c_void_p), ("rel_x", c_void_p), ("terms", c_void_p), ("k_split", c_void_p),
         ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32), ("v_state", c_void_p), ("v_delta_t", c_void_p), ("v_old_t", c_void_p),
         ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("gh", c_int32), ("gw", c_int32), ("qw", c_int32), ("store", c_int32),
+        ("kv", c_void_p), ("Nk", c_int32),
     ]
 
 
@@ -622,24 +624,28 @@ def stream_prep_fits(D, H, kcap, has_rel):
     return STREAM_PREP and QK_SPLIT and has_rel and D == 64 * H and kcap > 0 and kcap % 8 == 0
 
 
-def stream_prep(qkv, rel_y, rel_x, terms, idx, count, kcap, v_state, v_delta_t, v_old_t, B, H, N, D, gh, gw, qw, store):
+def stream_prep(qkv, rel_y, rel_x, terms, idx, count, kcap, v_state, v_delta_t, v_old_t, B, H, N, D, gh, gw, qw, store, kv=None, Nk=None):
     """rel-pos terms + key plane + transposed value gate of a gated frame in one launch; attention_stream(..., k_split_ready=True)
-    then skips its key-plane pre-kernel."""
-    d = StreamPrepDesc(_p(qkv), _p(rel_y), _p(rel_x), _p(terms), _p(k_split_plane(qkv, B, H, N, gh, gw)), _p(idx), _p(count), kcap, _p(v_state),
-                       _p(v_delta_t), _p(v_old_t), B, H, N, D, gh, gw, qw, store)
+    then skips its key-plane pre-kernel.  kv, Nk: pooled keys / values (idx / count / kcap / v_state are then the pooled ones)."""
+    nk = N if kv is None else int(Nk)
+    d = StreamPrepDesc(_p(qkv), _p(rel_y), _p(rel_x), _p(terms), _p(k_split_plane(qkv, B, H, nk, gh, gw)), _p(idx), _p(count), kcap, _p(v_state),
+                       _p(v_delta_t), _p(v_old_t), B, H, N, D, gh, gw, qw, store, _p(kv), 0 if kv is None else nk)
     _check(load().evt_stream_prep(ctypes.byref(d), _stream()))
 
 
 def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_terms=None, gh=0, gw=0, idx=None, count=None,
                      kcap=0, v_delta_t=None, v_old_t=None, v_state=None, out_f32=None, norm_ref=None, norm_parts=None,
-                     qk_split=None, k_split_ready=False):
-    """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N)."""
+                     qk_split=None, k_split_ready=False, kv=None, Nk=None):
+    """K5+K6 / first frame for N > 256 with in-kernel scores; a_state_t is the TRANSPOSED gate reference (B,H,Nk,N).
+    kv, Nk: pooled keys / values (the (B,Nk,2D) buffer of pool_kv); idx / count / kcap, v_state, v_delta_t / v_old_t are then the
+    pooled ones and gh x gw == Nk."""
     split = int(QK_SPLIT if qk_split is None else qk_split)
+    nk = N if kv is None else int(Nk)
     # split arithmetic: the frame's key rows as bf16 hi / lo fragments, written by the call's pre-kernel (4 KB per 16 keys and head)
-    ksp = k_split_plane(qkv, B, H, N, *((gh, gw) if rel_terms is not None else (0, 0))) if split else None
+    ksp = k_split_plane(qkv, B, H, nk, *((gh, gw) if rel_terms is not None else (0, 0))) if split else None
     d = AttnStreamDesc(_p(qkv), _p(rel_terms), gh, gw, _p(a_state_t), _p(idx), _p(count), kcap, _p(v_delta_t), _p(v_old_t),
                        _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts), B, H, N, D, store, float(scale),
-                       split, int(first), _p(ksp), int(bool(k_split_ready) and bool(split)))
+                       split, int(first), _p(ksp), int(bool(k_split_ready) and bool(split)), _p(kv), 0 if kv is None else nk)
     # algorithmic bytes: q, k read once per clip (8ND), rel terms, gate-reference columns read + rewritten (first frame:
     # written whole), v pieces, A.v state read-modify-write (first frame: v state read, state written), fp32 output
     # The gated form is priced by the LIVE selected-key count (threshold policy: `count` on the device, capacity N), never by kcap.
@@ -647,10 +653,10 @@ def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_te
     rel_b = 4.0 * H * N * (gh + gw) if rel_terms is not None else 0.0
     call = lambda: _check(load().evt_attention_stream(ctypes.byref(d), _stream()))   # noqa: E731
     if first:
-        _timed("attn", B * (8.0 * N * D + rel_b + 1.0 * es * H * N * N + 2.0 * es * N * D + 4.0 * N * D), call)
+        _timed("attn", B * (4.0 * (N + nk) * D + rel_b + 1.0 * es * H * N * nk + es * (N + nk) * D + 4.0 * N * D), call)
     else:
         per_row = 2.0 * es * H * N + 2.0 * es * D
-        fixed = B * (8.0 * N * D + rel_b + 2.0 * es * N * D + (4.0 * N * D if out_f32 is not None else 0.0))
+        fixed = B * (4.0 * (N + nk) * D + rel_b + 2.0 * es * N * D + (4.0 * N * D if out_f32 is not None else 0.0))
         _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0), call, count=count, per_row=per_row)
 
 

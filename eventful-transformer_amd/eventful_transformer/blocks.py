@@ -64,6 +64,7 @@ PROJ_FROM_STATE = os.environ.get("EVT_PROJ_FROM_STATE", "1") != "0"   # bf16 cas
 # epilogue's reference reads and the 12-partial selection cost what the 6 us row pass did); eight streams 6.37 vs 6.41 ms --
 # used from FUSE_DENSE_NORM_ROWS token rows per launch on (EVT_FUSE_DENSE_NORM_ROWS=0: always).
 FUSE_DENSE_NORM_ROWS = int(os.environ.get("EVT_FUSE_DENSE_NORM_ROWS", "8192"))
+STREAM_POOLED = os.environ.get("EVT_STREAM_POOLED", "1") != "0"   # pool_size blocks with > 256 tokens on evt_attention_stream (0: K4 + K5+K6 chain)
 REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
 # Diagnostic tap: a callable (block, gate tag, idx (B,cap) int32, count or None) invoked after every fused gate selection
 # with the DEVICE index list (scratch memory: clone to keep).  bench.py's self-check records the timed run's index sets
@@ -740,9 +741,10 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
 
         def refresh():
             buf = owner.b
-            if acc._product is None or acc._product.shape != (B, H, N, N):
-                acc._product = torch.empty((B, H, N, N), dtype=torch.float32, device=buf.device)
-            _native.qk_packed(buf, B, N, D, H, scale, acc._product)
+            kv, Nk = self._pool_kv(buf, B, N)   # (None, N) without pool_size
+            if acc._product is None or acc._product.shape != (B, H, N, Nk):
+                acc._product = torch.empty((B, H, N, Nk), dtype=torch.float32, device=buf.device)
+            _native.qk_packed(buf, B, N, D, H, scale, acc._product, kv=kv, Nk=Nk)
         acc.defer(refresh)
 
     def _first_frame_fused(self, qkv, B, N, attn, a_state=None, pv=None):
@@ -816,7 +818,7 @@ class EventfulBlock(EventfulMatmul1Block):
             product = self._scores(qkv, idx, count, cap, B, N)[0]
             self._ats_idx_k = None if idx is None else idx.long()
             return self._ats_attention(product, qkv, B, N, eventful=True) + (None,)
-        if self.pool_size is None:
+        if self.pool_size is None or STREAM_POOLED:
             _, _, gh_, gw_, _ = self._rel_tables()
             if _native.attention_stream_fits(N, D, H, store, gh_, gw_):
                 return self._attention_stream(qkv, idx, count, cap, B, N)
@@ -919,8 +921,10 @@ class EventfulBlock(EventfulMatmul1Block):
     def _attention_stream(self, qkv, idx, count, cap, B, N):
         """More than 256 tokens at head dim 64 (ViTDet global blocks): ONE evt_attention_stream launch per frame computes
         the scores in the kernel from the token buffer -- no q.k^T state, no K4 -- with the matmul_gate reference stored
-        transposed (`matmul_gate.p` is a transposed view of it, same logical (B,H,N,N) tensor as in the reference).
-        `matmul_accumulator_1.product` is refreshed lazily if anybody reads it (MatmulBuffer.defer)."""
+        transposed (`matmul_gate.p` is a transposed view of it, same logical (B,H,N,Nk) tensor as in the reference).
+        `matmul_accumulator_1.product` is refreshed lazily if anybody reads it (MatmulBuffer.defer).
+        With `pool_size` (blocks.py:303-326, 509-511, 525-540) the keys and values are the pooled cells: Nk = N / (p0 p1) rows of
+        the evt_pool_kv buffer, the key-side index list is the gate's list mapped to cells and de-duplicated (evt_pool_index)."""
         D, H = self.dim, self.heads
         dh = D // H
         sdt = self._store_dtype()
@@ -928,37 +932,48 @@ class EventfulBlock(EventfulMatmul1Block):
         vg, ag, acc, acc1 = self.v_gate, self.matmul_gate, self.matmul_accumulator_2, self.matmul_accumulator_1
         attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
         ry, rx, gh, gw, qw = self._rel_tables()
+        kv, Nk = self._pool_kv(qkv, B, N)
+        pooled = dict(kv=kv, Nk=Nk) if kv is not None else {}
+        idx_k, count_k, cap_k = idx, count, cap
+        if kv is not None and idx is not None:
+            cap_k = min(cap, Nk)
+            idx_k = self._ws("idx_k", (B, cap_k), torch.int32, qkv)
+            count_k = self._ws("cnt_k", (B,), torch.int32, qkv)
+            p0, p1 = self.pool_size
+            _native.pool_index(idx, count, B, cap, self.input_size[1], p0, p1, self.input_size[1] // p1, Nk, cap_k, idx_k, count_k)
         terms = None
+        prep = ry is not None and _native.stream_prep_fits(D, H, cap_k, True)
         if ry is not None:   # decomposed rel-pos terms of every query token, once per frame (utils.py:159-168)
             terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
             # (a gated frame computes them together with the key plane and the value gate: evt_stream_prep, below)
-            if acc.first or not _native.stream_prep_fits(D, H, cap, True):
+            if acc.first or not prep:
                 _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
             self.relative_position.count_fused(B, H)
         if acc.first:   # first frame of the clip: gate reference, value state, A.v state and the output in one launch
             vg.first = ag.first = acc.first = acc1.first = False
-            ag._state_t = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)   # [b][h][key][row]
+            ag._state_t = torch.empty((B, H, Nk, N), dtype=sdt, device=qkv.device)   # [b][h][key][row]
             ag.p = ag._state_t.transpose(-1, -2)
-            vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            vg._state = torch.empty((B, Nk, D), dtype=sdt, device=qkv.device)
             acc._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
-            vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            vg.p = vg._state.view(B, Nk, H, dh).permute(0, 2, 1, 3)
             acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
-            self._v_full(qkv, None, B, N, N, vg._state, store)
+            self._v_full(qkv, kv, B, N, Nk, vg._state, store)
             _native.attention_stream(qkv, ag._state_t, acc._state, B, H, N, D, self.scale, store, True, rel_terms=terms,
-                                     gh=gh, gw=gw, v_state=vg._state, out_f32=attn)
+                                     gh=gh, gw=gw, v_state=vg._state, out_f32=attn, **pooled)
             self._defer_scores(B, N)
-            acc1.matmul.count_product(B * H * N * N, dh)
-            acc.matmul.count_product(B * H * N * dh, N)
+            acc1.matmul.count_product(B * H * N * Nk, dh)
+            acc.matmul.count_product(B * H * N * dh, Nk)
             return attn, None, None
-        v_delta = self._ws("v_delta_t", (B, D, cap), sdt, qkv)
-        v_old = self._ws("v_old_t", (B, D, cap), sdt, qkv)
-        prepped = False
-        if terms is not None and _native.stream_prep_fits(D, H, cap, True):
+        v_delta = self._ws("v_delta_t", (B, D, cap_k), sdt, qkv)
+        v_old = self._ws("v_old_t", (B, D, cap_k), sdt, qkv)
+        if prep:
             # rel-pos terms, key plane and value gate depend only on the updated token buffer (and the index list): one launch
-            _native.stream_prep(qkv, ry, rx, terms, idx, count, cap, vg._state, v_delta, v_old, B, H, N, D, gh, gw, qw, store)
-            prepped = True
-        else:
+            _native.stream_prep(qkv, ry, rx, terms, idx_k, count_k, cap_k, vg._state, v_delta, v_old, B, H, N, D, gh, gw, qw, store, **pooled)
+        elif kv is None:
             _native.v_gate(qkv, idx, count, B, N, D, cap, vg._state, v_delta, v_old, store, True, transposed=True)
+        else:
+            _native.v_gate(kv, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True, transposed=True,
+                           v_offset=D, v_rs=2 * D)
         pg = self.projection_gate
         fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
@@ -968,19 +983,21 @@ class EventfulBlock(EventfulMatmul1Block):
             cap_p = pg.policy.capacity(N)
             state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
         _native.attention_stream(qkv, ag._state_t, acc._state, B, H, N, D, self.scale, store, False, rel_terms=terms,
-                                 gh=gh, gw=gw, idx=idx, count=count, kcap=cap, v_delta_t=v_delta, v_old_t=v_old,
+                                 gh=gh, gw=gw, idx=idx_k, count=count_k, kcap=cap_k, v_delta_t=v_delta, v_old_t=v_old,
                                  out_f32=None if state_src else attn, norm_ref=pg.p if fuse_norm else None,
-                                 norm_parts=nparts, k_split_ready=prepped)
+                                 norm_parts=nparts, k_split_ready=prep, **pooled)
         self._defer_scores(B, N)
         if self.count_mode or acc.count_mode or vg.count_mode or acc1.matmul.count_mode:
             n = self._n_rows(B, cap, count)
+            n_k = self._n_rows(B, cap_k, count_k)
             if acc1.matmul.count_mode:   # the reference's delta update of the q.k^T state (modules.py:232-247)
-                acc1.matmul.count_product(2 * H * N * n, dh)
-            self._count_gate(vg, B * N * D)
-            self._count_gate(ag, B * H * N * N)
+                acc1.matmul.count_product(H * Nk * n, dh)
+                acc1.matmul.count_product(H * N * n_k, dh)
+            self._count_gate(vg, B * Nk * D)
+            self._count_gate(ag, B * H * N * Nk)
             if acc.count_mode:
-                acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
-            acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+                acc.counts["accumulator_flops"] += n_k * D + 2 * B * N * D
+            acc.matmul.count_product(2 * B * N * D, n_k // B if B else 0)
         fused = dict(norm_parts=(nparts, H) if fuse_norm else None, state_src=acc._state if state_src else None)
         return attn, None, fused
 

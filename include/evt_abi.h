@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 7   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+#define EVT_ABI_VERSION 8   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
@@ -44,7 +44,9 @@ extern "C" {
                                     evt_stream_prep + evt_attn_stream_desc.k_split_ready (rel-pos terms, key plane and value gate
                                     of a gated frame in one launch); evt_attn_dense_desc.norm_ref / norm_parts +
                                     evt_attention_dense_resident (the projection gate's delta norm from the attention epilogue of
-                                    the windowed blocks) */
+                                    the windowed blocks);
+                                 8: evt_attn_stream_desc.kv / Nk, evt_stream_prep_desc.kv / Nk (pooled keys and values in
+                                    evt_attention_stream and its preparation launch) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -442,6 +444,12 @@ typedef struct evt_attn_stream_desc {
                                              with qk_split: the frame's key rows as bf16 hi / lo MFMA fragments (written by a
                                              pre-kernel of this call) */
   int32_t k_split_ready;                  /* ABI 6: 1 = evt_stream_prep has already written k_split for this frame: no pre-kernel */
+  /* ABI 8: pooled keys / values (`pool_size`, blocks.py:303-326, 509-511).  kv = the (B,Nk,2D) buffer of evt_pool_kv (keys | values
+   * per row), Nk = gh * gw pooled cells: the keys are its rows instead of the packed buffer's, a_state_t is (B,H,Nk,N), v_state
+   * (B,Nk,D), idx / count / kcap the POOLED index list of evt_pool_index (blocks.py:525-540), v_delta_t / v_old_t the value gate of
+   * kv's value half.  rel_terms (B,H,N,gh+gw) are the query tokens' terms against the pooled key grid.  NULL / 0: un-pooled
+   * (Nk = N).  k_split then holds evt_attention_stream_key_blocks(Nk, gh, gw) blocks. */
+  const float* kv; int32_t Nk;
 } evt_attn_stream_desc;
 
 /* Limits: head dim 64 (D == 64 H), N <= 32767 (32-bit byte offsets into a head's N x N reference), the tile's LDS within a CU
@@ -476,6 +484,10 @@ typedef struct evt_stream_prep_desc {
   void* v_delta_t; void* v_old_t;          /* out (B,D,kcap) store type                                                      */
   int32_t B, H, N, D, gh, gw, qw;
   int32_t store;                           /* evt_dtype of v_state / v_delta_t / v_old_t                                     */
+  /* ABI 8: pooled keys / values, as in evt_attn_stream_desc: kv = the (B,Nk,2D) buffer of evt_pool_kv, Nk = gh * gw; the key
+   * plane and the value gate then read kv's rows (v_state (B,Nk,D); idx / count / kcap the pooled list of evt_pool_index), the
+   * rel-pos terms stay those of the N query tokens.  NULL / 0: un-pooled (gh * gw == N). */
+  const float* kv; int32_t Nk;
 } evt_stream_prep_desc;
 
 EVT_API int evt_stream_prep(const evt_stream_prep_desc* d, void* stream);

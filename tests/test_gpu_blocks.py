@@ -736,6 +736,51 @@ def test_pooled_eventful_block_head_dim_64(cast, policy):
                 assert blk.matmul_gate.p.shape == (1, 4, 64, 16) and blk.v_gate.p.shape == (1, 4, 16, 64)
 
 
+@pytest.mark.parametrize("cast,policy,rel", [(None, ("topk", 90), True), ("bfloat16", ("topk", 90), True), (None, ("thr", 0.8), True),
+                                             ("float16", ("topk", 50), False)])
+def test_pooled_eventful_block_on_the_stream_kernel(cast, policy, rel):
+    """Pooled K/V with more than 256 tokens (the 'spatiotemporal' ViTDet variant's global blocks, blocks.py:303-326, 509-511,
+    525-540): ONE evt_attention_stream launch per frame with Nk = N / 4 pooled cells (ABI 8) instead of K4 + K5+K6 with an fp32
+    (B,H,N,Nk) score state.  N = 324 queries x 81 cells, batch 1, 4 frames against the oracle; the other path (EVT_STREAM_POOLED=0)
+    gives the same outputs to rounding."""
+    from eventful_transformer import blocks as blocks_mod
+    dim, heads, grid = 128, 2, (18, 18)
+    kw = dict(pool_size=2)
+    if rel:
+        kw["relative_embedding_size"] = (18, 18)
+    if cast:
+        kw["matmul_2_cast"] = cast
+    params = O.make_block_params(dim, 4, seed=41, std=0.05, rel_sizes=(18, 18) if rel else None, head_dim=64)
+    xs = O.make_token_stream(1, 324, dim, 4, 90, seed=42, small=0.02)
+    ora = O.BlockOracle("EventfulBlock", params, dim, heads, grid, **kw)
+    ora.set_policy(H.oracle_policy(policy))
+    tol = 3e-4 if cast is None else 1e-3
+    outs = {}
+    for pooled_stream in (True, False):
+        old = blocks_mod.STREAM_POOLED
+        blocks_mod.STREAM_POOLED = pooled_stream
+        try:
+            blk = H.product_block("EventfulBlock", params, dim, heads, grid, **kw)
+            H.product_policy(blk, policy)
+            ys = []
+            with torch.inference_mode():
+                for t in range(4):
+                    ys.append(blk(xs[t].to(DEV)).cpu())
+            assert (getattr(blk.matmul_gate, "_state_t", None) is not None) == pooled_stream
+            if pooled_stream:
+                assert blk.matmul_gate._state_t.shape == (1, 2, 81, 324) and blk.matmul_gate.p.shape == (1, 2, 324, 81)
+                assert blk.v_gate.p.shape == (1, 2, 81, 64)
+                assert blk.matmul_accumulator_1.product.shape == (1, 2, 324, 81)   # refreshed lazily from the token buffer
+            outs[pooled_stream] = ys
+        finally:
+            blocks_mod.STREAM_POOLED = old
+    for t in range(4):
+        ref = ora.forward(xs[t].clone())
+        err = float((outs[True][t] - ref).abs().max())
+        assert err <= tol, (cast, policy, t, err)
+        assert float((outs[True][t] - outs[False][t]).abs().max()) <= tol, (cast, policy, t)
+
+
 @pytest.mark.parametrize("policy,kw,windowed,resized", [("TokenNormTopK", dict(k=20), False, False), ("TokenNormThreshold", dict(threshold=0.8), False, False),
                                                         ("TokenNormTopK", dict(k=30), True, False), ("TokenNormTopK", dict(k=20), False, True)])
 def test_frame_graphs_replay_is_bit_identical(policy, kw, windowed, resized):

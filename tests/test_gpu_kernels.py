@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 7
+    assert lib.evt_version() == n.ABI_VERSION == 8
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -860,6 +860,144 @@ def test_stream_prep_matches_the_three_launches(cast, N, gw, k, counted):
     for name, a_, b_ in zip(("terms", "v_delta", "v_old", "v_state", "key plane", "a_state_t", "pv", "out", "norm_parts"), res[0], res[1]):
         assert torch.equal(a_.view(torch.uint8) if a_.dtype == torch.bfloat16 else a_, b_.view(torch.uint8) if b_.dtype == torch.bfloat16 else b_), name
     assert torch.isfinite(res[1][7]).all()
+
+
+@pytest.mark.parametrize("cast,qh,qw,pool,k,counted", [(None, 42, 42, (2, 2), 256, False), ("bfloat16", 64, 64, (2, 2), 400, True),
+                                                       ("float16", 18, 24, (3, 2), 40, False)])
+def test_stream_prep_pooled_matches_the_three_launches(cast, qh, qw, pool, k, counted):
+    """evt_stream_prep with pooled keys / values (ABI 8): the key plane and the value gate read the (B,Nk,2D) buffer of evt_pool_kv,
+    the rel-pos terms the N query tokens -- bit-identical to evt_rel_terms + evt_v_gate + evt_attention_stream's own key-plane
+    pre-kernel, and so is everything the following evt_attention_stream launch produces."""
+    n = native()
+    B, H, dh, scale = 1, 12, 64, 8.0
+    D = H * dh
+    N, gh, gw = qh * qw, qh // pool[0], qw // pool[1]
+    Nk = gh * gw
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator(device=DEV).manual_seed(N + k)
+    qkv = torch.randn(B, N, 3 * D, device=DEV, generator=g)
+    kv = torch.empty(B, Nk, 2 * D, device=DEV)
+    n.pool_kv(qkv, B, qh, qw, D, pool[0], pool[1], kv)
+    ry = torch.randn(qh, gh, dh, device=DEV, generator=g) * 0.2
+    rx = torch.randn(qw, gw, dh, device=DEV, generator=g) * 0.2
+    cap = Nk if counted else k
+    cap += (-cap) % 8
+    idx = torch.zeros(B, cap, dtype=torch.int32, device=DEV)
+    idx[0, :k] = torch.randperm(Nk, device=DEV, generator=g)[:k].sort()[0].int()
+    count = torch.full((B,), k, dtype=torch.int32, device=DEV) if (counted or cap != k) else None
+    apT0 = torch.rand(B, H, Nk, N, device=DEV, generator=g).to(sdt)
+    vp0 = torch.randn(B, Nk, D, device=DEV, generator=g).to(sdt)
+    pv0 = torch.randn(B, N, D, device=DEV, generator=g).to(sdt)
+    pref = torch.randn(B, N, D, device=DEV, generator=g)
+    res = []
+    for prep in (False, True):
+        n.clear_scratch()
+        apT, vp, pv = apT0.clone(), vp0.clone(), pv0.clone()
+        terms = torch.full((B, H, N, gh + gw), float("nan"), device=DEV)
+        vd = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+        vo = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+        out = torch.empty(B, N, D, device=DEV)
+        parts = torch.empty(B, N, H, device=DEV)
+        if prep:
+            assert n.stream_prep_fits(D, H, cap, True)
+            n.stream_prep(qkv, ry, rx, terms, idx, count, cap, vp, vd, vo, B, H, N, D, gh, gw, qw, store, kv=kv, Nk=Nk)
+        else:
+            n.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
+            n.v_gate(kv, idx, count, B, Nk, D, cap, vp, vd, vo, store, True, transposed=True, v_offset=D, v_rs=2 * D)
+        n.attention_stream(qkv, apT, pv, B, H, N, D, scale, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx, count=count, kcap=cap,
+                           v_delta_t=vd, v_old_t=vo, out_f32=out, norm_ref=pref, norm_parts=parts, k_split_ready=prep, kv=kv, Nk=Nk)
+        kplane = n.k_split_plane(qkv, B, H, Nk, gh, gw).clone()
+        res.append([t.cpu() for t in (terms, vd[..., :k], vo[..., :k], vp, kplane.view(torch.int16), apT, pv, out, parts)])
+    for name, a_, b_ in zip(("terms", "v_delta", "v_old", "v_state", "key plane", "a_state_t", "pv", "out", "norm_parts"), res[0], res[1]):
+        assert torch.equal(a_.view(torch.uint8) if a_.dtype == torch.bfloat16 else a_, b_.view(torch.uint8) if b_.dtype == torch.bfloat16 else b_), name
+    assert torch.isfinite(res[1][7]).all()
+
+
+@pytest.mark.parametrize("cast,qh,qw,pool,k,rel", [(None, 18, 18, (2, 2), 30, True), ("bfloat16", 42, 42, (2, 2), 200, True),
+                                                   ("float16", 20, 16, (2, 4), 25, False), (None, 24, 36, (3, 2), 60, True),
+                                                   ("bfloat16", 64, 40, (2, 2), 333, True)])
+@pytest.mark.parametrize("qk_split", [0, 1])
+def test_attention_stream_pooled_keys_matches_oracle(cast, qh, qw, pool, k, rel, qk_split):
+    """evt_attention_stream with POOLED keys / values (ABI 8: `kv`, `Nk`; blocks.py:303-326, 509-511): N = qh x qw query tokens
+    against Nk = N / (p0 p1) pooled cells -- the (B,Nk,2D) buffer of evt_pool_kv, the (B,H,Nk,N) transposed gate reference, the
+    pooled value state, index lists over the cells (incl. a device-side count < kcap), rel-pos terms against the pooled key grid
+    (utils.py:139-173 with the tables pooled along the key axis).  First frame + 3 gated frames against the oracle's softmax /
+    delta gates / accumulator on the same buffers, and the fused per-head ||out - ref||^2 partials."""
+    n = native()
+    import torch.nn.functional as F
+    B, H, dh, scale = 2, 2, 64, 8.0
+    D = H * dh
+    N, gh, gw = qh * qw, qh // pool[0], qw // pool[1]
+    Nk = gh * gw
+    sdt = torch.float32 if cast is None else getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(N * 7 + k)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    apT = torch.full((B, H, Nk, N), float("nan"), dtype=sdt, device=DEV)   # [b][h][cell][row]
+    vp = torch.empty(B, Nk, D, dtype=sdt, device=DEV)
+    pv = torch.full((B, N, D), float("nan"), dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    ry = torch.randn(qh, gh, dh, generator=g) * 0.2 if rel else None
+    rx = torch.randn(qw, gw, dh, generator=g) * 0.2 if rel else None
+    tol = (3e-5 if not qk_split else 3e-4) if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+
+    def pooled(x):   # (B,H,N,dh) -> (B,H,Nk,dh): Block._pool_tokens (blocks.py:303-326)
+        y = x.reshape(B * H, qh, qw, dh).permute(0, 3, 1, 2)
+        return F.avg_pool2d(y, pool).permute(0, 2, 3, 1).reshape(B, H, Nk, dh)
+
+    for t in range(4):
+        buf = torch.randn(B, N, 3 * D, generator=g) * 1.5
+        idx = torch.stack([torch.randperm(Nk, generator=g)[:k].sort()[0] for _ in range(B)])
+        q, kk, v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        kk, v = pooled(kk), pooled(v)
+        scores = (q / scale) @ kk.transpose(-2, -1)
+        if rel:
+            qg = q.reshape(B, H, qh, qw, dh)
+            ty = torch.einsum("abhwc,hkc->abhwk", qg, ry).unsqueeze(-1)
+            tx = torch.einsum("abhwc,wkc->abhwk", qg, rx).unsqueeze(-2)
+            logits = ((scores.view(B, H, qh, qw, gh, gw) + ty) + tx).view(B, H, N, Nk)
+        else:
+            logits = scores
+        a = logits.softmax(dim=-1)
+        if cast is not None:
+            a, v = a.to(sdt), v.to(sdt)
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        bd, idxd = buf.to(DEV), idx.int().to(DEV)
+        kv = torch.full((B, Nk, 2 * D), float("nan"), device=DEV)
+        n.pool_kv(bd, B, qh, qw, D, pool[0], pool[1], kv)
+        terms = None
+        if rel:
+            terms = torch.empty(B, H, N, gh + gw, device=DEV)
+            n.rel_terms(bd, ry.to(DEV), rx.to(DEV), B, H, N, D, gh, gw, qw, terms, split=qk_split)
+        relkw = dict(rel_terms=terms, gh=gh, gw=gw) if rel else {}
+        if t == 0:
+            n.v_gate(kv, None, None, B, Nk, D, 0, vp, None, None, store, False, v_offset=D, v_rs=2 * D)
+            n.attention_stream(bd, apT, pv, B, H, N, D, scale, store, True, v_state=vp, out_f32=out, qk_split=qk_split, kv=kv, Nk=Nk, **relkw)
+        else:
+            cap = k if t != 2 else k + 8
+            idx_cap = torch.full((B, cap), 0, dtype=torch.int32, device=DEV)
+            idx_cap[:, :k] = idxd
+            count = None if cap == k else torch.full((B,), k, dtype=torch.int32, device=DEV)
+            v_del = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            v_old = torch.full((B, D, cap), float("nan"), dtype=sdt, device=DEV)
+            n.v_gate(kv, idx_cap, count, B, Nk, D, cap, vp, v_del, v_old, store, True, transposed=True, v_offset=D, v_rs=2 * D)
+            ref_next = torch.randn(B, N, D, generator=g).to(DEV)
+            parts = torch.full((B, N, H), float("nan"), device=DEV)
+            n.attention_stream(bd, apT, pv, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap,
+                               v_delta_t=v_del, v_old_t=v_old, out_f32=out, norm_ref=ref_next, norm_parts=parts,
+                               qk_split=qk_split, kv=kv, Nk=Nk, **relkw)
+            want_parts = (out - ref_next).view(B, N, H, dh).pow(2).sum(-1)
+            assert torch.allclose(parts, want_parts, rtol=1e-5, atol=1e-6), float((parts - want_parts).abs().max())
+        atol_p = {None: tol * 0.1 + 3e-6, "bfloat16": 4e-3, "float16": 5e-4}[cast]
+        got_p = apT.float().cpu().transpose(-1, -2)
+        assert torch.allclose(got_p, ag.t.float(), atol=atol_p), (cast, t, float((got_p - ag.t.float()).abs().max()))
+        err = float((out.cpu() - ref).abs().max())
+        bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        assert err <= bar, (cast, N, Nk, k, t, err, bar)
+        assert torch.equal(out.cpu(), pv.float().cpu())
 
 
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),

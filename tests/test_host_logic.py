@@ -24,7 +24,7 @@ def test_abi_header_symbols_are_exported():
         assert hasattr(lib, name), f"{name} declared in include/evt_abi.h but not exported"
     lib.evt_version.restype = ctypes.c_int
     lib.evt_target_arch.restype = ctypes.c_char_p
-    assert lib.evt_version() == _native.ABI_VERSION == 7 and lib.evt_target_arch() == b"gfx950"
+    assert lib.evt_version() == _native.ABI_VERSION == 8 and lib.evt_target_arch() == b"gfx950"
 
 
 def test_abi_argument_errors_without_gpu():
