@@ -13,10 +13,6 @@ struct LinArgs {
   int a_planes, out_planes;
   // evt_linear_pipe.hip only: A is ONE bf16 plane (row pitch lda elements) of exactly bf16-representable values (ABI 4: a_bf16)
   int a_bf16;
-  // evt_linear_small.hip only (ABI 5): the gate's token selection runs INSIDE the launch -- every workgroup selects for the
-  // clip(s) of its rows from the delta norms; a_idx / o_idx only say which sides are indexed, the list is sel_idx
-  const float* sel_norms; int sel_parts, sel_N, sel_k, sel_mode; float sel_thr;
-  int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
 };
 
 // evt_linear_pipe.hip: persistent 256-row tiles, software-pipelined k-tiles, for launches that fill the chip.  evt_big_choice: the
@@ -27,7 +23,7 @@ bool evt_launch_split_big(const LinArgs& a, hipStream_t s);
 // evt_linear_small.hip: latency-oriented kernel for small gated row counts (one video stream).  Returns the K split it
 // launched with (0 = not taken; > 1 = partial planes in the workspace, the caller runs the finish pass).
 int evt_launch_split_small(const LinArgs& a, hipStream_t s);
-// true: evt_launch_split_small would take this launch (shape-only), i.e. it may carry an embedded selection
+// true: evt_launch_split_small would take this launch (shape-only)
 bool evt_small_accepts(const LinArgs& a);
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

@@ -607,22 +607,6 @@ int launch_linear(const LinArgs& a, void* stream) {
   return evt_check_launch("evt_gated_linear");
 }
 
-// Validates and installs the embedded-selection fields (evt_linear_desc / evt_mlp_desc sel_*).
-int set_selection(LinArgs& a, const float* norms, int parts, int N, int k, int mode, float thr, int32_t* idx, int32_t* count, int32_t* rest) {
-  if (idx == nullptr) return evt_fail(EVT_ERR_BAD_ARG, "embedded selection: sel_idx is null");
-  if (N <= 0 || N > 16384 || parts < 0) return evt_fail(EVT_ERR_BAD_SHAPE, "embedded selection: sel_N=%d sel_parts=%d", N, parts);
-  if (mode == 0) {
-    if (k <= 0 || k > N || k != a.kcap) return evt_fail(EVT_ERR_BAD_ARG, "embedded top-k selection: sel_k=%d must equal kcap=%d and be in 1..N=%d", k, a.kcap, N);
-  } else if (mode == 1) {
-    if (count == nullptr || a.kcap < N || thr != thr) return evt_fail(EVT_ERR_BAD_ARG, "embedded threshold selection needs sel_count, kcap >= N and a threshold");
-  } else {
-    return evt_fail(EVT_ERR_BAD_ARG, "embedded selection: sel_mode=%d", mode);
-  }
-  a.sel_norms = norms; a.sel_parts = parts; a.sel_N = N; a.sel_k = k; a.sel_mode = mode; a.sel_thr = thr;
-  a.sel_idx = idx; a.sel_count = count; a.sel_rest = rest;
-  return EVT_OK;
-}
-
 }  // namespace
 
 extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
@@ -638,14 +622,6 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
   EVT_REQUIRE(d->workspace_bytes >= 0, EVT_ERR_BAD_ARG, "evt_gated_linear: negative workspace_bytes");
   LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
             d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
-  if (d->sel_norms != nullptr) {
-    const int rc = set_selection(a, d->sel_norms, d->sel_parts, d->sel_N, d->sel_k, d->sel_mode, d->sel_thr, d->sel_idx, d->sel_count, d->sel_rest);
-    if (rc != EVT_OK) return rc;
-    EVT_REQUIRE(d->a_idx != nullptr && !d->a_bf16, EVT_ERR_BAD_ARG, "evt_gated_linear: an embedded selection needs gathered fp32 rows (a_idx)");
-    EVT_REQUIRE(evt_small_accepts(a), EVT_ERR_BAD_SHAPE,
-                "evt_gated_linear: this launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select): "
-                "B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
-  }
   if (d->a_bf16) {
     a.a_bf16 = 1;
     EVT_REQUIRE(d->act == EVT_ACT_NONE && evt_big_choice(a) != 0, EVT_ERR_BAD_SHAPE,
@@ -653,16 +629,6 @@ extern "C" int evt_gated_linear(const evt_linear_desc* d, void* stream) {
                 "evt_gated_linear_big_tile first): B*kcap=%d K=%d Nout=%d", d->B * d->kcap, d->K, d->Nout);
   }
   return launch_linear(a, stream);
-}
-
-extern "C" int evt_gated_linear_embeds_select(const evt_linear_desc* d) {
-  if (d == nullptr || d->B <= 0 || d->kcap <= 0 || d->K <= 0 || d->Nout <= 0 || d->a_idx == nullptr || d->a_bf16) return 0;
-  LinArgs a{d->A, d->lda, d->a_idx, d->a_rows, d->W, (const uint16_t*)d->W_split, d->bias, d->out, d->ldo, d->o_idx, d->o_rows,
-            d->count, d->p_upd, d->B, d->kcap, d->K, d->Nout, d->act, (float*)d->workspace, d->workspace_bytes};
-  a.sel_norms = d->sel_norms != nullptr ? d->sel_norms : reinterpret_cast<const float*>(d);   // shape-only: any non-null value
-  a.sel_mode = d->sel_mode;
-  a.sel_N = d->sel_N > 0 ? d->sel_N : d->a_rows;
-  return evt_small_accepts(a) ? 1 : 0;
 }
 
 extern "C" int evt_gated_linear_big_tile(const evt_linear_desc* d) {
@@ -693,12 +659,6 @@ extern "C" int evt_gated_mlp(const evt_mlp_desc* d, void* stream) {
               d->kcap, d->count, d->p_upd, d->B, d->kcap, d->D, d->Dh, EVT_ACT_GELU_ERF, (float*)d->workspace, d->workspace_bytes};
   LinArgs fc2{d->hidden, (int64_t)d->Dh, nullptr, d->kcap, d->W2, (const uint16_t*)d->W2_split, d->b2, d->out, d->ldo, d->idx,
               d->idx ? d->rows : d->kcap, d->count, nullptr, d->B, d->kcap, d->Dh, d->D, EVT_ACT_NONE, (float*)d->workspace, d->workspace_bytes};
-  if (d->sel_norms != nullptr) {   // the MLP gate's selection inside the first launch; the second reads the list it wrote
-    const int rc_sel = set_selection(fc1, d->sel_norms, d->sel_parts, d->sel_N, d->sel_k, d->sel_mode, d->sel_thr, d->sel_idx, d->sel_count, d->sel_rest);
-    if (rc_sel != EVT_OK) return rc_sel;
-    EVT_REQUIRE(d->idx != nullptr && evt_small_accepts(fc1), EVT_ERR_BAD_SHAPE,
-                "evt_gated_mlp: the first launch does not run on the small-row-count kernel (query evt_gated_linear_embeds_select)");
-  }
   // Both launches on the 256-row kernel: the hidden scratch holds hl32 lines (same bytes as fp32) -- GELU(x) is split once,
   // in the first launch's epilogue, and the second launch stages it without conversion.
   if (fc1.Wsplit != nullptr && (d->Dh & 31) == 0 && evt_big_choice(fc1) != 0 && evt_big_choice(fc2) != 0) {

@@ -23,7 +23,6 @@
 // accumulate); the k order inside a wave is ascending and the four wave partials are added in wave order, so results
 // are deterministic (they differ from the 128x128 kernel's by fp32 summation order only).
 #include "evt_linear.h"
-#include "evt_select_dev.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -37,23 +36,14 @@ typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
 // below a device-side count (one stream under the threshold policy); the straight-line form keeps the 64x64 tile within
 // the 256 registers two waves per SIMD allow (the loop spilled 47 of them: 12.2 -> 18.8 us for QKV at M = 256), so the
 // looped form runs four waves.
-// SEL: the gate's token selection (evt_select_block, the code of evt_select_*) runs inside the launch, behind the first
-// weight requests: every workgroup selects for the clip(s) its rows belong to -- redundantly, on LDS and registers of CUs
-// that would otherwise wait for a separate ~8-10 us selection launch (one workgroup on one CU) and its boundary -- and the
-// workgroup that owns a clip's first row in column tile 0 writes the index list (+ count, complement list) to HBM for the
-// later kernels of the block.
-template <int ACT, int BM, int BN, bool PARTIAL, int NW, bool LOOPED, bool SEL>
+template <int ACT, int BM, int BN, bool PARTIAL, int NW, bool LOOPED>
 __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_kernel(const LinArgs g, int tiles_n, int ksplit, int gm) {
   constexpr int MI = BM / 32, NJ = BN / 32, SMALL_THREADS = 64 * NW;
   constexpr int AJ = BM / 8, WJ = BN / 8;                 // 16-byte pieces per lane per k-tile: 8 rows x 8 chunks per wave instruction
   constexpr int WSTAGE = 2 * BM * 32 + 2 * BN * 32;       // bf16 elements of one wave's stage: A hi, A lo, W hi, W lo
   static_assert((size_t)WSTAGE * 2 >= (size_t)BM * BN * 4, "a wave's partial tile reuses its operand stage");
   extern __shared__ __attribute__((aligned(16))) unsigned char evt_small_smem[];
-  // (SEL: the selection scratch lies over the operand stages and may be the larger of the two)
-  const size_t front = SEL ? max((size_t)NW * WSTAGE * 2, (size_t)evt_select_smem_words(g.sel_N) * 4) : (size_t)NW * WSTAGE * 2;
-  int64_t* orow_off = reinterpret_cast<int64_t*>(evt_small_smem + front);   // [BM] output row offset (elements), -1 = masked row
-  int32_t* idx_l = reinterpret_cast<int32_t*>(orow_off + BM);                                  // SEL: [kcap] the index list of one clip
-  uint32_t* sel_smem = reinterpret_cast<uint32_t*>(evt_small_smem);                            // SEL: selection scratch over the (idle) stages
+  int64_t* orow_off = reinterpret_cast<int64_t*>(evt_small_smem + (size_t)NW * WSTAGE * 2);   // [BM] output row offset (elements), -1 = masked row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __bf16* Ahi = reinterpret_cast<__bf16*>(evt_small_smem) + wave * WSTAGE;   // this wave's private operand stage
@@ -93,14 +83,7 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
     bn = t8 / gm;
     bm_first = t8 - bn * gm;
   }
-  int sel_cnt = 0;
-  if (SEL && LOOPED) {   // one stream: the selection once, in front of the row-tile loop; idx_l stays valid throughout
-    const bool writer = bn == 0 && split == 0 && bm_first == 0;
-    sel_cnt = evt_select_block<SMALL_THREADS>(g.sel_norms, g.sel_parts, g.sel_N, g.sel_k, g.sel_thr, g.sel_mode, g.kcap, sel_smem, idx_l,
-                                              writer ? g.sel_idx : nullptr, writer ? g.sel_count : nullptr, writer ? g.sel_rest : nullptr);
-    __syncthreads();
-  }
-  const int rows_live = LOOPED ? min(M, SEL ? sel_cnt : g.count[0]) : M;
+  const int rows_live = LOOPED ? min(M, g.count[0]) : M;
   const int n0_inv = bn * BN;
   for (int bm = bm_first; bm * BM < rows_live; bm += gm) {
   const int m0 = bm * BM;
@@ -139,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
   Regs R0, R1;
   const int tc1 = t0 + 1 < t1 ? t0 + 1 : tc0;
   fetch_w(R0, tc0);   // weights first: they depend on nothing
-  if (!SEL) fetch_w(R1, tc1);   // (SEL: the second set is requested behind the selection -- held across it, it spills 48 registers)
+  fetch_w(R1, tc1);
 
   // ---- rows of the tile: liveness, output offsets, A row pointers (the dependent chain: index list -> rows) ---------
   int live = 0;
@@ -147,51 +130,28 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
   bool aok[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) { aok[j] = false; asrc[j] = (uint32_t)sc * 16u; }
-  // rows of clip `bsel` (-1: every clip) resolved through the index list `il` of that clip (SEL) or the lists in HBM
-  auto resolve = [&](int bsel, const int32_t* il, int cnt_b) __attribute__((always_inline)) {
-    for (int r = tid; r < BM; r += SMALL_THREADS) {
-      const int m = m0 + r;
-      if (m >= M) continue;
+  for (int r = tid; r < BM; r += SMALL_THREADS) {
+    const int m = m0 + r;
+    int64_t off = -1;
+    if (m < M) {
       const int b = m / g.kcap, ii = m - b * g.kcap;
-      if (bsel >= 0 && b != bsel) continue;
-      const bool ok = SEL ? ii < cnt_b : (g.count == nullptr || ii < g.count[b]);
-      if (!ok) continue;
-      const int o = (g.o_idx != nullptr) ? (SEL ? il[ii] : g.o_idx[m]) : ii;
-      orow_off[r] = ((int64_t)b * g.o_rows + o) * g.ldo;
-      live |= 1;
+      if (g.count == nullptr || ii < g.count[b]) {
+        const int o = (g.o_idx != nullptr) ? g.o_idx[m] : ii;
+        off = ((int64_t)b * g.o_rows + o) * g.ldo;
+        live |= 1;
+      }
     }
+    orow_off[r] = off;
+  }
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int m = m0 + sr + 8 * j;
-      if (m >= M) continue;
-      const int b = m / g.kcap, ii = m - b * g.kcap;
-      if (bsel >= 0 && b != bsel) continue;
-      const bool ok = SEL ? ii < cnt_b : (g.count == nullptr || ii < g.count[b]);
-      if (!ok) continue;
-      const int src = (g.a_idx != nullptr) ? (SEL ? il[ii] : g.a_idx[m]) : ii;
-      asrc[j] = (uint32_t)((b * g.a_rows + src) * (int)g.lda + sc * 4) * 4u;
-      aok[j] = true;
-    }
-  };
-  for (int r = tid; r < BM; r += SMALL_THREADS) orow_off[r] = -1;
-  if (!SEL) {
-    resolve(-1, nullptr, 0);
-  } else if (LOOPED) {
-    resolve(0, idx_l, sel_cnt);
-  } else {
-    // every clip this tile has rows of: select, resolve its rows, next clip (idx_l and the scratch are reused)
-    const int b_lo = m0 / g.kcap, b_hi = (min(m0 + BM, M) - 1) / g.kcap;
-    for (int b = b_lo; b <= b_hi; ++b) {
-      const bool writer = bn == 0 && split == 0 && b * g.kcap >= m0;   // (b * kcap < m0 + BM: b <= b_hi) the tile holding the clip's first row
-      const int cnt_b = evt_select_block<SMALL_THREADS>(g.sel_norms + (int64_t)b * g.sel_N * (g.sel_parts > 0 ? g.sel_parts : 1), g.sel_parts,
-                                                        g.sel_N, g.sel_k, g.sel_thr, g.sel_mode, g.kcap, sel_smem, idx_l,
-                                                        writer ? g.sel_idx + (int64_t)b * g.kcap : nullptr,
-                                                        (writer && g.sel_count != nullptr) ? g.sel_count + b : nullptr,
-                                                        (writer && g.sel_rest != nullptr) ? g.sel_rest + (int64_t)b * g.sel_N : nullptr);
-      __syncthreads();
-      resolve(b, idx_l, cnt_b);
-      __syncthreads();
-    }
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + sr + 8 * j;
+    if (m >= M) continue;
+    const int b = m / g.kcap, ii = m - b * g.kcap;
+    if (!(g.count == nullptr || ii < g.count[b])) continue;
+    const int src = (g.a_idx != nullptr) ? g.a_idx[m] : ii;
+    asrc[j] = (uint32_t)((b * g.a_rows + src) * (int)g.lda + sc * 4) * 4u;
+    aok[j] = true;
   }
   // threshold policy: kcap = N but only count[b] rows are live -- tiles of masked rows have nothing to do (with PARTIAL
   // their workspace rows stay unwritten; splitk_finish_kernel skips the same rows)
@@ -200,7 +160,6 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
 #pragma unroll
     for (int j = 0; j < AJ; ++j) R.a[j] = *reinterpret_cast<const f32x4*>(Abase + (asrc[j] + (uint32_t)t * 128u));
   };
-  if (SEL) fetch_w(R1, tc1);
   fetch_a(R0, tc0);
   fetch_a(R1, tc1);
 
@@ -314,18 +273,17 @@ __global__ __launch_bounds__(64 * NW, LOOPED ? 2 : 1) void gated_linear_small_ke
   }
 }
 
-template <int ACT, int BM, int BN, int NW, bool LOOPED, bool SEL>
+template <int ACT, int BM, int BN, int NW, bool LOOPED>
 void launch_small_inst(const LinArgs& a, hipStream_t s, int ksplit, int tiles_n, int gm) {
   const size_t stages = (size_t)NW * (2 * BM * 32 + 2 * BN * 32) * 2;
-  const size_t front = SEL ? std::max(stages, (size_t)evt_select_smem_words(a.sel_N) * 4) : stages;
-  const size_t lds = front + (size_t)BM * sizeof(int64_t) + (SEL ? (size_t)a.kcap * sizeof(int32_t) : 0);
+  const size_t lds = stages + (size_t)BM * sizeof(int64_t);
   const dim3 grid(LOOPED ? ((tiles_n + 7) & ~7) * gm : 8 * ((tiles_n * gm + 7) / 8), 1, ksplit);
   if (ksplit > 1) {
-    EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), lds);
-    hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED, SEL>), grid, dim3(64 * NW), lds, s, a, tiles_n, ksplit, gm);
+    EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED>), lds);
+    hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, true, NW, LOOPED>), grid, dim3(64 * NW), lds, s, a, tiles_n, ksplit, gm);
   } else {
-    EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, false, NW, LOOPED, SEL>), lds);
-    hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, false, NW, LOOPED, SEL>), grid, dim3(64 * NW), lds, s, a, tiles_n, 1, gm);
+    EVT_ALLOW_LDS((gated_linear_small_kernel<ACT, BM, BN, false, NW, LOOPED>), lds);
+    hipLaunchKernelGGL((gated_linear_small_kernel<ACT, BM, BN, false, NW, LOOPED>), grid, dim3(64 * NW), lds, s, a, tiles_n, 1, gm);
   }
 }
 
@@ -333,18 +291,13 @@ template <int ACT, int BM, int BN>
 void launch_small_tile(const LinArgs& a, hipStream_t s, int ksplit) {
   const int M = a.B * a.kcap;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (a.Nout + BN - 1) / BN;
-  const bool looped = (a.count != nullptr || (a.sel_norms != nullptr && a.sel_mode == 1)) && a.B == 1;
+  const bool looped = a.count != nullptr && a.B == 1;
   // row tiles launched under a device-side count: enough for 512 rows, but not more (column, row) pairs than CUs when that
   // still covers 256 rows -- a 9th workgroup on a 32-CU XCD is a second round
   const int gm_l = std::min(tiles_m, 512 / BM);
   const int gm = looped ? gm_l : tiles_m;
-  if (a.sel_norms != nullptr) {
-    if (looped) launch_small_inst<ACT, BM, BN, 4, true, true>(a, s, ksplit, tiles_n, gm);
-    else launch_small_inst<ACT, BM, BN, 8, false, true>(a, s, ksplit, tiles_n, gm);
-  } else {
-    if (looped) launch_small_inst<ACT, BM, BN, 4, true, false>(a, s, ksplit, tiles_n, gm);
-    else launch_small_inst<ACT, BM, BN, 8, false, false>(a, s, ksplit, tiles_n, gm);
-  }
+  if (looped) launch_small_inst<ACT, BM, BN, 4, true>(a, s, ksplit, tiles_n, gm);
+  else launch_small_inst<ACT, BM, BN, 8, false>(a, s, ksplit, tiles_n, gm);
 }
 
 }  // namespace
@@ -358,18 +311,16 @@ bool evt_small_accepts(const LinArgs& a) {
   // live rows: all of M for top-k; with a per-clip count (threshold policy) kcap = N but few rows are live -- the dead tiles
   // exit at once.  Larger launches belong to the 128x128 / 256-row kernels.
   if ((int64_t)a.B * a.a_rows * a.lda * 4 >= ((int64_t)1 << 31) || (int64_t)a.Nout * hl32_pitch(a.K) * 2 >= ((int64_t)1 << 31)) return false;
-  const bool counted = a.count != nullptr || (a.sel_norms != nullptr && a.sel_mode == 1);
+  const bool counted = a.count != nullptr;
   if (!counted && M > 1024) return false;
   if (counted && (a.B > 4 || M > 16384)) return false;
-  // embedded selection: the scratch (N + 4.4 K words) lives over the operand stages, the list beside them
-  if (a.sel_norms != nullptr && (a.sel_N > 8192 || a.kcap > 8192)) return false;
   return evt_big_choice(a) == 0;
 }
 
 int evt_launch_split_small(const LinArgs& a, hipStream_t s) {
   if (!evt_small_accepts(a)) return 0;
   const int64_t M = (int64_t)a.B * a.kcap;
-  const bool counted_ = a.count != nullptr || (a.sel_norms != nullptr && a.sel_mode == 1);
+  const bool counted_ = a.count != nullptr;
   const int live = counted_ ? (int)std::min<int64_t>(M, 512) : (int)M;   // planning figure for the tile choice
   // tile: 64x64 unless that leaves fewer than ~128 workgroups (graph-replayed launches at M = 256, us incl. the ~1.5 us
   // boundary, 64x64 / 32x32: QKV 12.2 / 14.0, MLP-1 12.7 / 16.0, projection 11.3 / 6.6, MLP-2 24.8 / 13.1; MLP-2 as

@@ -25,7 +25,7 @@ ABI_VERSION = 8   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_row_pass_ord", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
-    "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_linear_embeds_select", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
+    "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
 )
 
@@ -37,8 +37,6 @@ class LinearDesc(Structure):
         ("o_idx", c_void_p), ("o_rows", c_int32), ("count", c_void_p), ("p_upd", c_void_p),
         ("B", c_int32), ("kcap", c_int32), ("K", c_int32), ("Nout", c_int32), ("act", c_int32),
         ("W_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64), ("a_bf16", c_int32),
-        ("sel_norms", c_void_p), ("sel_parts", c_int32), ("sel_N", c_int32), ("sel_k", c_int32), ("sel_mode", c_int32),
-        ("sel_thr", c_float), ("sel_idx", c_void_p), ("sel_count", c_void_p), ("sel_rest", c_void_p),
     ]
 
 
@@ -49,8 +47,6 @@ class MlpDesc(Structure):
         ("hidden", c_void_p), ("out", c_void_p), ("ldo", c_int64), ("count", c_void_p),
         ("p_upd", c_void_p), ("B", c_int32), ("kcap", c_int32), ("D", c_int32), ("Dh", c_int32),
         ("W1_split", c_void_p), ("W2_split", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
-        ("sel_norms", c_void_p), ("sel_parts", c_int32), ("sel_N", c_int32), ("sel_k", c_int32), ("sel_mode", c_int32),
-        ("sel_thr", c_float), ("sel_idx", c_void_p), ("sel_count", c_void_p), ("sel_rest", c_void_p),
     ]
 
 
@@ -160,7 +156,6 @@ def _bind(lib):
         "evt_scatter_rows": [P, P, P, P, I, I, I, I, P],
         "evt_gated_linear": [POINTER(LinearDesc), P],
         "evt_gated_linear_big_tile": [POINTER(LinearDesc)],
-        "evt_gated_linear_embeds_select": [POINTER(LinearDesc)],
         "evt_gated_mlp": [POINTER(MlpDesc), P],
         "evt_split_weights": [P, P, c_int64, c_int64, P],
         "evt_qk": [POINTER(QkDesc), P],
@@ -425,54 +420,27 @@ def gated_linear_big_tile(lda, gathered, a_rows, ldo, scattered, o_rows, has_cou
     launches that accept bf16 activations (`a_bf16`).  Shape-only -- the descriptor's pointers are only compared with NULL."""
     one = ctypes.c_void_p(1)
     d = LinearDesc(one, lda, one if gathered else None, a_rows, one, one, one, ldo, one if scattered else None, o_rows,
-                   one if has_count else None, None, B, kcap, K, Nout, ACT_NONE, one if has_split else None, None, 0, 0,
-                   *_sel_fields(None))
+                   one if has_count else None, None, B, kcap, K, Nout, ACT_NONE, one if has_split else None, None, 0, 0)
     return int(load().evt_gated_linear_big_tile(ctypes.byref(d)))
 
 
-# Small launches can run the gate's selection INSIDE the gated linear (evt_abi.h sel_* fields).  Measured on ViTDet 672^2 (round 3):
-# the embedded form adds ~8.5 us to the gated linear (dependent chain norms -> selection -> row requests in every workgroup)
-# while the stand-alone selection launch costs 5.3 us + a ~1.5 us boundary since its register-resident rewrite: OFF by default.
-EMBED_SELECT = os.environ.get("EVT_EMBED_SELECT", "0") != "0"
-
-
-def _sel_fields(select):
-    """select: None, or dict(norms, parts, N, k, mode, thr, idx, count, rest) -> the sel_* descriptor fields."""
-    if select is None:
-        return (None, 0, 0, 0, 0, 0.0, None, None, None)
-    return (_p(select["norms"]), int(select.get("parts", 0)), int(select["N"]), int(select.get("k", 0)), int(select["mode"]),
-            float(select.get("thr", 0.0)), _p(select["idx"]), _p(select.get("count")), _p(select.get("rest")))
-
-
-def embeds_select(lda, a_rows, ldo, scattered, o_rows, counted, B, kcap, K, Nout, N, has_split=True):
-    """True when a gated linear of this shape runs on the small-row-count kernel and can therefore carry the gate's token
-    selection (evt_gated_linear_embeds_select; shape-only)."""
-    if not EMBED_SELECT or GEMM_MODE != "split" or not has_split or kcap <= 0:
-        return False
-    one = ctypes.c_void_p(1)
-    d = LinearDesc(one, lda, one, a_rows, one, one, one, ldo, one if scattered else None, o_rows, one if counted else None, None,
-                   B, kcap, K, Nout, ACT_NONE, one, None, 1 << 40, 0, None, 0, N, 0, 1 if counted else 0, 0.0, None, None, None)
-    return bool(load().evt_gated_linear_embeds_select(ctypes.byref(d)))
-
-
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
-                 W_split=None, a_bf16=False, select=None):
-    """a_bf16: A is a bfloat16 tensor of exactly representable activations (the A.v state; see evt_abi.h).
-    select: the gate's token selection runs inside the launch (see _sel_fields / embeds_select)."""
+                 W_split=None, a_bf16=False):
+    """a_bf16: A is a bfloat16 tensor of exactly representable activations (the A.v state; see evt_abi.h)."""
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
-                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16), *_sel_fields(select))
+                   _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16))
     _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
 
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
-              W2_split=None, select=None):
+              W2_split=None):
     s1, s2 = W1_split, W2_split
     if s1 is None or s2 is None:
         s1 = s2 = None
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
-                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes, *_sel_fields(select))
+                _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes)
     _timed("gemm", 4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
 
 

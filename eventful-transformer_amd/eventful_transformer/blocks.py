@@ -52,9 +52,6 @@ from eventful_transformer.utils import DropPath, RelativePositionEmbedding
 LN_EPS = 1e-6
 
 
-def policy_cap(gate, n_tokens):
-    """Row stride of a gate's index list (= rows per clip of the compact MLP hidden scratch)."""
-    return gate.policy.capacity(n_tokens) if isinstance(gate.policy, _NormPolicy) else n_tokens
 # q.k^T state update: above this fraction of changed state entries the whole product is recomputed instead of the
 # row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
 QK_FULL_RATIO = 0.7
@@ -482,14 +479,9 @@ class EventfulTokenwiseBlock(Block):
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
     # ---------------------------------------------------------------------------------------------
-    def _select(self, gate, c, norms, B, N, tag, parts=0, embed_for=None):
+    def _select(self, gate, c, norms, B, N, tag, parts=0):
         """Runs the gate's policy on the norms already produced by the row pass (parts > 0: on the per-head partial
-        sums of squares produced by the fused attention epilogue).
-
-        embed_for = (K, Nout, ldo, scattered, o_rows) of the gated linear that consumes the list: when that launch is a small one
-        (a few hundred rows: one video stream), the selection is NOT launched here -- the returned `select` dict rides on the gated linear,
-        whose workgroups run it themselves while their first weight tiles are in flight (evt_abi.h, sel_* fields).
-        Returns (idx, count, cap, select or None)."""
+        sums of squares produced by the fused attention epilogue).  Returns (idx, count, cap)."""
         policy = gate.policy
         if isinstance(policy, _NormPolicy):
             cap = policy.capacity(N)
@@ -498,11 +490,6 @@ class EventfulTokenwiseBlock(Block):
             # the qkv gate of blocks with a q.k^T state also wants the complement list (K4 skips re-written rows)
             rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
             self._rest = rest if tag == "qkv" else self._rest
-            if embed_for is not None and cap > 0 and _native.embeds_select(
-                    lda=self.dim, a_rows=N, ldo=embed_for[2], scattered=embed_for[3], o_rows=embed_for[4], counted=count is not None,
-                    B=B, kcap=cap, K=embed_for[0], Nout=embed_for[1], N=N):
-                mode, k, thr = policy.select_params(N)
-                return idx, count, cap, dict(norms=norms, parts=parts, N=N, k=k, mode=mode, thr=thr, idx=idx, count=count, rest=rest)
             if _native.PREFETCH and B * N <= _native.PREFETCH_MAX_ROWS:
                 # one stream: the single-workgroup selection launch also pulls the weight planes of the gated linears one or two
                 # launches ahead into the memory-side cache (MLP-1 behind the projection gate; MLP-2 and the NEXT block's QKV
@@ -515,13 +502,13 @@ class EventfulTokenwiseBlock(Block):
             policy.select_into(norms, B, N, idx, count, rest, parts=parts)
             if INDEX_TAP is not None:
                 INDEX_TAP(self, tag, idx, count)
-            return idx, count, cap, None
+            return idx, count, cap
         # Any other callable gets the delta tensor like in the reference (modules.py:149).
         index = policy(c - gate.p, dim=-1)
         idx = index.reshape(B, -1).to(torch.int32).contiguous()
         if tag == "qkv":
             self._rest = None
-        return idx, None, idx.shape[1], None
+        return idx, None, idx.shape[1]
 
     def _count_gate(self, gate, n):
         if gate.count_mode:
@@ -569,7 +556,7 @@ class EventfulTokenwiseBlock(Block):
         if self.gate_before_ln and ln is not None:
             raw = self._ws("gate_raw", (B, N, D), torch.float32, src)
             _native.row_pass(src, rows, D, res=res, sum_out=sum_out, c_out=raw, p=gate.p, norms=norms, order=_norm_order(gate))
-            idx, count, cap, _ = self._select(gate, raw, norms, B, N, tag)
+            idx, count, cap = self._select(gate, raw, norms, B, N, tag)
             _native.row_pass(raw, rows, D, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c)
             if stgt:
                 _native.row_pass(raw, rows, D, c_out=gate.p)
@@ -589,40 +576,33 @@ class EventfulTokenwiseBlock(Block):
             else:
                 _native.row_pass(src, rows, D, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, eps=LN_EPS, c_out=c,
                                  p=gate.p, norms=norms, order=_norm_order(gate))
-            # (K, Nout of the consuming launch, ldo, scattered, o_rows): the MLP's first launch writes a compact hidden scratch
-            embed_for = None
-            if src16 is None:
-                Dh = self.mlp_1.out_features
-                embed_for = (D, Dh, Dh, False, policy_cap(gate, N)) if tag == "mlp" else (D, out_features, out_features, True, N)
-            idx, count, cap, select = self._select(gate, c, norms, B, N, tag, parts=parts, embed_for=embed_for)
+            idx, count, cap = self._select(gate, c, norms, B, N, tag, parts=parts)
             if src16 is not None:   # the fp32 attention output was not written: the projection reads the bf16 A.v state
                 assert parts and count is None and not stgt
                 linear_fn(src16, idx, count, buffer.b, gate.p, B, cap, a_bf16=True)
             else:
-                linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap, **(dict(select=select) if select is not None else {}))
-                if select is not None and INDEX_TAP is not None:
-                    INDEX_TAP(self, tag, idx, count)
+                linear_fn(c, idx, count, buffer.b, None if stgt else gate.p, B, cap)
             if stgt:
                 _native.row_pass(c, rows, D, c_out=gate.p)
         return buffer.b, idx, count, cap
 
     def _linear_fn(self, layer):
-        def run(a, idx, count, out, p_upd, B, cap, a_bf16=False, select=None):
+        def run(a, idx, count, out, p_upd, B, cap, a_bf16=False):
             N = out.shape[1]
             _native.gated_linear(a, layer.in_features, idx, N if idx is not None else cap, layer.weight, layer.bias,
                                  out, layer.out_features, idx, N if idx is not None else cap, count, p_upd, B, cap,
-                                 layer.in_features, layer.out_features, W_split=layer.split_planes(), a_bf16=a_bf16, select=select)
+                                 layer.in_features, layer.out_features, W_split=layer.split_planes(), a_bf16=a_bf16)
             if layer.count_mode:
                 layer.count_rows(self._n_rows(B, cap, count))
         return run
 
-    def _mlp_fn(self, a, idx, count, out, p_upd, B, cap, select=None):
+    def _mlp_fn(self, a, idx, count, out, p_upd, B, cap):
         N = out.shape[1]
         D, Dh = self.dim, self.mlp_1.out_features
         hidden = self._ws("mlp_hidden", (B * cap, Dh), torch.float32, a)
         _native.gated_mlp(a, D, idx, N if idx is not None else cap, self.mlp_1.weight, self.mlp_1.bias,
                           self.mlp_2.weight, self.mlp_2.bias, hidden, out, D, count, p_upd, B, cap, D, Dh,
-                          W1_split=self.mlp_1.split_planes(), W2_split=self.mlp_2.split_planes(), select=select)
+                          W1_split=self.mlp_1.split_planes(), W2_split=self.mlp_2.split_planes())
         if self.mlp_1.count_mode:
             n = self._n_rows(B, cap, count)
             self.mlp_1.count_rows(n)

@@ -51,11 +51,6 @@ class _NormPolicy(ExtendedModule):
         """Exact per-clip count if it is data-independent, else None."""
         raise NotImplementedError
 
-    def select_params(self, n_tokens):
-        """(mode, k, threshold) of the kernel-side selection: mode 0 = top-k, 1 = threshold (evt_select_* / the selection
-        embedded in small gated linears)."""
-        raise NotImplementedError
-
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         """norms (B,N) f32 -> idx (B,capacity) int32 ascending; `count` (B,) int32 if data-dependent;
         `rest` (B,N) int32, optional: the complement list (unselected tokens, ascending).
@@ -76,10 +71,6 @@ class TokenNormThreshold(_NormPolicy):
 
     def fixed_count(self, n_tokens):
         return None
-
-    def select_params(self, n_tokens):
-        self._check_order()
-        return 1, 0, float(self.threshold)
 
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
@@ -116,10 +107,6 @@ class TokenNormTopK(_NormPolicy):
 
     def fixed_count(self, n_tokens):
         return self._k(n_tokens)
-
-    def select_params(self, n_tokens):
-        self._check_order()
-        return 0, self._k(n_tokens), 0.0
 
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()

@@ -46,7 +46,9 @@ extern "C" {
                                     evt_attention_dense_resident (the projection gate's delta norm from the attention epilogue of
                                     the windowed blocks);
                                  8: evt_attn_stream_desc.kv / Nk, evt_stream_prep_desc.kv / Nk (pooled keys and values in
-                                    evt_attention_stream and its preparation launch) */
+                                    evt_attention_stream and its preparation launch); REMOVED: the embedded selection of ABI 5
+                                    (sel_* fields, evt_gated_linear_embeds_select) -- measured slower than the selection launch
+                                    in every configuration */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -179,14 +181,6 @@ typedef struct evt_linear_desc {
                                            /* which IS the attention output (blocks.py:183-189): half the bytes, no split,   */
                                            /* one MFMA of three skipped, bit-identical results.  p_upd still receives fp32.  */
                                            /* Only launches for which evt_gated_linear_big_tile() != 0 accept it.            */
-  /* ABI 5 -- the gate's token selection INSIDE this launch (launches that evt_gated_linear_embeds_select() accepts):  */
-  /* sel_norms != NULL: the (B, sel_N [, sel_parts]) delta norms (evt_row_pass norms, or the per-head partial squares  */
-  /* of evt_softmax_av_gated / evt_attention_stream when sel_parts > 0).  The launch selects like evt_select_topk     */
-  /* (sel_mode 0, sel_k) / evt_select_threshold (sel_mode 1, sel_thr), gathers / scatters through the list it just    */
-  /* built and WRITES it: sel_idx (B, kcap), sel_count (B,) for mode 1, sel_rest (B, sel_N) nullable complement lists. */
-  /* a_idx / o_idx / idx / count are then only flags (which sides are indexed; count for the finish pass).            */
-  const float* sel_norms; int32_t sel_parts, sel_N, sel_k, sel_mode; float sel_thr;
-  int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
 } evt_linear_desc;
 
 EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
@@ -194,12 +188,6 @@ EVT_API int evt_gated_linear(const evt_linear_desc* d, void* stream);
 /* The tile configuration of the persistent 256-row kernel this launch would run on (0: it runs on the 128x128 kernel or its
  * split-K form).  Shape-only: pointers are compared with NULL, nothing is dereferenced, no GPU needed. */
 EVT_API int evt_gated_linear_big_tile(const evt_linear_desc* d);
-
-/* 1 when this launch would run on the small-row-count kernel (evt_linear_small.hip: a few hundred gated rows, one video
- * stream) and may therefore carry the gate's token selection (sel_* fields): the selection then costs no launch of its
- * own -- every workgroup of the gated linear runs it for its clip while its first weight tiles are in flight, one of them
- * writes the list.  Replaces the same reference lines as evt_select_* (policies.py:63, :28-32).  Shape-only, no GPU needed. */
-EVT_API int evt_gated_linear_embeds_select(const evt_linear_desc* d);
 
 /* Split-K for launches with few output tiles (one stream, small r: ViTDet, batch 1).  When the
  * 128x128 tiling yields fewer workgroups than the chip has CUs, the split-precision kernel divides K
@@ -240,14 +228,6 @@ typedef struct evt_mlp_desc {
   const void* W1_split; const void* W2_split;   /* nullable pair: split-precision MFMA path      */
   void* workspace;       int64_t workspace_bytes; /* nullable: split-K partials, max over both   */
                                                   /* linears of evt_gated_linear_workspace_bytes  */
-  /* ABI 5 -- the gate's token selection INSIDE this launch (first launch; evt_gated_linear_embeds_select() on its shape):  */
-  /* sel_norms != NULL: the (B, sel_N [, sel_parts]) delta norms (evt_row_pass norms, or the per-head partial squares  */
-  /* of evt_softmax_av_gated / evt_attention_stream when sel_parts > 0).  The launch selects like evt_select_topk     */
-  /* (sel_mode 0, sel_k) / evt_select_threshold (sel_mode 1, sel_thr), gathers / scatters through the list it just    */
-  /* built and WRITES it: sel_idx (B, kcap), sel_count (B,) for mode 1, sel_rest (B, sel_N) nullable complement lists. */
-  /* a_idx / o_idx / idx / count are then only flags (which sides are indexed; count for the finish pass).            */
-  const float* sel_norms; int32_t sel_parts, sel_N, sel_k, sel_mode; float sel_thr;
-  int32_t* sel_idx; int32_t* sel_count; int32_t* sel_rest;
 } evt_mlp_desc;
 
 EVT_API int evt_gated_mlp(const evt_mlp_desc* d, void* stream);

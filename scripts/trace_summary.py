@@ -12,8 +12,8 @@ def short(n):
     return n.split("(")[0][:70]
 sel = sum(1 for k in ks if "select_kernel" in k[2])
 frames = sel / 36.0
-if frames < 1:   # the selections are embedded in the gated linears: count the global blocks' rel-pos launches (4 per frame)
-    frames = sum(1 for k in ks if "rel_terms_kernel" in k[2]) / 4.0
+if frames < 1:   # no selection launches in the trace: count the global blocks' preparation launches (4 per frame)
+    frames = sum(1 for k in ks if "stream_prep_kernel" in k[2] or "rel_terms" in k[2]) / 4.0
 tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
 durs = collections.defaultdict(list)
 prev = ks[0][0]

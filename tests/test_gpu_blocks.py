@@ -1009,39 +1009,3 @@ def test_lazy_qk_state_is_exact_when_read():
             _native.FUSED_QK = old
     for a, b_ in zip(outs[True], outs[False]):
         assert float((a - b_).abs().max()) <= 1e-3
-
-
-@pytest.mark.parametrize("policy", [("topk", 12), ("thr", 0.8)])
-def test_embedded_selection_matches_standalone(policy):
-    """The gate's token selection embedded in the small-row-count gated linear (evt_abi.h sel_* fields; off by default, see
-    _native.EMBED_SELECT) against the stand-alone selection launch: same index sets, same outputs, bit for bit, on an
-    EventfulBlock over 4 frames (top-k and threshold, two clips)."""
-    from eventful_transformer import _native, blocks as evt_blocks
-    params = O.make_block_params(64, 4, seed=41, std=0.08)
-    xs = O.make_token_stream(2, 37, 64, 4, 12, seed=42, small=0.02)
-    runs = []
-    try:
-        for embed in (False, True):
-            _native.EMBED_SELECT = embed
-            blk = H.product_block("EventfulBlock", params, 64, 4, (6, 6))
-            H.product_policy(blk, policy)
-            taps = []
-            evt_blocks.INDEX_TAP = lambda _b, tag, idx, count: taps.append((tag, idx.clone(), None if count is None else count.clone()))
-            with torch.inference_mode():
-                ys = [blk(xs[t].to(DEV)).cpu() for t in range(4)]
-            runs.append((ys, taps))
-    finally:
-        _native.EMBED_SELECT = False
-        evt_blocks.INDEX_TAP = None
-    (y0, t0), (y1, t1) = runs
-    assert len(t0) == len(t1) == 9
-    for (tag0, i0, c0), (tag1, i1, c1) in zip(t0, t1):
-        assert tag0 == tag1
-        if c0 is None:
-            assert torch.equal(i0, i1)
-        else:
-            assert torch.equal(c0, c1)
-            for b in range(i0.shape[0]):
-                assert torch.equal(i0[b, : int(c0[b])], i1[b, : int(c1[b])])
-    for a, b in zip(y0, y1):
-        assert torch.equal(a, b)
