@@ -789,7 +789,9 @@ def gpu_clock_mhz():
             if read(path) is not None:
                 _CLOCK_SOURCE["sysfs"] = path
     if _CLOCK_SOURCE["sysfs"]:
-        return read(_CLOCK_SOURCE["sysfs"])
+        mhz = read(_CLOCK_SOURCE["sysfs"])
+        if mhz is not None:
+            return mhz   # (else: this sample from rocm-smi -- the file stopped marking a plausible level)
     if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
         return None
     import shutil
@@ -829,8 +831,10 @@ class ClockSampler:
         self._thread.join(timeout=30)
 
     def summary(self):
-        if not self.samples:
-            return None
+        if not self.samples:   # say why, instead of a bare null
+            paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            return {"median": None, "samples": 0, "note": f"no reading on this box: sysfs files {len(paths)}, plausible sysfs level "
+                    f"{bool(_CLOCK_SOURCE['sysfs'])}, rocm-smi {'skipped under the profiler' if os.environ.get('LD_PRELOAD') else 'gave none'}"}
         v = sorted(self.samples)
         return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "shader clock (sysfs pp_dpm_sclk, else rocm-smi) sampled during warm-up + timed region"}
 
