@@ -766,8 +766,10 @@ def test_pooled_eventful_block_on_the_stream_kernel(cast, policy, rel):
             with torch.inference_mode():
                 for t in range(4):
                     ys.append(blk(xs[t].to(DEV)).cpu())
-            assert (getattr(blk.matmul_gate, "_state_t", None) is not None) == pooled_stream
-            if pooled_stream:
+            from eventful_transformer import _native
+            on_stream = pooled_stream and _native.STREAM_QK and _native.FUSED_QK   # (EVT_STREAM_QK=0 / EVT_FUSED_QK=0: the chain)
+            assert (getattr(blk.matmul_gate, "_state_t", None) is not None) == on_stream
+            if on_stream:
                 assert blk.matmul_gate._state_t.shape == (1, 2, 81, 324) and blk.matmul_gate.p.shape == (1, 2, 324, 81)
                 assert blk.v_gate.p.shape == (1, 2, 81, 64)
                 assert blk.matmul_accumulator_1.product.shape == (1, 2, 324, 81)   # refreshed lazily from the token buffer
