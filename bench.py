@@ -809,6 +809,31 @@ def gpu_clock_mhz():
     return None
 
 
+def vendor_dense_bf16(device):
+    """torch.matmul (hipBLASLt) on plain bf16 operands, timed with events: a large square GEMM and the headline's own three GEMM
+    shapes (rows = resident gated rows).  Not part of the product: a yardstick for `roofline.mfma_issued_tflops` -- the chip's
+    matrix cores under its power limit run well below the 2.4 GHz the 2500 TFLOP/s spec peak assumes (profiles/r05/dense_bf16_peak.txt)."""
+    out = {}
+    for name, (m, n, kk) in (("8192x8192x8192", (8192, 8192, 8192)), ("qkv 32768x2304x768", (32768, 2304, 768)),
+                             ("mlp1 32768x3072x768", (32768, 3072, 768)), ("mlp2 32768x768x3072", (32768, 768, 3072))):
+        a = torch.randn(m, kk, device=device, dtype=torch.bfloat16)
+        b = torch.randn(kk, n, device=device, dtype=torch.bfloat16)
+        for _ in range(3):
+            a @ b
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            a @ b
+        e1.record()
+        torch.cuda.synchronize(device)
+        out[name] = round(2.0 * m * n * kk * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+        del a, b
+    out["unit"] = "TFLOP/s"
+    out["note"] = ("plain bf16 GEMM of the vendor library, same box, same run: compare with roofline.mfma_issued_tflops (the bf16 MFMA work "
+                   "the gated GEMMs issue: 3 per fp32 product, 2 for bf16 activations)")
+    return out
+
+
 class ClockSampler:
     """Samples the shader clock (rocm-smi) from a host thread while the timed region runs: rank 0 only, a reading every ~2 s."""
 
@@ -980,6 +1005,8 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
         launches = sum(ev[3] for ev in events)
         if timed_kernel == "gemm":
             achieved = work / (ms * 1e-3) / 1e12
+            # bf16 MFMA FLOP/s actually issued: 3 per fp32 product in split mode, 2 for the launches whose activations are bf16
+            issued = sum(_native.event_work(ev) * (ev[4] if len(ev) > 4 else 1.0) for ev in events) / (ms * 1e-3) / 1e12
             split = _native.GEMM_MODE == "split"
             # split mode: each fp32 product = 3 bf16 MFMA products (hi.hi + hi.lo + lo.hi).  `achieved` stays
             # ALGORITHMIC (2*M*K*N per launch) and is priced against the bf16 dense peak, so 1/3 is the ceiling
@@ -992,7 +1019,7 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
                         "traffic_note": (f"HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), {traffic_src}"
                                          if traffic_src else "no PMC file under profiles/ matches this tree's GEMM source: null"),
                         "arith": "bf16x3 split MFMA, fp32 accumulate" if split else "fp32-input MFMA",
-                        "mfma_issue_frac": round(achieved * (3 if split else 1) / peak, 4),
+                        "mfma_issue_frac": round(issued / peak, 4), "mfma_issued_tflops": round(issued, 1),
                         "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                         "share_of_step_time": round(ms * 1e-3 / (w["serial_pass_s"] if lanes else elapsed), 3)}
             if lanes:
@@ -1537,6 +1564,10 @@ def main():
         if not args.no_exact and kind == "vivit" and _native.GEMM_MODE == "split":
             line["exact_fp32_frames_s"] = exact_fp32_rate(model, data[0], frames)
             log(f"exact-fp32 arithmetic: {line['exact_fp32_frames_s']} frames/s")
+            if line["roofline"] and line["roofline"].get("bound") == "mfma":
+                # what the vendor's plain dense bf16 GEMM reaches on THIS box (power-limited clock), next to the spec peak `frac` is priced on
+                line["roofline"]["vendor_dense_bf16"] = vendor_dense_bf16(device)
+                log(f"hipBLASLt dense bf16 on this box: {line['roofline']['vendor_dense_bf16']}")
         if not args.no_cpu_baseline:
             log("CPU baseline (oracle on the host cores) ...")
             if kind == "vivit":

@@ -353,8 +353,8 @@ def set_kernel_events(family, sink):
         _EVENTS[family] = sink
 
 
-def _timed(family, work, fn, launches=1, count=None, per_row=0.0):
-    """work: algorithmic FLOP / bytes of the launch.  count (device int32 (B,), threshold policy): the launch touches
+def _timed(family, work, fn, launches=1, count=None, per_row=0.0, issue=1.0):
+    """work: algorithmic FLOP / bytes of the launch; issue: matrix-core products issued per algorithmic product (gemm family).  count (device int32 (B,), threshold policy): the launch touches
     `per_row` more work for every LIVE selected row -- the capacity of the index list says nothing about it -- so the entry's
     work becomes a callable that reads a copy of the counts (taken before the start event) once the timed region is over."""
     sink = _EVENTS.get(family)
@@ -368,7 +368,7 @@ def _timed(family, work, fn, launches=1, count=None, per_row=0.0):
     s.record()
     fn()
     e.record()
-    sink.append((s, e, work, launches))
+    sink.append((s, e, work, launches, issue))
 
 
 def event_work(entry):
@@ -430,7 +430,9 @@ def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count,
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
                    _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16))
-    _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())))
+    # split arithmetic: 3 bf16 MFMA products per fp32 product; 2 when the activations are exactly bf16 (no lo plane)
+    issue = (2.0 if a_bf16 else 3.0) if (GEMM_MODE == "split" and W_split is not None) else 1.0
+    _timed("gemm", 2.0 * B * kcap * K * Nout, lambda: _check(load().evt_gated_linear(ctypes.byref(d), _stream())), issue=issue)
 
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
@@ -441,7 +443,8 @@ def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd,
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, D, Dh), (B, kcap, Dh, D)) if s1 is not None else (None, 0)
     d = MlpDesc(_p(A), lda, _p(idx), rows, _p(W1), _p(b1), _p(W2), _p(b2), _p(hidden), _p(out), ldo, _p(count),
                 _p(p_upd), B, kcap, D, Dh, _p(s1), _p(s2), _p(ws), ws_bytes)
-    _timed("gemm", 4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2)
+    _timed("gemm", 4.0 * B * kcap * D * Dh, lambda: _check(load().evt_gated_mlp(ctypes.byref(d), _stream())), launches=2,
+           issue=3.0 if (GEMM_MODE == "split" and s1 is not None) else 1.0)
 
 
 def _ptr_off(t, elems):
