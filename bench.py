@@ -729,10 +729,17 @@ def clips_for_rank(total_clips, world, rank):
     return list(range(rank, total_clips, world))
 
 
-def batches_for_rank(total_clips, world, rank, resident):
-    """This rank's share of the clip set, cut into resident batches of at most `resident` clips."""
+def batches_for_rank(total_clips, world, rank, resident, in_flight=1):
+    """This rank's share of the clip set, cut into resident batches of at most `resident` clips.  in_flight > 1 (vivit workloads:
+    --overlap): a share that makes fewer batches than HIP streams -- the 8-GPU split of the default clip set leaves ONE batch of 256
+    per rank -- is cut into `in_flight` equal ones instead, so that a rank still has a batch per stream (measured on one GPU with a
+    256-clip share: 2 x 128 on two streams 11 008 frames/s, 1 x 256 10 788; gpurun_out p40)."""
     mine = clips_for_rank(total_clips, world, rank)
-    return [mine[i:i + resident] for i in range(0, len(mine), resident)]
+    batches = [mine[i:i + resident] for i in range(0, len(mine), resident)]
+    if in_flight > 1 and 0 < len(batches) < in_flight and len(mine) >= 32 * in_flight:
+        per = -(-len(mine) // in_flight)
+        batches = [mine[i:i + per] for i in range(0, len(mine), per)]
+    return batches
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -893,7 +900,9 @@ def build_workload(name, device, world, rank, clips=256, total_clips=None, frame
         scaling = "strong" if total > 0 else "weak"
         if total == 0:
             total = world * resident
-    my_batches = batches_for_rank(total, world, rank, resident)
+    my_batches = batches_for_rank(total, world, rank, resident, overlap if kind == "vivit" else 1)
+    if kind == "vivit" and my_batches:
+        resident = max(len(b) for b in my_batches)
     # weights: rank 0 generates, RCCL broadcasts one flat buffer (the only start-up collective); the other ranks only
     # allocate the same shapes
     if kind == "vivit":
@@ -1646,7 +1655,7 @@ def dry_run(args, world, rank):
     scaling = "strong" if total > 0 else "weak"
     if total == 0:
         total = world * args.clips
-    mine = batches_for_rank(total, world, rank, args.clips)
+    mine = batches_for_rank(total, world, rank, args.clips, args.overlap)
 
     def step():
         for b in mine:

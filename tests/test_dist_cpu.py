@@ -96,13 +96,13 @@ def _dry_run(gpus, *extra):
 
 def test_eight_rank_dry_run_is_the_strong_scaling_split_of_the_one_rank_run():
     """The driver's scaling curve compares N = 1, 2, 4, 8 like for like: the SAME clip set (config.clips_per_step) at every
-    N.  World size 8 over gloo with the bench's default sizes (2048 clips, 256 resident): one resident batch per rank, a
-    disjoint cover of the set, weights generated on rank 0 only and received by the others, ONE JSON line."""
+    N.  World size 8 over gloo with the bench's default sizes (2048 clips, 256 resident): a rank's share is ONE resident batch, cut
+    in two so that both of its HIP streams have work (bench.batches_for_rank, --overlap 2), a disjoint cover of the set, weights generated on rank 0 only and received by the others, ONE JSON line."""
     one = _dry_run(1, "--clips", "256", "--total-clips", "2048")
     eight = _dry_run(8, "--clips", "256", "--total-clips", "2048")
     assert one["config"]["clips_per_step"] == eight["config"]["clips_per_step"] == 2048
     assert one["scaling"] == eight["scaling"] == "strong"
-    assert one["batches_per_rank"] == [[256] * 8] and eight["batches_per_rank"] == [[256]] * 8
+    assert one["batches_per_rank"] == [[256] * 8] and eight["batches_per_rank"] == [[128, 128]] * 8
     assert one["disjoint_cover"] and eight["disjoint_cover"]
     assert eight["n_gpus"] == 8 and eight["clips_per_rank"] == [256] * 8 and eight["weights_from_rank0"] is True
     # SURVEY section 8(e): no data-path collective.  bench.timed_region counts every torch.distributed call issued between its two
