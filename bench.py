@@ -772,48 +772,64 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
     return None, None, {}
 
 
-_CLOCK_SOURCE = {"sysfs": None}   # sysfs path that gave a plausible reading (False: none does)
+_CLOCK_SOURCE = {"dir": None, "sysfs": None}   # sysfs directory of THIS process's GPU 0; its pp_dpm_sclk if that gave a plausible reading
+
+
+def gpu_sysfs_dir():
+    """/sys/class/drm/cardN/device of the GPU that HIP device 0 of this process is -- matched by PCI address: the box shows the
+    sysfs entries of every GPU of the node (card0 is usually somebody else's), the container only one of them as a HIP device.
+    None when the address is not known or not found (then no reading is taken: a number from another GPU would be worse)."""
+    if _CLOCK_SOURCE["dir"] is None:
+        _CLOCK_SOURCE["dir"] = False
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for c in sorted(glob.glob("/sys/class/drm/card*")):
+                dev = os.path.join(c, "device")
+                if os.path.basename(os.path.realpath(dev)).lower().startswith(bdf):
+                    _CLOCK_SOURCE["dir"] = dev
+                    break
+        except Exception:
+            pass
+    return _CLOCK_SOURCE["dir"] or None
 
 
 def gpu_clock_mhz():
-    """Current shader clock of GPU 0 (None when no reading is available): sysfs first (`pp_dpm_sclk`, the level marked `*`: a file
-    read, no child process), rocm-smi otherwise -- but never under a profiler: its preloaded library initialises the GPU in every
-    child, and a child that then execs (rocm-smi is a `#!/usr/bin/env python3` script) is refused on this pool."""
-    def read(path):
-        try:
-            for ln in open(path).read().splitlines():
-                if ln.strip().endswith("*"):
-                    m = re.search(r"(\d+)\s*mhz", ln.lower())
-                    if m and int(m.group(1)) >= 500:   # (some boxes list a 95 MHz level as current whatever the load: not a reading)
-                        return int(m.group(1))
-        except Exception:
-            pass
+    """Current shader clock of this process's GPU 0 (None when no reading is available): `pp_dpm_sclk` of ITS sysfs entry (the level
+    marked `*`: a file read, no child process).  (rocm-smi is not used any more: its device numbering is the node's, not the
+    container's, and under a profiler a child that execs is refused on this pool.)"""
+    d = gpu_sysfs_dir()
+    if d is None:
         return None
-
-    if _CLOCK_SOURCE["sysfs"] is None:
-        _CLOCK_SOURCE["sysfs"] = False
-        for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:1]:
-            if read(path) is not None:
-                _CLOCK_SOURCE["sysfs"] = path
-    if _CLOCK_SOURCE["sysfs"]:
-        mhz = read(_CLOCK_SOURCE["sysfs"])
-        if mhz is not None:
-            return mhz   # (else: this sample from rocm-smi -- the file stopped marking a plausible level)
-    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
-        return None
-    import shutil
-    tool = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     try:
-        out = subprocess.run([tool, "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-        card = next(iter(json.loads(out).values()))
-        for key, val in card.items():
-            if "sclk" in key.lower():
-                m = re.search(r"(\d+)\s*mhz", str(val).lower())
+        for ln in open(os.path.join(d, "pp_dpm_sclk")).read().splitlines():
+            if ln.strip().endswith("*"):
+                m = re.search(r"(\d+)\s*mhz", ln.lower())
                 if m:
+                    _CLOCK_SOURCE["sysfs"] = True
                     return int(m.group(1))
     except Exception:
         pass
     return None
+
+
+def gpu_power_w():
+    """(socket power in W, power cap in W) of this process's GPU 0 from its amdgpu hwmon files (None where a file is missing): whether
+    the shader clock the run sustains is the chip's power limit at work."""
+    def read_uw(path):
+        try:
+            return int(open(path).read().strip()) / 1e6
+        except Exception:
+            return None
+    d = gpu_sysfs_dir()
+    if d is None:
+        return None, None
+    for h in sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))[:1]:
+        now = read_uw(os.path.join(h, "power1_average"))
+        if now is None:
+            now = read_uw(os.path.join(h, "power1_input"))
+        return now, read_uw(os.path.join(h, "power1_cap"))
+    return None, None
 
 
 def vendor_dense_bf16(device):
@@ -842,10 +858,10 @@ def vendor_dense_bf16(device):
 
 
 class ClockSampler:
-    """Samples the shader clock (rocm-smi) from a host thread while the timed region runs: rank 0 only, a reading every ~2 s."""
+    """Samples the shader clock (and the socket power) from a host thread while the timed region runs: rank 0 only, a reading every ~2 s."""
 
     def __init__(self):
-        self.samples, self._stop, self._thread = [], threading.Event(), None
+        self.samples, self.power, self.cap, self._stop, self._thread = [], [], None, threading.Event(), None
 
     def __enter__(self):
         def run():
@@ -853,6 +869,10 @@ class ClockSampler:
                 v = gpu_clock_mhz()
                 if v is not None:
                     self.samples.append(v)
+                pw, cap = gpu_power_w()
+                if pw is not None:
+                    self.power.append(pw)
+                    self.cap = cap
                 self._stop.wait(2.0)
         self._thread = threading.Thread(target=run, daemon=True)
         self._thread.start()
@@ -864,11 +884,14 @@ class ClockSampler:
 
     def summary(self):
         if not self.samples:   # say why, instead of a bare null
-            paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-            return {"median": None, "samples": 0, "note": f"no reading on this box: sysfs files {len(paths)}, plausible sysfs level "
-                    f"{bool(_CLOCK_SOURCE['sysfs'])}, rocm-smi {'skipped under the profiler' if os.environ.get('LD_PRELOAD') else 'gave none'}"}
+            return {"median": None, "samples": 0, "note": "no reading: " + ("pp_dpm_sclk of this GPU's sysfs entry marks no level" if gpu_sysfs_dir()
+                                                                           else "this GPU's sysfs entry was not found by PCI address")}
         v = sorted(self.samples)
-        return {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "shader clock (sysfs pp_dpm_sclk, else rocm-smi) sampled during warm-up + timed region"}
+        out = {"min": v[0], "median": v[len(v) // 2], "max": v[-1], "samples": len(v), "source": "shader clock (pp_dpm_sclk of this GPU's sysfs entry, matched by PCI address) sampled during warm-up + timed region"}
+        if self.power:
+            pw = sorted(self.power)
+            out["socket_power_w"] = {"median": round(pw[len(pw) // 2]), "max": round(pw[-1]), "cap": None if self.cap is None else round(self.cap)}
+        return out
 
 
 _T0 = time.perf_counter()
