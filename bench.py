@@ -1015,6 +1015,7 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
             # last batch must also reproduce the overlapped step's output bit for bit.
             elapsed, inside = timed_region(step, steps, world, torch.cuda.synchronize)
             out_overlapped = step().clone()
+            serial_step()   # untimed: the serial order's own first-call effects (allocator growth of `model.clip`) stay out of the pass below
             torch.cuda.synchronize()
             _native.set_kernel_events(timed_kernel, events)
             t0 = time.perf_counter()
