@@ -65,20 +65,22 @@ typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 template <typename T, int TPW, int NREG, int QK = 0>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 : 1) void softmax_av_gated_kernel(const FusedArgs a) {
   constexpr int P = Tile<T>::PITCH;
+  constexpr int DHC = 64 * TPW;                        // head dim of this instantiation (== a.dh: launch_fused)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* An = reinterpret_cast<T*>(smem_raw);              // [FR][P]
   T* Ad = An + FR * P;                                 // [FR][P]
   T* Vd = Ad + FR * P;                                 // [dh][P]
-  T* Vo = Vd + a.dh * P;                               // [dh][P]
-  float* relv = reinterpret_cast<float*>(Vo + a.dh * P);  // [FR][gh+gw] rel-pos terms per row
+  T* Vo = Vd + DHC * P;                                // [dh][P]
+  float* relv = reinterpret_cast<float*>(Vo + DHC * P);   // [FR][gh+gw] rel-pos terms per row
   float* et = relv + FR * (a.gh + a.gw);               // [FR][EP] exp(x - max) (NREG > 0 only)
   // The V tiles are idle before the chunk loop and after it; they double as
   float* qs = reinterpret_cast<float*>(Vd);            // [FR][dh] q rows for the rel-pos dots (prologue)
   float* red1 = reinterpret_cast<float*>(Vd);          // [FR][dh] round(a~ . dv~)          (epilogue)
-  float* red2 = red1 + FR * a.dh;                      // [FR][dh] round(da~ . v_old)       (2*FR*dh*4 <= 2*dh*P*sizeof(T))
+  float* red2 = red1 + FR * DHC;                       // [FR][dh] round(da~ . v_old)       (2*FR*dh*4 <= 2*dh*P*sizeof(T))
   const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value in a scalar register: row indices of a wave are wave-uniform
   // XCD-aware placement: workgroups are dispatched round-robin over the 8 XCDs in linear order (x fastest), which
   // would spread the row tiles of one (clip, head) over 8 private L2s.  Remapped so that all row tiles of a head run on
   // ONE XCD: its dv~ / v_old tiles -- and, in QK mode, its K rows -- are fetched into one L2 instead of up to eight.
@@ -101,6 +103,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   const float* prod = a.product + (int64_t)bh * a.N * a.Nk;
   T* st = reinterpret_cast<T*>(a.a_state) + (int64_t)bh * a.N * a.Nk;
   const int32_t* ix = a.idx + (int64_t)b * a.kcap;
+  // Addressing.  Every tensor is reached through a wave-uniform base (scalar registers: the (clip, head) / clip slice) plus a
+  // 32-bit BYTE offset -- one integer add per access instead of a 64-bit multiply-add chain per lane (the launch is bound by the
+  // vector ALU: 1 894 VALU instructions per wave at ~70 % VALU busy, profiles/r05/attn_pmc_counters.txt).  All slices are far below
+  // 4 GB (entry-point limits: N <= 32767).
+  char* const stb = reinterpret_cast<char*>(st);
+  auto st_off = [&](int row, int col) __attribute__((always_inline)) { return (uint32_t)(row * a.Nk + col) * (uint32_t)sizeof(T); };
+  auto st_load = [&](uint32_t off) __attribute__((always_inline)) { return Store<T>::load(reinterpret_cast<const T*>(stb + off)); };
+  auto st_store = [&](uint32_t off, float v) __attribute__((always_inline)) { Store<T>::store(reinterpret_cast<T*>(stb + off), v); };
 
   // Everything the chunk loop and the epilogue read from HBM that does not depend on the softmax is requested up
   // front (registers), so one workgroup waits for ~2 dependent round trips instead of one per phase: the index list
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     for (int it = 0; it < VIT; ++it) {
       const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
       const bool in = kk < a.kcap;
-      const int64_t o = (int64_t)d * a.kcap + (in ? kk : 0);
-      const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+      const uint32_t o = (uint32_t)(d * a.kcap + (in ? kk : 0)) * (uint32_t)sizeof(T);
+      const uint4 xd = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Vg_d) + o), xo = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Vg_o) + o);
       pd[it] = in ? xd : make_uint4(0, 0, 0, 0);
       po[it] = in ? xo : make_uint4(0, 0, 0, 0);
     }
@@ -141,13 +151,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     for (int it = 0; it < VIT; ++it) {
       const int e = tid + 256 * it, d = e / (FKC / VEC), jj = (e - d * (FKC / VEC)) * VEC, kk = k0 + jj;
       const bool in = kk < a.kcap;   // kcap % VEC == 0: a piece is wholly in or out
-      const int64_t o = (int64_t)d * a.kcap + (in ? kk : 0);
-      const uint4 xd = *reinterpret_cast<const uint4*>(Vg_d + o), xo = *reinterpret_cast<const uint4*>(Vg_o + o);
+      const uint32_t o = (uint32_t)(d * a.kcap + (in ? kk : 0)) * (uint32_t)sizeof(T);
+      const uint4 xd = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Vg_d) + o), xo = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Vg_o) + o);
       vpd[it] = in ? xd : make_uint4(0, 0, 0, 0);
       vpo[it] = in ? xo : make_uint4(0, 0, 0, 0);
     }
   };
   T* pv = reinterpret_cast<T*>(a.pv);
+  T* const pv_bh = pv + ((int64_t)b * a.N * a.D + h * DHC);                                   // this clip's rows, this head's channels
+  const float* const nref_bh = a.norm_ref ? a.norm_ref + ((int64_t)b * a.N * a.D + h * DHC) : nullptr;
   constexpr int PIT = FR * (64 * TPW / 8) / 256;      // 8-channel state pieces per thread (epilogue)
   union Pv8 { uint4 u[(8 * sizeof(T)) / 16]; T t[8]; };
   Pv8 pvr[PIT];
@@ -156,13 +168,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   auto load_pv = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
-      const int e = tid + 256 * it, row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8, i = i0 + row;
-      const int64_t o = ((int64_t)b * a.N + (i < a.N ? i : a.N - 1)) * a.D + h * a.dh + c8;   // clamped: branch-free
+      const int e = tid + 256 * it, row = e / (DHC / 8), c8 = (e - row * (DHC / 8)) * 8, i = i0 + row;
+      const uint32_t o = (uint32_t)((i < a.N ? i : a.N - 1) * a.D + c8);   // element offset; clamped: branch-free
 #pragma unroll
-      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) pvr[it].u[q] = reinterpret_cast<const uint4*>(pv + o)[q];
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q)
+        pvr[it].u[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pv_bh) + (o * (uint32_t)sizeof(T) + 16u * q));
       if (a.norm_ref != nullptr) {   // wave-uniform
-        nrr[it].v[0] = reinterpret_cast<const float4*>(a.norm_ref + o)[0];
-        nrr[it].v[1] = reinterpret_cast<const float4*>(a.norm_ref + o)[1];
+        nrr[it].v[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nref_bh) + o * 4u);
+        nrr[it].v[1] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nref_bh) + (o * 4u + 16u));
       }
     }
   };
@@ -219,8 +232,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     for (int c = 0; c < PF; ++c)
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
-        const int i = i0 + wave * 8 + rr;
-        oldpf[c][rr] = Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + (jpf[c] >= 0 ? jpf[c] : 0));   // branch-free
+        const int i = i0 + wave_s * 8 + rr;   // (scalar)
+        oldpf[c][rr] = st_load(st_off(i < a.N ? i : 0, jpf[c] >= 0 ? jpf[c] : 0));   // branch-free
       }
     if (vvec) load_v(0);
     load_pv();
@@ -229,8 +242,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     // ---- phase 0 (QK mode): S = (q / scale) k^T for the 32 rows into the LDS tile `et` (pitch EP).  Wave w owns keys
     // 16w .. 16w+15 of every 64-key chunk; lane (l15, kg) holds, of q row l15 / key l15, the channels `chan` of its
     // fragment pieces ("Operand path" below); one workgroup barrier (the q rows), none per chunk.
-    const int64_t rs = 3 * (int64_t)a.D;
+    const int rs = 3 * a.D;   // floats per token row
     const float* clip = a.qkv + (int64_t)b * a.N * rs;
+    const char* const qbase = reinterpret_cast<const char*>(clip + h * 64);           // this head's q channels of token 0
+    const char* const kbase_b = reinterpret_cast<const char*>(clip + a.D + h * 64);   // ... its k channels
     const int l15 = lane & 15, kg = lane >> 4;
     const float inv = 1.0f / a.scale;
     const bool pow2 = (inv * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
@@ -266,29 +281,31 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + 256 * u, row = e >> 4, i = i0 + row;
-      qg[u] = *reinterpret_cast<const float4*>(clip + (int64_t)(i < a.N ? i : a.N - 1) * rs + h * 64 + 4 * (e & 15));
+      qg[u] = *reinterpret_cast<const float4*>(qbase + (uint32_t)((i < a.N ? i : a.N - 1) * rs + 4 * (e & 15)) * 4u);
     }
     // (named native vectors, not a float4 array handed to a lambda: hipcc kept that array in scratch memory)
     typedef float kvec __attribute__((ext_vector_type(4)));
-    kvec kr0, kr1, kr2, kr3;
+    kvec kr0, kr1, kr2, kr3;       // raw set A: chunks 0 and 2
+    kvec ks0, ks1, ks2, ks3;       // raw set B: chunks 1 and 3
     const int krow = lane >> 4, kcol = 4 * (lane & 15);
-    const float* kbase = clip + a.D + h * 64 + kcol;
-#define EVT_LOAD_KRAW(c0_)                                                                                     \
+    const uint32_t kcol_b = (uint32_t)kcol * 4u, rs_b = (uint32_t)rs * 4u;   // byte offsets
+    // (rows past N are clamped to the last row -- one v_min each -- so that EVERY chunk's loads are unconditional: the four chunks
+    // below are straight-line code and each wait counts exactly the younger requests; inside nested conditions hipcc waited vmcnt(0))
+#define EVT_LOAD_KRAW(c0_, r0_, r1_, r2_, r3_)                                                                 \
     do {   /* the wave's 16 key rows of chunk c0_, 4 rows per load */                                          \
-      const int j0_ = (c0_) + wave * 16 + krow;                                                                \
-      kr0 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ < a.N ? j0_ : a.N - 1) * rs);                 \
-      kr1 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 4 < a.N ? j0_ + 4 : a.N - 1) * rs);         \
-      kr2 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 8 < a.N ? j0_ + 8 : a.N - 1) * rs);         \
-      kr3 = *reinterpret_cast<const kvec*>(kbase + (int64_t)(j0_ + 12 < a.N ? j0_ + 12 : a.N - 1) * rs);       \
+      const int j0_ = (c0_) + wave_s * 16 + krow, nl_ = a.N - 1;                                               \
+      r0_ = *reinterpret_cast<const kvec*>(kbase_b + ((uint32_t)min(j0_, nl_) * rs_b + kcol_b));               \
+      r1_ = *reinterpret_cast<const kvec*>(kbase_b + ((uint32_t)min(j0_ + 4, nl_) * rs_b + kcol_b));           \
+      r2_ = *reinterpret_cast<const kvec*>(kbase_b + ((uint32_t)min(j0_ + 8, nl_) * rs_b + kcol_b));           \
+      r3_ = *reinterpret_cast<const kvec*>(kbase_b + ((uint32_t)min(j0_ + 12, nl_) * rs_b + kcol_b));          \
     } while (0)
-    // ONE raw register set (the next chunk's rows, in flight while the current chunk is multiplied) + one fragment set: a
-    // second raw set made hipcc load piece by piece with a wait each (three workgroups per CU: 164 registers).  The
-    // score-independent requests of the chunk loop and the epilogue (`prefetch`: 16 two-byte gathers of the old a~ values
-    // among them) go out BEHIND the q rows and the first key chunk: vmcnt retires in order, so in front of them every
-    // q.k^T wait was also a wait for the slowest gather.
-    EVT_LOAD_KRAW(0);
-    asm volatile("" ::: "memory");
-    prefetch();
+    // TWO raw register sets used alternately (the 32-bit addressing freed the registers: 152 + 16), so that the first TWO key
+    // chunks are requested ahead of everything else and every later chunk two chunks ahead: the q.k^T phase is a chain of
+    // dependent round trips, and one raw set made it one round trip per chunk.  The score-independent requests of the chunk loop
+    // and the epilogue (`prefetch`: 16 two-byte gathers of the old a~ values among them) go out BEHIND the q rows and the first two
+    // key chunks: vmcnt retires in order, so in front of them every q.k^T wait was also a wait for the slowest gather.
+    EVT_LOAD_KRAW(0, kr0, kr1, kr2, kr3);
+    EVT_LOAD_KRAW(QKC, ks0, ks1, ks2, ks3);   // (past N: clamped re-reads of the last row, never used)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -312,12 +329,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     float4 kf[4];
     float* kst_w = kst + krow * KP + kcol;
     const float* kst_r = kst + l15 * KP;
-#define EVT_STAGE_K()                                                                                          \
+#define EVT_STAGE_K(r0_, r1_, r2_, r3_)                                                                                          \
     do {                                                                                                       \
-      *reinterpret_cast<kvec*>(kst_w) = kr0;                                                                   \
-      *reinterpret_cast<kvec*>(kst_w + 4 * KP) = kr1;                                                          \
-      *reinterpret_cast<kvec*>(kst_w + 8 * KP) = kr2;                                                          \
-      *reinterpret_cast<kvec*>(kst_w + 12 * KP) = kr3;                                                         \
+      *reinterpret_cast<kvec*>(kst_w) = r0_;                                                                   \
+      *reinterpret_cast<kvec*>(kst_w + 4 * KP) = r1_;                                                          \
+      *reinterpret_cast<kvec*>(kst_w + 8 * KP) = r2_;                                                          \
+      *reinterpret_cast<kvec*>(kst_w + 12 * KP) = r3_;                                                         \
       __builtin_amdgcn_s_waitcnt(0xc07f);                                                                      \
       __builtin_amdgcn_wave_barrier();                                                                         \
       _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) kf[p_] = *reinterpret_cast<const float4*>(kst_r + chan(p_)); \
@@ -360,34 +377,24 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
         }
       }
     };
-    // N <= 256 (entry-point check): at most four chunks, written out -- in a loop the same wait instruction would serve the
-    // first chunk (many younger requests in flight) and the later ones (none), and hipcc has to assume none.
+    // N <= 256 (entry-point check): at most four chunks, written out as straight-line code -- qk_chunk skips a chunk past N
+    // (wave-uniform), its (clamped) loads and staging are harmless.  Issue order (vmcnt retires in order): chunks 0, 1 | chunk 2
+    // behind the staging of 0, chunk 3 behind the staging of 1 | then the score-independent requests of the chunk loop and the
+    // epilogue (`prefetch`), so that no q.k^T wait includes them; they land during the last two chunks and the statistics.
     static_assert(QKC == 64, "four chunks of 64 keys cover N <= 256");
-    // a chunk's row loads and their staging sit in ONE basic block (nested conditions, N <= 256 = four chunks): a load
-    // whose use is in a later conditional block is waited for with vmcnt(0) where it is issued
-    EVT_STAGE_K();
-    if (QKC < a.N) {
-      EVT_LOAD_KRAW(QKC);
-      qk_chunk(0, kf);
-      EVT_STAGE_K();
-      if (2 * QKC < a.N) {
-        EVT_LOAD_KRAW(2 * QKC);
-        qk_chunk(QKC, kf);
-        EVT_STAGE_K();
-        if (3 * QKC < a.N) {
-          EVT_LOAD_KRAW(3 * QKC);
-          qk_chunk(2 * QKC, kf);
-          EVT_STAGE_K();
-          qk_chunk(3 * QKC, kf);
-        } else {
-          qk_chunk(2 * QKC, kf);
-        }
-      } else {
-        qk_chunk(QKC, kf);
-      }
-    } else {
-      qk_chunk(0, kf);
-    }
+    EVT_STAGE_K(kr0, kr1, kr2, kr3);
+    EVT_LOAD_KRAW(2 * QKC, kr0, kr1, kr2, kr3);   // set A is free again
+    qk_chunk(0, kf);
+    EVT_STAGE_K(ks0, ks1, ks2, ks3);
+    EVT_LOAD_KRAW(3 * QKC, ks0, ks1, ks2, ks3);
+    asm volatile("" ::: "memory");
+    prefetch();
+    asm volatile("" ::: "memory");
+    qk_chunk(QKC, kf);
+    EVT_STAGE_K(kr0, kr1, kr2, kr3);
+    qk_chunk(2 * QKC, kf);
+    EVT_STAGE_K(ks0, ks1, ks2, ks3);
+    qk_chunk(3 * QKC, kf);
 #undef EVT_LOAD_KRAW
 #undef EVT_STAGE_K
     __syncthreads();
@@ -395,17 +402,24 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   }
   if (NREG > 0) {
     float xv[8][NREG > 0 ? NREG : 1];
+    // (wave-uniform) only a row's LAST register can reach past Nk: the others need no clamp, no mask and no store predicate, and
+    // their LDS addresses are one per-row base + immediate offsets
+    const bool fullregs = QK && a.Nk > 64 * (NREG - 1);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr, i = i0 + r;
+      const int r = wave_s * 8 + rr, i = i0 + r;
       const float* prow = QK ? (et + r * EP) : (prod + (int64_t)(i < a.N ? i : 0) * a.Nk);
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
         // branch-free: a clamped address keeps all 8*NREG loads of the wave in flight together (a predicated load
         // inside `if (j < Nk)` compiles to load + s_waitcnt vmcnt(0) per element)
         const int j = lane + 64 * u;
-        const float x = prow[j < a.Nk ? j : a.Nk - 1];
-        xv[rr][u] = (j < a.Nk) ? x : -INFINITY;
+        if (fullregs && u < NREG - 1) {
+          xv[rr][u] = prow[j];
+        } else {
+          const float x = prow[j < a.Nk ? j : a.Nk - 1];
+          xv[rr][u] = (j < a.Nk) ? x : -INFINITY;
+        }
       }
     }
     if (QK) {   // every lane holds its scores before the row's exps overwrite them in the same tile
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 #pragma unroll
       for (int u = 0; u < NREG; ++u) {
         const float e = fast_exp(xv[rr][u] - rmax[rr]);  // exp(-inf) == 0 past N
-        if (lane + 64 * u < a.Nk) et[(wave * 8 + rr) * EP + lane + 64 * u] = e;
+        if ((fullregs && u < NREG - 1) || lane + 64 * u < a.Nk) et[(wave_s * 8 + rr) * EP + lane + 64 * u] = e;
         sum += e;
       }
       rsum[rr] = wave_sum_dpp(sum);
@@ -580,15 +594,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     float oldv[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int i = i0 + wave * 8 + rr;
-      oldv[rr] = oldp ? oldp[rr] : Store<T>::load(st + (int64_t)(i < a.N ? i : 0) * a.Nk + js);
+      const int i = i0 + wave_s * 8 + rr;
+      oldv[rr] = oldp ? oldp[rr] : st_load(st_off(i < a.N ? i : 0, js));
     }
     // the 8 exp-tile reads of the lane's column go out together and are waited for once (hipcc otherwise sinks each read
     // into the predicated store block of its row: eight serialised LDS round trips per chunk)
     float ev[8];
     if (NREG > 0) {
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) ev[rr] = et[(wave * 8 + rr) * EP + js];
+      for (int rr = 0; rr < 8; ++rr) ev[rr] = et[(wave_s * 8 + rr) * EP + js];
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ev[rr]));
     } else {   // streamed path: the 8 score gathers likewise (eight serialised HBM round trips per chunk otherwise)
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr, i = i0 + r;
+      const int r = wave_s * 8 + rr, i = i0 + r;
       const bool ok = i < a.N && jcol >= 0;
       float e;
       if (NREG > 0) {
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       }
       float an = Store<T>::round(e * rinv[rr]);
       float ad = Store<T>::round(an - oldv[rr]);
-      if (ok) Store<T>::store(st + (int64_t)i * a.Nk + jcol, an);
+      if (ok) st_store(st_off(i, jcol), an);
       an = ok ? an : 0.f;
       ad = ok ? ad : 0.f;
       Store<T>::store(An + r * P + lane, an);
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       }
       if (!ahead && k0 + FKC < cnt) load_v(k0 + FKC);   // flies during the MFMA sweep of this chunk
     } else {
-      for (int e = tid; e < a.dh * FKC; e += 256) {
+      for (int e = tid; e < DHC * FKC; e += 256) {
         const int d = e / FKC, jj = e - d * FKC, kk = k0 + jj;
         float vd = 0.f, vo = 0.f;
         if (kk < cnt) {
@@ -681,31 +695,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        redp[row * a.dh + (half + 2 * t) * 32 + lr] = Store<T>::round(acc[t][r]);
+        redp[row * DHC + (half + 2 * t) * 32 + lr] = Store<T>::round(acc[t][r]);
       }
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
-    const int e = tid + 256 * it, row = e / (a.dh / 8), c8 = (e - row * (a.dh / 8)) * 8;
+    const int e = tid + 256 * it, row = e / (DHC / 8), c8 = (e - row * (DHC / 8)) * 8;
     const int i = i0 + row;
     const bool ok = i < a.N;
-    const int64_t o = ((int64_t)b * a.N + (ok ? i : a.N - 1)) * a.D + h * a.dh + c8;
+    const uint32_t o = (uint32_t)((ok ? i : a.N - 1) * a.D + c8);   // element offset from this clip's rows / this head's channels
     Pv8 st8 = pvr[it];
     union { float4 v[2]; float f[8]; } o8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[row * a.dh + c8 + q]);  // += a~ . dv~
-      v = Store<T>::round(v + red2[row * a.dh + c8 + q]);                                 // += da~ . v_old
+      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[row * DHC + c8 + q]);  // += a~ . dv~
+      v = Store<T>::round(v + red2[row * DHC + c8 + q]);                                 // += da~ . v_old
       Store<T>::store(&st8.t[q], v);
       o8.f[q] = v;
     }
     if (ok) {
 #pragma unroll
-      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q) reinterpret_cast<uint4*>(pv + o)[q] = st8.u[q];
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q)
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(pv_bh) + (o * (uint32_t)sizeof(T) + 16u * q)) = st8.u[q];
       if (a.out_f32 != nullptr) {   // wave-uniform; NULL: the caller reads the (identical) values from the A.v state
-        reinterpret_cast<float4*>(a.out_f32 + o)[0] = o8.v[0];
-        reinterpret_cast<float4*>(a.out_f32 + o)[1] = o8.v[1];
+        char* const ob = reinterpret_cast<char*>(a.out_f32 + ((int64_t)b * a.N * a.D + h * DHC));
+        *reinterpret_cast<float4*>(ob + o * 4u) = o8.v[0];
+        *reinterpret_cast<float4*>(ob + (o * 4u + 16u)) = o8.v[1];
       }
     }
     if (a.norm_parts != nullptr) {   // wave-uniform
@@ -714,8 +730,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       float ss = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { const float d = o8.f[q] - nrr[it].f[q]; ss = fmaf(d, d, ss); }
-      for (int m = 1; m < a.dh / 8; m <<= 1) ss += __shfl_xor(ss, m, 64);
-      if (ok && (tid & (a.dh / 8 - 1)) == 0) a.norm_parts[((int64_t)b * a.N + i) * a.H + h] = ss;
+#pragma unroll
+      for (int m = 1; m < DHC / 8; m <<= 1) ss += __shfl_xor(ss, m, 64);
+      if (ok && (tid & (DHC / 8 - 1)) == 0) (a.norm_parts + ((int64_t)b * a.N * a.H + h))[(uint32_t)(i * a.H)] = ss;
     }
   }
 #ifdef EVT_PROF
