@@ -590,6 +590,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     // set1: this chunk's V pieces are in vpd1 / vpo1 (requested two chunks ahead); ahead: the NEXT chunk's pieces have
     // already been requested (into the other set), nothing to request here
     // ---- phase 2a: gather the chunk's columns for this wave's 8 rows (A delta gate) -------------
+    // `full`: predicated stores sit in exec-masked branches; hipcc cannot count them and the next counted wait -- the epilogue's,
+    // for the A.v state rows requested long ago -- became vmcnt(0): a whole store round trip in the open.
+    const bool full = i0 + FR <= a.N && k0 + FKC <= cnt;
     const int js = jcol >= 0 ? jcol : 0;
     float oldv[8];
 #pragma unroll
@@ -628,9 +631,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       }
       float an = Store<T>::round(e * rinv[rr]);
       float ad = Store<T>::round(an - oldv[rr]);
-      if (ok) st_store(st_off(i, jcol), an);
-      an = ok ? an : 0.f;
-      ad = ok ? ad : 0.f;
+      if (full) {   // (wave-uniform) every row of the tile and every column of the chunk exists: the reference store is unconditional
+        st_store(st_off(i, jcol), an);
+      } else {
+        if (ok) st_store(st_off(i, jcol), an);
+        an = ok ? an : 0.f;
+        ad = ok ? ad : 0.f;
+      }
       Store<T>::store(An + r * P + lane, an);
       Store<T>::store(Ad + r * P + lane, ad);
     }
@@ -669,6 +676,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     ATT_TICK(3);   // MFMA sweep (+ barrier)
   };
   if (PF > 0) {
+    // The A.v state rows and the next gate's reference (requested with `prefetch`, used in the epilogue) are claimed HERE, while no
+    // store is in flight: the reference stores of the chunk loop sit in conditional blocks hipcc cannot count, so the first wait
+    // behind them is vmcnt(0) -- in the epilogue that was a whole store round trip in the open.
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+#pragma unroll
+      for (int q = 0; q < (int)((8 * sizeof(T)) / 16); ++q)
+        asm volatile("" : "+v"(pvr[it].u[q].x), "+v"(pvr[it].u[q].y), "+v"(pvr[it].u[q].z), "+v"(pvr[it].u[q].w));
+      if (a.norm_ref != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          asm volatile("" : "+v"(nrr[it].v[q].x), "+v"(nrr[it].v[q].y), "+v"(nrr[it].v[q].z), "+v"(nrr[it].v[q].w));
+      }
+    }
     // the second chunk's V pieces go out now (the q.k^T fragment registers are free again) instead of during the first
     // chunk's MFMA sweep: at r = 128 (two chunks) nothing inside the chunk loop waits for HBM / L2 any more
     const bool two = vvec && cnt > FKC;
