@@ -444,8 +444,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       float mx = xv[rr][0];
 #pragma unroll
       for (int u = 1; u < NREG; ++u) mx = fmaxf(mx, xv[rr][u]);
-      rmax[rr] = wave_max_dpp(mx);
+      rmax[rr] = mx;
     }
+    wave_max_dpp_rows<8>(rmax);   // the eight rows' reductions step by step (same bits as wave_max_dpp per row)
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       float sum = 0.f;
@@ -455,8 +456,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
         if ((fullregs && u < NREG - 1) || lane + 64 * u < a.Nk) et[(wave_s * 8 + rr) * EP + lane + 64 * u] = e;
         sum += e;
       }
-      rsum[rr] = wave_sum_dpp(sum);
+      rsum[rr] = sum;
     }
+    wave_sum_dpp_rows<8>(rsum);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();  // each wave only ever reads back its own 8 rows
   } else {

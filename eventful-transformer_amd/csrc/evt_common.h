@@ -116,6 +116,37 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// The same reductions for NROW independent values at once, step by step across the rows: every DPP step of a row depends on the
+// previous one (two wait states each), and eight rows written one after the other left hipcc ~90 s_nop in the fused attention
+// kernel's statistics pass.  Per row the operations and their order are those of wave_max_dpp / wave_sum_dpp: same bits.
+template <int NROW>
+__device__ __forceinline__ void wave_max_dpp_rows(float* v) {
+  const float ninf = -INFINITY;
+#define EVT_ROWS_STEP(CTRL, RM, BM) _Pragma("unroll") for (int r = 0; r < NROW; ++r) v[r] = fmaxf(v[r], evt_dpp<CTRL, RM, BM>(ninf, v[r]));
+  EVT_ROWS_STEP(0x111, 0xf, 0xf)
+  EVT_ROWS_STEP(0x112, 0xf, 0xf)
+  EVT_ROWS_STEP(0x114, 0xf, 0xe)
+  EVT_ROWS_STEP(0x118, 0xf, 0xc)
+  EVT_ROWS_STEP(0x142, 0xa, 0xf)
+  EVT_ROWS_STEP(0x143, 0xc, 0xf)
+#undef EVT_ROWS_STEP
+#pragma unroll
+  for (int r = 0; r < NROW; ++r) v[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[r]), 63));
+}
+template <int NROW>
+__device__ __forceinline__ void wave_sum_dpp_rows(float* v) {
+#define EVT_ROWS_STEP(CTRL, RM, BM) _Pragma("unroll") for (int r = 0; r < NROW; ++r) v[r] += evt_dpp<CTRL, RM, BM>(0.f, v[r]);
+  EVT_ROWS_STEP(0x111, 0xf, 0xf)
+  EVT_ROWS_STEP(0x112, 0xf, 0xf)
+  EVT_ROWS_STEP(0x114, 0xf, 0xe)
+  EVT_ROWS_STEP(0x118, 0xf, 0xc)
+  EVT_ROWS_STEP(0x142, 0xa, 0xf)
+  EVT_ROWS_STEP(0x143, 0xc, 0xf)
+#undef EVT_ROWS_STEP
+#pragma unroll
+  for (int r = 0; r < NROW; ++r) v[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[r]), 63));
+}
+
 // j -> (j / gw, j % gw) without an integer division: (j + 0.5) / gw is at least 0.5/gw away from every
 // integer, far more than fp32 rounding for j < 2^20, gw <= 4096, so truncation is exact.
 __device__ __forceinline__ int fast_div(int j, float inv_gw) { return (int)(((float)j + 0.5f) * inv_gw); }
