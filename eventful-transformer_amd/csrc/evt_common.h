@@ -116,36 +116,40 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// The same reductions for NROW independent values at once, step by step across the rows: every DPP step of a row depends on the
-// previous one (two wait states each), and eight rows written one after the other left hipcc ~90 s_nop in the fused attention
+// The same reductions for NROW independent values at once, step by step across the rows, each step ONE instruction
+// (v_max_f32_dpp / v_add_f32_dpp with all three operands the row's register: lanes the step does not write keep their value, which
+// is what the builtin form expresses with `old` = -inf / 0).  Through __builtin_amdgcn_update_dpp + fmaxf hipcc emitted four
+// instructions per max step (copy, v_mov_b32_dpp, a canonicalising v_max x, x, x, v_max) and ~90 hazard nops in the fused attention
 // kernel's statistics pass.  Per row the operations and their order are those of wave_max_dpp / wave_sum_dpp: same bits.
+// Hazards (inline asm is invisible to hipcc's hazard recognizer): a DPP operand needs two wait states behind the VALU write of
+// its register -- NROW >= 3 rows interleaved provide them between steps; s_nop 1 in front of the first and behind the last step.
+#define EVT_DPP_ROWS_STEP(OP, CTRL)                                                                                  \
+  _Pragma("unroll") for (int r = 0; r < NROW; ++r) asm volatile(OP " %0, %0, %0 " CTRL : "+v"(v[r]));
+#define EVT_DPP_ROWS_ALL(OP)                                                                                         \
+  asm volatile("s_nop 1");                                                                                           \
+  EVT_DPP_ROWS_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                                      \
+  EVT_DPP_ROWS_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                                      \
+  EVT_DPP_ROWS_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xe")                                                      \
+  EVT_DPP_ROWS_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xc")                                                      \
+  EVT_DPP_ROWS_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                                   \
+  EVT_DPP_ROWS_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                                   \
+  asm volatile("s_nop 1");
 template <int NROW>
 __device__ __forceinline__ void wave_max_dpp_rows(float* v) {
-  const float ninf = -INFINITY;
-#define EVT_ROWS_STEP(CTRL, RM, BM) _Pragma("unroll") for (int r = 0; r < NROW; ++r) v[r] = fmaxf(v[r], evt_dpp<CTRL, RM, BM>(ninf, v[r]));
-  EVT_ROWS_STEP(0x111, 0xf, 0xf)
-  EVT_ROWS_STEP(0x112, 0xf, 0xf)
-  EVT_ROWS_STEP(0x114, 0xf, 0xe)
-  EVT_ROWS_STEP(0x118, 0xf, 0xc)
-  EVT_ROWS_STEP(0x142, 0xa, 0xf)
-  EVT_ROWS_STEP(0x143, 0xc, 0xf)
-#undef EVT_ROWS_STEP
+  static_assert(NROW >= 3, "interleaved rows cover the DPP wait states");
+  EVT_DPP_ROWS_ALL("v_max_f32_dpp")
 #pragma unroll
   for (int r = 0; r < NROW; ++r) v[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[r]), 63));
 }
 template <int NROW>
 __device__ __forceinline__ void wave_sum_dpp_rows(float* v) {
-#define EVT_ROWS_STEP(CTRL, RM, BM) _Pragma("unroll") for (int r = 0; r < NROW; ++r) v[r] += evt_dpp<CTRL, RM, BM>(0.f, v[r]);
-  EVT_ROWS_STEP(0x111, 0xf, 0xf)
-  EVT_ROWS_STEP(0x112, 0xf, 0xf)
-  EVT_ROWS_STEP(0x114, 0xf, 0xe)
-  EVT_ROWS_STEP(0x118, 0xf, 0xc)
-  EVT_ROWS_STEP(0x142, 0xa, 0xf)
-  EVT_ROWS_STEP(0x143, 0xc, 0xf)
-#undef EVT_ROWS_STEP
+  static_assert(NROW >= 3, "interleaved rows cover the DPP wait states");
+  EVT_DPP_ROWS_ALL("v_add_f32_dpp")
 #pragma unroll
   for (int r = 0; r < NROW; ++r) v[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[r]), 63));
 }
+#undef EVT_DPP_ROWS_ALL
+#undef EVT_DPP_ROWS_STEP
 
 // j -> (j / gw, j % gw) without an integer division: (j + 0.5) / gw is at least 0.5/gw away from every
 // integer, far more than fp32 rounding for j < 2^20, gw <= 4096, so truncation is exact.
