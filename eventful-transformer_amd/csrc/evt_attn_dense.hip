@@ -423,8 +423,7 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const DenseArgs a) {
       }
       mx[rr] = m;
     }
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) mx[rr] = wave_max_dpp(mx[rr]);
+    wave_max_dpp_rows<8>(mx);   // (one DPP instruction per step, the eight rows interleaved: evt_common.h)
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       float sum = 0.f;
@@ -435,8 +434,9 @@ __global__ __launch_bounds__(256, 3) void attn_dense_kernel(const DenseArgs a) {
       }
       rinv[rr] = sum;
     }
+    wave_sum_dpp_rows<8>(rinv);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) rinv[rr] = 1.0f / wave_sum_dpp(rinv[rr]);
+    for (int rr = 0; rr < 8; ++rr) rinv[rr] = 1.0f / rinv[rr];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();   // every lane has read the fp32 rows before anyone overwrites them with T
 #pragma unroll
