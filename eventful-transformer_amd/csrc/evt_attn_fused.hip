@@ -729,11 +729,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     const bool ok = i < a.N;
     const uint32_t o = (uint32_t)((ok ? i : a.N - 1) * a.D + c8);   // element offset from this clip's rows / this head's channels
     Pv8 st8 = pvr[it];
-    union { float4 v[2]; float f[8]; } o8;
+    union { float4 v[2]; float f[8]; } o8, r1, r2;
+    // the thread's 8 channels of both rounded products as 16-byte LDS reads (rows are DHC floats apart: the same banks -- element by
+    // element the 8 rows of a wave collided 8-way on every read)
+    r1.v[0] = *reinterpret_cast<const float4*>(red1 + row * DHC + c8);
+    r1.v[1] = *reinterpret_cast<const float4*>(red1 + row * DHC + c8 + 4);
+    r2.v[0] = *reinterpret_cast<const float4*>(red2 + row * DHC + c8);
+    r2.v[1] = *reinterpret_cast<const float4*>(red2 + row * DHC + c8 + 4);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + red1[row * DHC + c8 + q]);  // += a~ . dv~
-      v = Store<T>::round(v + red2[row * DHC + c8 + q]);                                 // += da~ . v_old
+      float v = Store<T>::round(Store<T>::load(&st8.t[q]) + r1.f[q]);  // += a~ . dv~
+      v = Store<T>::round(v + r2.f[q]);                                 // += da~ . v_old
       Store<T>::store(&st8.t[q], v);
       o8.f[q] = v;
     }
