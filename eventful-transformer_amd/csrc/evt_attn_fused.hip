@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   // The V tiles are idle before the chunk loop and after it; they double as
   float* qs = reinterpret_cast<float*>(Vd);            // [FR][dh] q rows for the rel-pos dots (prologue)
   float* red1 = reinterpret_cast<float*>(Vd);          // [FR][dh] round(a~ . dv~)          (epilogue)
-  float* red2 = red1 + FR * DHC;                       // [FR][dh] round(da~ . v_old)       (2*FR*dh*4 <= 2*dh*P*sizeof(T))
+  constexpr int RDP = DHC + 4;                         // row pitch of the two tiles: rows land 4 banks apart (16-byte reads of
+                                                       // neighbouring rows do not collide); 2 FR RDP floats <= the V tiles
+  static_assert((size_t)2 * FR * RDP * sizeof(float) <= (size_t)2 * DHC * P * sizeof(T), "the rounded-product tiles alias the V tiles");
+  float* red2 = red1 + FR * RDP;                       // [FR][RDP] round(da~ . v_old)
   const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        redp[row * DHC + (half + 2 * t) * 32 + lr] = Store<T>::round(acc[t][r]);
+        redp[row * RDP + (half + 2 * t) * 32 + lr] = Store<T>::round(acc[t][r]);
       }
   }
   __syncthreads();
@@ -732,10 +735,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     union { float4 v[2]; float f[8]; } o8, r1, r2;
     // the thread's 8 channels of both rounded products as 16-byte LDS reads (rows are DHC floats apart: the same banks -- element by
     // element the 8 rows of a wave collided 8-way on every read)
-    r1.v[0] = *reinterpret_cast<const float4*>(red1 + row * DHC + c8);
-    r1.v[1] = *reinterpret_cast<const float4*>(red1 + row * DHC + c8 + 4);
-    r2.v[0] = *reinterpret_cast<const float4*>(red2 + row * DHC + c8);
-    r2.v[1] = *reinterpret_cast<const float4*>(red2 + row * DHC + c8 + 4);
+    r1.v[0] = *reinterpret_cast<const float4*>(red1 + row * RDP + c8);
+    r1.v[1] = *reinterpret_cast<const float4*>(red1 + row * RDP + c8 + 4);
+    r2.v[0] = *reinterpret_cast<const float4*>(red2 + row * RDP + c8);
+    r2.v[1] = *reinterpret_cast<const float4*>(red2 + row * RDP + c8 + 4);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float v = Store<T>::round(Store<T>::load(&st8.t[q]) + r1.f[q]);  // += a~ . dv~
