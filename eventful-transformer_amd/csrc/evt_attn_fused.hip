@@ -51,6 +51,9 @@ struct FusedArgs {
 };
 
 constexpr int QKC = 64;       // QK mode: keys per chunk (16 per wave)
+// Row pitch (floats) of the score / exp tile: 4 x an odd number -- rows are 16-byte aligned (the q.k^T phase stores 4 consecutive
+// keys of a row as one ds_write_b128) and 16 consecutive rows start 4 (mod 64) x odd banks apart: those stores are conflict-free.
+__host__ __device__ inline int fused_ep(int Nk) { return 4 * (((Nk + 3) >> 2) | 1); }
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 // TPW = 32-column tiles per wave = dh / 64.  NREG > 0: N <= 64*NREG and the 8 rows a wave owns are held
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
                                                        // neighbouring rows do not collide); 2 FR RDP floats <= the V tiles
   static_assert((size_t)2 * FR * RDP * sizeof(float) <= (size_t)2 * DHC * P * sizeof(T), "the rounded-product tiles alias the V tiles");
   float* red2 = red1 + FR * RDP;                       // [FR][RDP] round(da~ . v_old)
-  const int EP = a.Nk | 1;                              // odd pitch: row-strided LDS access conflict-free
+  const int EP = fused_ep(a.Nk);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same value in a scalar register: row indices of a wave are wave-uniform
@@ -353,10 +356,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
           for (int p_ = 0; p_ < 4; ++p_)
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr) {
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].x, kf[p_].x, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].y, kf[p_].y, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].z, kf[p_].z, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[hr][p_].w, kf[p_].w, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].x, qf[hr][p_].x, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].y, qf[hr][p_].y, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].z, qf[hr][p_].z, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[p_].w, qf[hr][p_].w, sacc[hr], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -365,18 +368,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
             split8(kf[2 * m], kf[2 * m + 1], &kh, &kl);
 #pragma unroll
             for (int hr = 0; hr < 2; ++hr) {
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[hr][m], kh, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kl, sacc[hr], 0, 0, 0);
-              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[hr][m], kh, sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[hr][m], sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[hr][m], sacc[hr], 0, 0, 0);
+              sacc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[hr][m], sacc[hr], 0, 0, 0);
             }
           }
         }
-        const int j = n0 + l15;
-        if (j < a.N) {
+        // Keys are the A operand, the q rows the B operand: a lane holds, of query row 16 hr + l15, the scores of the 4 consecutive
+        // keys n0 + 4 kg .. + 3 -- one 16-byte LDS store per row group instead of four 4-byte ones per row.  (Columns in [N, EP) take
+        // the scores of the clamped / staged rows past N: nobody reads them.)
+        const int j4 = n0 + 4 * kg;
+        if (j4 < EP) {
 #pragma unroll
           for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) et[(hr * 16 + 4 * kg + r) * EP + j] = sacc[hr][r];
+            *reinterpret_cast<f32x4_acc*>(et + (hr * 16 + l15) * EP + j4) = sacc[hr];
         }
       }
     };
@@ -784,7 +789,7 @@ template <typename T>
 int launch_fused(const FusedArgs& a, void* stream) {
   constexpr int P = Tile<T>::PITCH;
   const int nreg = (a.Nk + 63) / 64;
-  const size_t tile_e = nreg <= 4 ? (size_t)FR * (a.Nk | 1) : 0;        // exp tile; q rows and the rounded-product
+  const size_t tile_e = nreg <= 4 ? (size_t)FR * fused_ep(a.Nk) : 0;   // exp tile; q rows and the rounded-product
   static_assert(2 * FR * sizeof(float) <= 2 * P * sizeof(T), "red tiles must fit in the V tiles");  // tiles alias Vd/Vo
   const size_t lds = (size_t)(2 * FR + 2 * a.dh) * P * sizeof(T) + (tile_e + FR * (a.gh + a.gw)) * sizeof(float);
   const dim3 grid((a.N + FR - 1) / FR, a.B * a.H);
