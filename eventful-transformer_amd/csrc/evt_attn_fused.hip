@@ -280,9 +280,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     // chunk through a staging block of its own (no workgroup barrier; the next chunk's rows are in flight in registers
     // meanwhile).  The staging blocks live in the A / V tiles, which are idle until the chunk loop.
     constexpr int KP = 68;   // fp32 row pitch: 16 rows x 4 dwords of a fragment read cover the 64 banks once
-    static_assert((size_t)(FR + 4 * 16) * KP * sizeof(float) <= (size_t)(2 * FR + 2 * 64) * P * sizeof(T), "operand staging fits the A / V tiles");
-    float* qst = reinterpret_cast<float*>(smem_raw);            // [FR][KP] q rows / scale
-    float* kst = qst + FR * KP + wave * 16 * KP;                // [16][KP] this wave's keys of the current chunk
+    constexpr int QPB = 64 + 8;  // bf16 row pitch of the split q planes: 144-byte rows, conflict-free 16-byte reads over 16-lane groups
+    constexpr size_t QREG = (QK == 2) ? (size_t)2 * FR * QPB * 2 : (size_t)FR * KP * sizeof(float);   // bytes of the q staging block
+    static_assert(QREG % 16 == 0 && QREG + (size_t)4 * 16 * KP * sizeof(float) <= (size_t)(2 * FR + 2 * 64) * P * sizeof(T), "operand staging fits the A / V tiles");
+    float* qst = reinterpret_cast<float*>(smem_raw);            // [FR][KP] q rows / scale (exact mode)
+    float* kst = reinterpret_cast<float*>(smem_raw + QREG) + wave * 16 * KP;   // [16][KP] this wave's keys of the current chunk
     float4 qg[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -313,23 +315,41 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
     EVT_LOAD_KRAW(0, kr0, kr1, kr2, kr3);
     EVT_LOAD_KRAW(QKC, ks0, ks1, ks2, ks3);   // (past N: clamped re-reads of the last row, never used)
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + 256 * u;
-      *reinterpret_cast<float4*>(qst + (e >> 4) * KP + 4 * (e & 15)) = scaled(qg[u]);
-    }
-    __syncthreads();
+    // Split mode: the q rows are split into bf16 hi | lo ONCE, by the thread that loaded the piece, and staged as two planes (pitch
+    // QPB: 144-byte rows, conflict-free 16-byte reads over 16-lane groups) -- every wave reads all 32 rows' fragments, and splitting
+    // them after the read was the same 96 VALU instructions four times over, behind the barrier.  Exact mode: fp32 rows as before.
+    __bf16* const qsh = reinterpret_cast<__bf16*>(smem_raw);    // [FR][QPB] hi plane (split mode)
+    __bf16* const qsl = qsh + FR * QPB;                          // [FR][QPB] lo plane
     float4 qf[2][4];
-#pragma unroll
-    for (int hr = 0; hr < 2; ++hr)
-#pragma unroll
-      for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qst + (hr * 16 + l15) * KP + chan(p_));
     bf16x8_t qh[2][2], ql[2][2];
     if (QK == 2) {
 #pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        bf16x4_t h4, l4;
+        split4(scaled(qg[u]), &h4, &l4);
+        *reinterpret_cast<bf16x4_t*>(qsh + (e >> 4) * QPB + 4 * (e & 15)) = h4;
+        *reinterpret_cast<bf16x4_t*>(qsl + (e >> 4) * QPB + 4 * (e & 15)) = l4;
+      }
+      __syncthreads();
+#pragma unroll
       for (int hr = 0; hr < 2; ++hr)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) split8(qf[hr][2 * m], qf[hr][2 * m + 1], &qh[hr][m], &ql[hr][m]);
+        for (int m = 0; m < 2; ++m) {
+          qh[hr][m] = *reinterpret_cast<const bf16x8_t*>(qsh + (hr * 16 + l15) * QPB + 32 * m + 8 * kg);
+          ql[hr][m] = *reinterpret_cast<const bf16x8_t*>(qsl + (hr * 16 + l15) * QPB + 32 * m + 8 * kg);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        *reinterpret_cast<float4*>(qst + (e >> 4) * KP + 4 * (e & 15)) = scaled(qg[u]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) qf[hr][p_] = *reinterpret_cast<const float4*>(qst + (hr * 16 + l15) * KP + chan(p_));
     }
     // raw rows -> the wave's staging block -> this lane's fragment pieces (wave-private: only the wave's own LDS traffic is waited for)
     float4 kf[4];
