@@ -647,6 +647,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) asm volatile("" : "+v"(ev[rr]));
     }
+    if (NREG > 0 && full) {
+      // every row of the tile and every column of the chunk exists: straight-line code for the eight rows (no per-row exec-mask
+      // block), the rounded values' bits reused for the stores
+      const uint32_t jb = (uint32_t)jcol * (uint32_t)sizeof(T);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave_s * 8 + rr;
+        const float an = Store<T>::round(ev[rr] * rinv[rr]);
+        const float ad = Store<T>::round(an - oldv[rr]);
+        st_store((uint32_t)((i0 + r) * a.Nk) * (uint32_t)sizeof(T) + jb, an);
+        Store<T>::store(An + r * P + lane, an);
+        Store<T>::store(Ad + r * P + lane, ad);
+      }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave_s * 8 + rr, i = i0 + r;
@@ -670,6 +684,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
       }
       Store<T>::store(An + r * P + lane, an);
       Store<T>::store(Ad + r * P + lane, ad);
+    }
     }
     ATT_TICK(5);   // 2a: old values, exp tile reads, A gate, scattered state stores, LDS stores
     // ---- phase 2b: stage the chunk of dv~^T and v_old^T (k contiguous; requested one chunk ahead) ----
