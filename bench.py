@@ -1018,11 +1018,24 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
             serial_step()   # untimed: the serial order's own first-call effects (allocator growth of `model.clip`) stay out of the pass below
             torch.cuda.synchronize()
             _native.set_kernel_events(timed_kernel, events)
+            second = [] if (events is not None and timed_kernel == "gemm") else None   # the second kernel family of the step: attention
+            if second is not None:
+                _native.set_kernel_events("attn", second)
             t0 = time.perf_counter()
             out_serial = serial_step()
             torch.cuda.synchronize()
             w["serial_pass_s"] = time.perf_counter() - t0
             _native.set_kernel_events(timed_kernel, None)
+            if second is not None:
+                _native.set_kernel_events("attn", None)
+                ms2 = sum(ev[0].elapsed_time(ev[1]) for ev in second)
+                n2 = sum(ev[3] for ev in second)
+                if n2:
+                    gbs = sum(_native.event_work(ev) for ev in second) / (ms2 * 1e-3) / 1e9
+                    w["attention_family"] = {"kernel": "softmax_av_gated_kernel (the gated frames' fused attention launches)",
+                                             "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(gbs, 1), "unit": "GB/s",
+                                             "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4), "bound": "hbm (algorithmic bytes)",
+                                             "share_of_step_time": round(ms2 * 1e-3 / w["serial_pass_s"], 3)}
             w["overlap_bit_identical"] = bool(torch.equal(out_overlapped, out_serial))
         else:
             _native.set_kernel_events(timed_kernel, events)
@@ -1562,6 +1575,7 @@ def main():
                        "launch": ("hip-graph replay" if args.graphs else "eager") +
                                  (f", {len(w['lanes'])} resident batches in flight on {len(w['lanes'])} HIP streams" if w.get("lanes") else "")},
             "roofline": roofline,
+            "second_kernel_family": w.get("attention_family"),   # same serial pass, HIP events: the fused attention launches
             "gpu_clock_mhz": sampler.summary() if sampler is not None else None,
         }
         if w.get("lanes"):
