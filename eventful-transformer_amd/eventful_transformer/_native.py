@@ -21,12 +21,13 @@ ACT_NONE, ACT_GELU = 0, 1
 _STORE_OF = {torch.float32: EVT_F32, torch.bfloat16: EVT_BF16, torch.float16: EVT_F16}
 
 # Every symbol include/evt_abi.h declares (tests check that the .so exports all of them).
-ABI_VERSION = 8   # include/evt_abi.h EVT_ABI_VERSION
+ABI_VERSION = 9   # include/evt_abi.h EVT_ABI_VERSION
 ABI_SYMBOLS = (
     "evt_version", "evt_last_error_string", "evt_target_arch", "evt_row_pass", "evt_row_pass_ord", "evt_select_topk",
     "evt_select_threshold", "evt_select_topk_sq", "evt_select_threshold_sq", "evt_gate_gather_update", "evt_scatter_rows", "evt_gated_linear",
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
+    "evt_attention_gated", "evt_attention_gated_fits", "evt_attention_gated_tile_bytes",
 )
 
 
@@ -125,6 +126,15 @@ class StreamPrepDesc(Structure):
     ]
 
 
+class AttnGatedDesc(Structure):
+    _fields_ = [
+        ("qkv", c_void_p), ("a_tiles", c_void_p), ("idx", c_void_p), ("count", c_void_p), ("kcap", c_int32),
+        ("v_state", c_void_p), ("pv", c_void_p), ("out_f32", c_void_p), ("norm_ref", c_void_p), ("norm_parts", c_void_p),
+        ("B", c_int32), ("H", c_int32), ("N", c_int32), ("D", c_int32), ("store", c_int32), ("scale", c_float),
+        ("qk_split", c_int32), ("first", c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -145,6 +155,10 @@ def _bind(lib):
     lib.evt_attention_stream_key_blocks.restype = c_int64
     lib.evt_attention_dense_resident.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.evt_attention_dense_resident.restype = c_int
+    lib.evt_attention_gated_fits.argtypes = [c_int32, c_int32, c_int32, c_int32, c_int32]
+    lib.evt_attention_gated_fits.restype = c_int
+    lib.evt_attention_gated_tile_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.evt_attention_gated_tile_bytes.restype = c_int64
     sigs = {
         "evt_row_pass": [P, P, I, P, P, P, F, P, P, P, I, I, P],
         "evt_row_pass_ord": [P, P, I, P, P, P, F, P, P, P, I, I, I, P],
@@ -168,6 +182,7 @@ def _bind(lib):
         "evt_attention_dense": [POINTER(AttnDenseDesc), P],
         "evt_attention_stream": [POINTER(AttnStreamDesc), P],
         "evt_stream_prep": [POINTER(StreamPrepDesc), P],
+        "evt_attention_gated": [POINTER(AttnGatedDesc), P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -628,6 +643,54 @@ def attention_stream(qkv, a_state_t, pv, B, H, N, D, scale, store, first, rel_te
     else:
         per_row = 2.0 * es * H * N + 2.0 * es * D
         fixed = B * (4.0 * (N + nk) * D + rel_b + 2.0 * es * N * D + (4.0 * N * D if out_f32 is not None else 0.0))
+        _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0), call, count=count, per_row=per_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# K10 (evt_attention_gated): EventfulBlock's attention for <= 256 tokens, one workgroup per (clip, head), value gate included.
+# The gate reference lives in a TILED layout (include/evt_abi.h): (B, H, NT, NT, 2, 2, 32, 2, 4) = per (row tile, key block) a
+# 2 KB tile [t = c / 16][half = c / 4 % 2][row][g2 = c / 8 % 2][e = c % 4] for key-in-block c.
+# ------------------------------------------------------------------------------------------------
+def attention_gated_fits(N, D, H, store):
+    return bool(load().evt_attention_gated_fits(N, D, H, store, int(QK_SPLIT))) and FUSED_QK
+
+
+def gated_tiles_empty(B, H, N, dtype, device):
+    nt = (N + 31) // 32
+    t = torch.empty((B, H, nt, nt, 2, 2, 32, 2, 4), dtype=dtype, device=device)
+    assert t.numel() * t.element_size() == load().evt_attention_gated_tile_bytes(B, H, N)
+    return t
+
+
+def tiles_to_logical(tiles, N):
+    """Tiled gate reference -> the logical (B, H, N, N) tensor (a copy)."""
+    B, H, nt = tiles.shape[:3]
+    return tiles.permute(0, 1, 2, 6, 3, 4, 7, 5, 8).reshape(B, H, nt * 32, nt * 32)[:, :, :N, :N].contiguous()
+
+
+def logical_to_tiles(p, tiles):
+    """Writes a logical (B, H, N, N) tensor into the tiled gate reference (padding rows / keys become zero)."""
+    B, H, nt = tiles.shape[:3]
+    N = p.shape[-1]
+    padded = torch.zeros((B, H, nt * 32, nt * 32), dtype=tiles.dtype, device=tiles.device)
+    padded[:, :, :N, :N] = p.to(device=tiles.device, dtype=tiles.dtype)
+    tiles.permute(0, 1, 2, 6, 3, 4, 7, 5, 8).copy_(padded.view(B, H, nt, 32, nt, 2, 2, 2, 4))
+
+
+def attention_gated(qkv, a_tiles, v_state, pv, B, H, N, D, scale, store, first, idx=None, count=None, kcap=0, out_f32=None,
+                    norm_ref=None, norm_parts=None):
+    d = AttnGatedDesc(_p(qkv), _p(a_tiles), _p(idx), _p(count), kcap, _p(v_state), _p(pv), _p(out_f32), _p(norm_ref), _p(norm_parts),
+                      B, H, N, D, store, float(scale), 1, int(first))
+    # algorithmic bytes: q, k read once (8 N D); per selected key its reference column read + rewritten, its value row read and
+    # its value-reference row read-modify-written; A.v state read-modify-write (first frame: written); fp32 output
+    es = 2
+    call = lambda: _check(load().evt_attention_gated(ctypes.byref(d), _stream()))   # noqa: E731
+    out_b = 4.0 * N * D if out_f32 is not None else 0.0
+    if first:
+        _timed("attn", B * (12.0 * N * D + 1.0 * es * H * N * N + 2.0 * es * N * D + out_b), call)
+    else:
+        per_row = 2.0 * es * H * N + 4.0 * D + 2.0 * es * D
+        fixed = B * (8.0 * N * D + 2.0 * es * N * D + out_b)
         _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0), call, count=count, per_row=per_row)
 
 

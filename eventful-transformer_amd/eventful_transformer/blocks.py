@@ -802,6 +802,9 @@ class EventfulBlock(EventfulMatmul1Block):
             _, _, gh_, gw_, _ = self._rel_tables()
             if _native.attention_stream_fits(N, D, H, store, gh_, gw_):
                 return self._attention_stream(qkv, idx, count, cap, B, N)
+        if self.pool_size is None and self.relative_position is None and _native.attention_gated_fits(N, D, H, store) and \
+                (ag._tiles is not None or (acc.first and idx is None and self.matmul_accumulator_1.first)):
+            return self._attention_resident(qkv, idx, count, cap, B, N)
         if acc.first and idx is None and self.matmul_accumulator_1.first:
             a_state = torch.empty((B, H, N, N), dtype=sdt, device=qkv.device)
             pv = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
@@ -896,6 +899,52 @@ class EventfulBlock(EventfulMatmul1Block):
             if acc.count_mode:
                 acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
             acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+        return attn, None, fused
+
+    def _attention_resident(self, qkv, idx, count, cap, B, N):
+        """At most 256 tokens, head dim 64, a 16-bit `matmul_2_cast`, no relative position (every ViViT frame): ONE
+        evt_attention_gated launch per frame -- value delta gate, scores from the token buffer, softmax, A delta gate and both
+        accumulator products (blocks.py:558-575), one workgroup per (clip, head).  `matmul_gate.p` lives in the kernel's tiled layout
+        (`_GateBase.use_tiles`: reads return the logical tensor), `matmul_accumulator_1.product` is refreshed lazily if read."""
+        D, H = self.dim, self.heads
+        dh = D // H
+        sdt = self._store_dtype()
+        store = _native.store_code(sdt)
+        vg, ag, acc, acc1 = self.v_gate, self.matmul_gate, self.matmul_accumulator_2, self.matmul_accumulator_1
+        attn = self._ws("attn_out", (B, N, D), torch.float32, qkv)
+        if acc.first:
+            vg.first = ag.first = acc.first = acc1.first = False
+            ag.use_tiles(_native.gated_tiles_empty(B, H, N, sdt, qkv.device), N)
+            vg._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            acc._state = torch.empty((B, N, D), dtype=sdt, device=qkv.device)
+            vg.p = vg._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            acc.product = acc._state.view(B, N, H, dh).permute(0, 2, 1, 3)
+            _native.attention_gated(qkv, ag._tiles, vg._state, acc._state, B, H, N, D, self.scale, store, True, out_f32=attn)
+            self._defer_scores(B, N)
+            acc1.matmul.count_product(B * H * N * N, dh)
+            acc.matmul.count_product(B * H * N * dh, N)
+            return attn, None, None
+        pg = self.projection_gate
+        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
+        nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
+        state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
+        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+                and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
+            cap_p = pg.policy.capacity(N)
+            state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
+        _native.attention_gated(qkv, ag._tiles, vg._state, acc._state, B, H, N, D, self.scale, store, False, idx=idx, count=count,
+                                kcap=cap, out_f32=None if state_src else attn, norm_ref=pg.p if fuse_norm else None, norm_parts=nparts)
+        self._defer_scores(B, N)
+        if self.count_mode or acc.count_mode or vg.count_mode or acc1.matmul.count_mode:
+            n = self._n_rows(B, cap, count)
+            if acc1.matmul.count_mode:   # the reference's delta update of the q.k^T state (modules.py:232-247)
+                acc1.matmul.count_product(2 * H * N * n, dh)
+            self._count_gate(vg, B * N * D)
+            self._count_gate(ag, B * H * N * N)
+            if acc.count_mode:
+                acc.counts["accumulator_flops"] += n * D + 2 * B * N * D
+            acc.matmul.count_product(2 * B * N * D, n // B if B else 0)
+        fused = dict(norm_parts=(nparts, H) if fuse_norm else None, state_src=acc._state if state_src else None)
         return attn, None, fused
 
     def _attention_stream(self, qkv, idx, count, cap, B, N):

@@ -39,6 +39,9 @@ def _index_i32(index, lead, device):
 
 
 class _GateBase(ExtendedModule):
+    _tiles = None   # (EventfulBlock.matmul_gate on evt_attention_gated) the reference in the kernel's tiled layout
+    _p = None
+
     def __init__(self, structure="row"):
         super().__init__()
         assert structure in ["row", "col"]
@@ -48,9 +51,33 @@ class _GateBase(ExtendedModule):
         self.p = None
         self._state_t = None   # EventfulBlock's large-N path keeps the "col" gate reference transposed; `p` is a view of it
 
+    # `p` is the reference's state attribute (modules.py:122).  EventfulBlock's <= 256-token attention kernel keeps the "col" gate's
+    # reference in a tiled layout (`use_tiles`): reading `p` then returns the logical (B,H,N,N) tensor as a COPY, assigning a tensor
+    # of that shape writes it into the tiles (a documented deviation: in-place edits of the returned tensor do not reach the state).
+    @property
+    def p(self):
+        if self._tiles is not None:
+            return _native.tiles_to_logical(self._tiles, self._tiles_n)
+        return self._p
+
+    @p.setter
+    def p(self, value):
+        if self._tiles is not None and torch.is_tensor(value) and value.ndim == 4 and value.shape[-1] == value.shape[-2] == self._tiles_n \
+                and tuple(value.shape[:2]) == tuple(self._tiles.shape[:2]):
+            _native.logical_to_tiles(value, self._tiles)
+            return
+        self._tiles = None
+        self._p = value
+
+    def use_tiles(self, tiles, n):
+        """The reference lives in `tiles` (evt_attention_gated layout) from now on; `p` reads / writes go through it."""
+        self._p = None
+        self._tiles, self._tiles_n = tiles, n
+
     def reset_self(self):
         self.first = True
         self.p = None
+        self._tiles = None
         self._state_t = None
 
     # -- selection --------------------------------------------------------------------------------

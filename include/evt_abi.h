@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EVT_ABI_VERSION 8   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
+#define EVT_ABI_VERSION 9   /* 2: split-K workspace fields, evt_qk_desc.split, evt_attention_dense, workspace query;
                                  3: evt_split_weights(rows, cols) writes the hl32 layout, evt_split_weights_bytes;
                                  4: evt_rel_terms, evt_softmax_av_desc.rel_terms, evt_linear_desc.a_bf16,
                                     evt_gated_linear_big_tile;
@@ -48,7 +48,11 @@ extern "C" {
                                  8: evt_attn_stream_desc.kv / Nk, evt_stream_prep_desc.kv / Nk (pooled keys and values in
                                     evt_attention_stream and its preparation launch); REMOVED: the embedded selection of ABI 5
                                     (sel_* fields, evt_gated_linear_embeds_select) -- measured slower than the selection launch
-                                    in every configuration */
+                                    in every configuration;
+                                 9: evt_attention_gated (+ _fits, _tile_bytes): the attention of EventfulBlock for <= 256 tokens,
+                                    one workgroup per (clip, head), value gate included, gate reference in a tiled layout;
+                                    evt_gate_cols / evt_scatter_cols (column-structured stand-alone gate / buffer),
+                                    evt_ats_scores / evt_ats_stabilize (adaptive token sampling), evt_gather_rows_map */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -523,6 +527,50 @@ EVT_API int evt_attention_dense(const evt_attn_dense_desc* d, void* stream);
 /* 1 when a launch of this shape WITHOUT state outputs runs the resident kernel (one workgroup per (group, head), the group's K / V
  * planes staged once: they must fit a CU's LDS); gh = gw = 0: no relative position.  Shape-only. */
 EVT_API int evt_attention_dense_resident(int32_t N, int32_t gh, int32_t gw, int32_t store, int32_t qk_split);
+
+
+/* ------------------------------------------------------------------------------------------ *
+ * K10 (ABI 9).  The attention of EventfulBlock for AT MOST 256 TOKENS (every ViViT frame), resident form: one workgroup per
+ * (clip, head), first frame or gated frame in ONE launch, the value delta gate included.  Replaces evt_v_gate +
+ * evt_softmax_av_gated (gated frames) and evt_attention_dense(state outputs) + evt_v_gate (first frame) where it applies:
+ *
+ *   first=0  v~ = round(v[idx]); dv~ = round(v~ - v_state[idx]); v_old = round(v~ - dv~); v_state[idx] = v~
+ *                                                               (TokenDeltaGate rows, modules.py:187-201; blocks.py:561-567)
+ *            x = (q / scale) k^T from the packed token buffer, softmax over the keys              (blocks.py:514-522)
+ *            a~ = round(softmax(x))[:, idx]; da~ = round(a~ - ref[:, idx]); ref[:, idx] = a~       ("col" gate, modules.py:187-201)
+ *            pv += round(a~ . dv~); pv += round(da~ . v_old); out = pv, heads merged              (modules.py:285-295)
+ *   first=1  ref = round(softmax(x)); v_state = round(v); pv = out = round(ref . v_state)         (modules.py:183-185, 277-283)
+ *
+ * The head's keys (bf16 hi | lo planes) and value operands are staged once in LDS; the value operands are scattered into
+ * full-length [channel][key] planes with zero columns for the keys that are not selected, so the accumulator products contract
+ * over all keys and the probabilities never leave the matrix-core register layout.
+ *
+ * a_tiles is the gate reference (matmul_gate.p) in a TILED layout, evt_attention_gated_tile_bytes(B, H, N) bytes: per (clip, head)
+ * NT x NT tiles (NT = ceil(N / 32)) of 32 query rows x 32 keys, tile (rt, kb) at ((b H + h) NT + rt) NT + kb, 2 KB each; element
+ * (row r, key c) of a tile at 512 (c / 16) + 8 (32 (c / 4 % 2) + r) + 4 (c / 8 % 2) + c % 4.  Rows / keys past N are padding
+ * (written, never meaningful).  The host exposes the logical (B,H,N,N) tensor (eventful_transformer/modules.py).
+ * Head dim 64, 16-bit store type, qk_split = 1 (q, k as bf16 hi + lo, three bf16 MFMAs per product); idx ascending, no duplicates.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct evt_attn_gated_desc {
+  const float* qkv;                       /* (B,N,3D) packed token buffer (qkv_accumulator.b), selected rows already updated */
+  void* a_tiles;                          /* tiled gate reference, store type (see above)                       */
+  const int32_t* idx; const int32_t* count; int32_t kcap;   /* gated frame: selected keys (B,kcap), 0 < kcap <= N */
+  void* v_state;                          /* (B,N,D) store type: v_gate.p, read-modify-written (first: written)  */
+  void* pv;                               /* (B,N,D) store type: matmul_accumulator_2.product                   */
+  float* out_f32;                         /* (B,N,D), nullable: the output equals the pv state, widened          */
+  const float* norm_ref; float* norm_parts;   /* nullable pair: see evt_softmax_av_desc                          */
+  int32_t B, H, N, D;
+  int32_t store;                          /* EVT_BF16 or EVT_F16                                                */
+  float scale;                            /* q / scale (blocks.py:514)                                          */
+  int32_t qk_split;                       /* must be 1                                                          */
+  int32_t first;                          /* 1 = first frame of a clip                                          */
+} evt_attn_gated_desc;
+
+EVT_API int evt_attention_gated(const evt_attn_gated_desc* d, void* stream);
+/* 1 when evt_attention_gated takes this shape / store type / score arithmetic.  Shape-only. */
+EVT_API int evt_attention_gated_fits(int32_t N, int32_t D, int32_t H, int32_t store, int32_t qk_split);
+/* Bytes of the tiled gate reference. */
+EVT_API int64_t evt_attention_gated_tile_bytes(int32_t B, int32_t H, int32_t N);
 
 #ifdef __cplusplus
 }

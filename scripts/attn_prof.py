@@ -18,6 +18,7 @@ ap.add_argument("--clips", type=int, default=256)
 ap.add_argument("--dense", choices=["vivit", "window"], default=None,
                 help="K8 (evt_attention_dense) instead: vivit = first frame of a clip (B clips, N = 197, bf16, states written); "
                      "window = ViTDet 14 x 14 windows of a 42 x 42 frame (fp32, rel-pos)")
+ap.add_argument("--gated", action="store_true", help="K10 (evt_attention_gated): ViViT-B gated frame, one workgroup per (clip, head)")
 ap.add_argument("--vitdet", action="store_true", help="one stream, N = 1764 (42 x 42 grid, rel-pos), k = 256, fp32 store, score state read from HBM")
 a = ap.parse_args()
 if a.dense is not None:
@@ -62,6 +63,34 @@ if a.dense is not None:
     print(f"K8 {a.dense}: wave 0 of one workgroup: {tot} ticks")
     for q, nm in enumerate(names):
         print(f"   {nm:30s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")
+    sys.exit(0)
+if a.gated:
+    B, N, D, H, k = a.clips, 197, 768, 12, 128
+    dev = torch.device("cuda", 0)
+    sdt = torch.bfloat16
+    store = n.store_code(sdt)
+    g = torch.Generator(device=dev).manual_seed(0)
+    qkv = torch.randn(B, N, 3 * D, device=dev, generator=g)
+    p = torch.randn(B, N, D, device=dev, generator=g)
+    idx = torch.stack([torch.randperm(N, device=dev, generator=g)[:k].sort()[0] for _ in range(B)]).int().contiguous()
+    tiles = n.gated_tiles_empty(B, H, N, sdt, dev)
+    tiles.zero_()
+    vp = torch.randn(B, N, D, device=dev, generator=g).to(sdt)
+    pv = torch.zeros(B, N, D, device=dev, dtype=sdt)
+    nparts = torch.empty(B, N, H, device=dev)
+    for _ in range(100):
+        n.attention_gated(qkv, tiles, vp, pv, B, H, N, D, 8.0, store, False, idx=idx, kcap=k, norm_ref=p, norm_parts=nparts)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 12)()
+    lib = n.load()
+    lib.evt_debug_prof_gated.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    assert lib.evt_debug_prof_gated(buf) == 0
+    names = ["requests issued", "zero fill + barrier", "planes written (K split, value gate) + barrier", "q fragments + S^T products",
+             "softmax", "pack + pass 1 (a~ . dv~)", "pass 2 (A gate, da~ . v_old, tile stores)", "epilogue"]
+    tot = sum(buf[q] for q in range(8))
+    print(f"K10 gated frame: wave 0 of one workgroup: {tot} ticks")
+    for q, nm in enumerate(names):
+        print(f"   {nm:48s} {buf[q]:8d}  {100.0 * buf[q] / max(1, tot):5.1f} %")
     sys.exit(0)
 B, N, D, H, k = (1, 1764, 768, 12, 256) if a.vitdet else (a.clips, 197, 768, 12, 128)
 dev = torch.device("cuda", 0)

@@ -76,6 +76,12 @@ def main():
     n.v_gate(qkv, idx, None, B, N, D, k, vp, vd_t, vo_t, store, True, transposed=True)
     n.v_gate(qkv, idx, None, B, N, D, k, vp, vd, vo, store, True)
 
+    tiles = None
+    if sdt != torch.float32 and n.attention_gated_fits(N, D, H, store):
+        tiles = n.gated_tiles_empty(B, H, N, sdt, dev)
+        n.logical_to_tiles(ap_, tiles)
+    fused_bytes = B * H * N * (2 * es * k) + B * N * D * (8 + 2 * es) + B * k * D * (4 + 2 * es)   # reference columns, q / k, A.v state, value gate
+
     M = B * k
     Sq, Sp, S1, S2 = (n.split_weight(t) for t in (Wqkv, Wp, W1, W2))
     cases = {
@@ -121,6 +127,14 @@ def main():
         "softmax_av_fused_qk_norm": (lambda: n.softmax_av_gated(None, ap_, idx, None, k, vd_t, vo_t, pv, out, B, H, N, D, store, qkv=qkv, scale=8.0,
                                                                 norm_ref=p, norm_parts=nparts),
                                      ("GB/s", B * H * N * (2 * es * k) + B * N * D * (8 + 4 + 4 + 2 * es))),
+        "gated_resident_norm_noout": (lambda: n.attention_gated(qkv, tiles, vp, pv, B, H, N, D, 8.0, store, False, idx=idx, kcap=k, norm_ref=p, norm_parts=nparts),
+                                      ("GB/s", fused_bytes + 4 * B * N * D)),
+        "gated_resident_norm": (lambda: n.attention_gated(qkv, tiles, vp, pv, B, H, N, D, 8.0, store, False, idx=idx, kcap=k, out_f32=out, norm_ref=p, norm_parts=nparts),
+                                ("GB/s", fused_bytes + 8 * B * N * D)),
+        "gated_resident_plain": (lambda: n.attention_gated(qkv, tiles, vp, pv, B, H, N, D, 8.0, store, False, idx=idx, kcap=k, out_f32=out),
+                                 ("GB/s", fused_bytes + 4 * B * N * D)),
+        "gated_resident_first": (lambda: n.attention_gated(qkv, tiles, vp, pv, B, H, N, D, 8.0, store, True, out_f32=out),
+                                 ("GB/s", B * H * N * N * es + B * N * D * (12 + 4 + 2 * es))),
         "softmax_gated": (lambda: n.softmax_gate(product, ap_, B, H, N, N, D, store, a_new=a_new, a_delta=a_del,
                                                  idx=idx, kcap=k, gated=True),
                           ("GB/s", B * H * N * (4 * N + 4 * es * k))),
@@ -138,7 +152,7 @@ def main():
     only = [s for s in a.only.split(",") if s]
     print(f"# B={B} N={N} k={k} D={D} cast={a.cast}")
     for name, (fn, (unit, work)) in cases.items():
-        if only and name not in only:
+        if (only and name not in only) or (name.startswith("gated_resident") and tiles is None):
             continue
         us = timeit(fn, a.iters)
         rate = work / us * 1e-3 if unit == "GB/s" else work / us * 1e-6

@@ -20,7 +20,7 @@ def native():
 def test_library_is_loaded_and_targets_gfx950():
     n = native()
     lib = n.load()
-    assert lib.evt_version() == n.ABI_VERSION == 8
+    assert lib.evt_version() == n.ABI_VERSION == 9
     assert lib.evt_target_arch() == b"gfx950"
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
@@ -998,6 +998,81 @@ def test_attention_stream_pooled_keys_matches_oracle(cast, qh, qw, pool, k, rel,
         bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
         assert err <= bar, (cast, N, Nk, k, t, err, bar)
         assert torch.equal(out.cpu(), pv.float().cpu())
+
+
+@pytest.mark.parametrize("cast,N,k", [("bfloat16", 197, 128), ("float16", 197, 128), ("bfloat16", 37, 12), ("float16", 70, 40),
+                                      ("bfloat16", 256, 100), ("bfloat16", 130, 130), ("float16", 225, 1), ("bfloat16", 64, 33)])
+def test_attention_gated_resident_matches_oracle(cast, N, k):
+    """evt_attention_gated (K10: one workgroup per (clip, head); value gate, scores, softmax, A gate and both accumulator products in
+    one launch; TILED gate reference): first frame + 3 gated frames against the oracle's value gate / softmax / delta gates /
+    accumulator on the same token buffers -- incl. a device-side count < kcap, partial last tiles (N % 32 != 0), N = 256, every key
+    selected, a single key selected, and the fused per-head ||out - ref||^2 partials."""
+    n = native()
+    B, H, dh, scale = 2, 3, 64, 8.0
+    D = H * dh
+    sdt = getattr(torch, cast)
+    store = n.store_code(sdt)
+    assert n.attention_gated_fits(N, D, H, store)
+    g = torch.Generator().manual_seed(N * 19 + k)
+    vs, ag, acc = O.Slot(), O.Slot(), O.Slot()
+    tiles = n.gated_tiles_empty(B, H, N, sdt, DEV)
+    tiles.view(torch.int16).fill_(0x7fc0 if cast == "bfloat16" else 0x7e00)   # NaN everywhere: the first frame must write every tile
+    vp = torch.full((B, N, D), float("nan"), dtype=sdt, device=DEV)
+    pv = torch.full((B, N, D), float("nan"), dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    tol = 2e-2 if cast == "bfloat16" else 3e-3
+    for t in range(4):
+        buf = torch.randn(B, N, 3 * D, generator=g) * 1.5
+        idx = torch.stack([torch.randperm(N, generator=g)[:k].sort()[0] for _ in range(B)])
+        q, kk, v = buf.view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        a = ((q / scale) @ kk.transpose(-2, -1)).softmax(dim=-1).to(sdt)
+        v = v.to(sdt)
+        v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=idx if t else None)
+        a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=idx if t else None, structure="col")
+        ref = O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float()
+        bd, idxd = buf.to(DEV), idx.int().to(DEV)
+        if t == 0:
+            n.attention_gated(bd, tiles, vp, pv, B, H, N, D, scale, store, True, out_f32=out)
+        else:
+            cap = k if (t != 2 or k == N) else min(N, k + 5)
+            idx_cap = torch.full((B, cap), 0, dtype=torch.int32, device=DEV)
+            idx_cap[:, :k] = idxd
+            count = None if cap == k else torch.full((B,), k, dtype=torch.int32, device=DEV)
+            ref_next = torch.randn(B, N, D, generator=g).to(DEV)      # stands for the projection gate's reference
+            parts = torch.full((B, N, H), float("nan"), device=DEV)
+            n.attention_gated(bd, tiles, vp, pv, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap, out_f32=out,
+                              norm_ref=ref_next, norm_parts=parts)
+            want_parts = (out - ref_next).view(B, N, H, dh).pow(2).sum(-1)
+            assert torch.allclose(parts, want_parts, rtol=1e-5, atol=1e-6), float((parts - want_parts).abs().max())
+        # the value reference is elementwise: exact
+        got_v = vp.view(B, N, H, dh).permute(0, 2, 1, 3).float().cpu()
+        assert torch.equal(got_v, vs.t.float()), (cast, t, float((got_v - vs.t.float()).abs().max()))
+        # probabilities are rounded to the store type from scores computed in a different fp32 summation order than the CPU's:
+        # one ulp of the store type at p <= 1 (bf16 2^-8, fp16 2^-11)
+        atol_p = {"bfloat16": 4e-3, "float16": 5e-4}[cast]
+        got_p = n.tiles_to_logical(tiles, N).float().cpu()
+        assert torch.isfinite(got_p).all()
+        assert torch.allclose(got_p, ag.t.float(), atol=atol_p), (cast, t, float((got_p - ag.t.float()).abs().max()))
+        err = float((out.cpu() - ref).abs().max())
+        # the output IS the store-type A.v state, and the state persists: a rounding flipped in one frame (the fp32 sums are added in
+        # another order than the CPU's) stays, so an element may be off by one ulp of the store type per rounding that flipped so
+        # far -- two are seen (fp16, ~0.2 % of the roundings flip), never more on these streams
+        ulps = 1 if t == 0 else 2
+        bar = max(tol, ulps * float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        assert err <= bar, (cast, N, k, t, err, bar)
+        assert torch.equal(out.cpu(), pv.float().cpu())
+    # the fp32 output may be omitted (the caller reads the A.v state): same state
+    pv2, tiles2, vp2 = pv.clone(), tiles.clone(), vp.clone()
+    n.attention_gated(bd, tiles2, vp2, pv2, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap)
+    pv3, tiles3, vp3 = pv.clone(), tiles.clone(), vp.clone()
+    n.attention_gated(bd, tiles3, vp3, pv3, B, H, N, D, scale, store, False, idx=idx_cap, count=count, kcap=cap, out_f32=out)
+    assert torch.equal(pv2.view(torch.int16), pv3.view(torch.int16)) and torch.equal(out, pv3.float())
+    # layout round trip through the host helpers (what matmul_gate.p's setter / getter do)
+    tiles4 = torch.zeros_like(tiles)
+    n.logical_to_tiles(n.tiles_to_logical(tiles, N), tiles4)
+    assert torch.equal(n.tiles_to_logical(tiles4, N).view(torch.int16), n.tiles_to_logical(tiles, N).view(torch.int16))
+    with pytest.raises(RuntimeError, match="evt_attention_gated"):
+        n.attention_gated(torch.empty(1, 300, 3 * D, device=DEV), tiles, vp, pv, 1, H, 300, D, scale, store, True, out_f32=out)
 
 
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),

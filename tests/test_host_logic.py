@@ -24,7 +24,7 @@ def test_abi_header_symbols_are_exported():
         assert hasattr(lib, name), f"{name} declared in include/evt_abi.h but not exported"
     lib.evt_version.restype = ctypes.c_int
     lib.evt_target_arch.restype = ctypes.c_char_p
-    assert lib.evt_version() == _native.ABI_VERSION == 8 and lib.evt_target_arch() == b"gfx950"
+    assert lib.evt_version() == _native.ABI_VERSION == 9 and lib.evt_target_arch() == b"gfx950"
 
 
 def test_abi_argument_errors_without_gpu():
@@ -222,3 +222,31 @@ def test_big_tile_choice_respects_the_4gb_weight_plane_bound():
     assert _native.gated_linear_big_tile(768, True, N, 2304, True, N, False, B, kcap, 768, 2304) != 0
     big_k, big_n = 65536, 32768          # 32768 rows x 65536 x 4 bytes of hl32 lines = 8 GB
     assert _native.gated_linear_big_tile(big_k, True, N, big_n, True, N, False, B, kcap, big_k, big_n) == 0
+
+
+def test_gated_tile_layout_matches_the_abi_formula():
+    """The tiled gate reference of evt_attention_gated: the host's permute-based conversion places element (row i, key j) where
+    include/evt_abi.h says -- tile (i / 32, j / 32), offset 512 (c / 16) + 8 (32 (c / 4 % 2) + r) + 4 (c / 8 % 2) + c % 4 -- and the
+    setter / getter of `matmul_gate.p` round-trip through it."""
+    import torch
+
+    from eventful_transformer import _native
+    from eventful_transformer.modules import TokenDeltaGate
+
+    B, H, N = 2, 3, 70
+    nt = (N + 31) // 32
+    p = torch.arange(B * H * N * N, dtype=torch.float32).view(B, H, N, N)
+    tiles = torch.full((B, H, nt, nt, 2, 2, 32, 2, 4), -1.0)
+    _native.logical_to_tiles(p, tiles)
+    flat = tiles.view(B, H, nt * nt, 1024)
+    for (b, h, i, j) in [(0, 0, 0, 0), (1, 2, 69, 69), (0, 1, 33, 5), (1, 0, 7, 63), (0, 2, 40, 47), (1, 1, 31, 32), (0, 0, 64, 12)]:
+        r, c = i % 32, j % 32
+        off = 512 * (c // 16) + 8 * (32 * ((c // 4) % 2) + r) + 4 * ((c // 8) % 2) + c % 4
+        assert flat[b, h, (i // 32) * nt + j // 32, off] == p[b, h, i, j]
+    assert torch.equal(_native.tiles_to_logical(tiles, N), p)
+    gate = TokenDeltaGate(structure="col")
+    gate.use_tiles(torch.zeros_like(tiles), N)
+    gate.p = p
+    assert torch.equal(gate.p, p) and gate._tiles is not None
+    gate.reset()
+    assert gate.p is None and gate._tiles is None
