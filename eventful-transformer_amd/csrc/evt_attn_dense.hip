@@ -554,10 +554,9 @@ extern "C" int evt_attention_dense(const evt_attn_dense_desc* d, void* stream) {
               d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0, d->rel_y ? d->qw : 1, d->scale, d->norm_ref, d->norm_parts};
   EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_attention_dense: norm_ref / norm_parts come together");
   // Resident form first (evt_attn_window.hip: the group's K / V staged once per (group, head)); the tiled kernel below keeps
-  // the launches that want state outputs and the shapes whose planes do not fit a CU's LDS.  EVT_DENSE_TILED=1 forces it.
-  static const bool tiled_only = getenv("EVT_DENSE_TILED") != nullptr && atoi(getenv("EVT_DENSE_TILED")) != 0;
+  // the launches that want state outputs and the shapes whose planes do not fit a CU's LDS.
   if (a.G == 0) return EVT_OK;
-  if (!tiled_only && evt_launch_window(a, d->store, d->qk_split, evt_stream(stream))) return evt_check_launch("evt_attention_dense (resident)");
+  if (evt_launch_window(a, d->store, d->qk_split, evt_stream(stream))) return evt_check_launch("evt_attention_dense (resident)");
   EVT_REQUIRE(d->norm_ref == nullptr, EVT_ERR_BAD_SHAPE, "evt_attention_dense: norm_ref / norm_parts are outputs of the resident kernel only "
               "(no state outputs, planes within a CU's LDS: ask evt_attention_dense_resident first)");
   EVT_DISPATCH_STORE(d->store, T, { return launch_dense<T>(a, d->qk_split, stream); });

@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && TPW == 1 && NREG > 0) ? 3 :
   const int32_t* ix = a.idx + (int64_t)b * a.kcap;
   // Addressing.  Every tensor is reached through a wave-uniform base (scalar registers: the (clip, head) / clip slice) plus a
   // 32-bit BYTE offset -- one integer add per access instead of a 64-bit multiply-add chain per lane (the launch is bound by the
-  // vector ALU: 1 894 VALU instructions per wave at ~70 % VALU busy, profiles/r05/attn_pmc_counters.txt).  All slices are far below
-  // 4 GB (entry-point limits: N <= 32767).
+  // vector ALU: 1 894 VALU instructions per wave at ~70 % VALU busy, profiles/r05/attn_pmc_counters.txt).  Every slice addressed this
+  // way is below 4 GB: evt_softmax_av_gated checks it (EVT_ERR_BAD_SHAPE otherwise).
   char* const stb = reinterpret_cast<char*>(st);
   auto st_off = [&](int row, int col) __attribute__((always_inline)) { return (uint32_t)(row * a.Nk + col) * (uint32_t)sizeof(T); };
   auto st_load = [&](uint32_t off) __attribute__((always_inline)) { return Store<T>::load(reinterpret_cast<const T*>(stb + off)); };
@@ -872,6 +872,11 @@ extern "C" int evt_softmax_av_gated(const evt_softmax_av_desc* d, void* stream) 
               d->pv, d->out_f32, d->B, d->H, d->N, d->Nk, d->D, d->dh, d->kcap, d->rel_y ? d->gh : 0, d->rel_y ? d->gw : 0,
               d->rel_y ? d->qw : 1, d->scale, d->qk_split, d->norm_ref, d->norm_parts, d->rel_y ? d->rel_terms : nullptr};
   EVT_REQUIRE((d->norm_ref == nullptr) == (d->norm_parts == nullptr), EVT_ERR_BAD_ARG, "evt_softmax_av_gated: norm_ref / norm_parts come together");
+  // the kernel addresses a head's N x Nk reference, a clip's (N, D) states and its (D, kcap) value operands by 32-bit byte offsets
+  EVT_REQUIRE((int64_t)d->N * d->Nk * 4 < (1ll << 32) && (int64_t)d->N * d->D * 4 < (1ll << 32) && (int64_t)d->D * d->kcap * 4 < (1ll << 32) &&
+              (int64_t)d->N * 3 * d->D * 4 < (1ll << 32), EVT_ERR_BAD_SHAPE,
+              "evt_softmax_av_gated: a head's reference (N x Nk), a clip's state (N x D) or its token buffer exceeds 4 GB (N=%d Nk=%d D=%d kcap=%d)",
+              d->N, d->Nk, d->D, d->kcap);
   EVT_DISPATCH_STORE(d->store, T, { return launch_fused<T>(a, stream); });
   return EVT_OK;
 }

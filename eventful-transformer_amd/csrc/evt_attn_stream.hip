@@ -950,7 +950,7 @@ void launch_stream_inst(const StreamArgs& a, hipStream_t s) {
 
 // Tile height: the launch runs in ceil(workgroups / slots) rounds of (almost) equal length, slots = CUs x workgroups per
 // CU (two by registers; fewer when LDS says so), and a workgroup of NHR row groups costs ~(1 + NHR) units (the key
-// fragments are split once per workgroup, everything else is per row group).  EVT_STREAM_NHR forces 2 or 3.
+// fragments are split once per workgroup, everything else is per row group).
 template <typename T>
 int stream_pick_nhr(const StreamArgs& a) {
   const int cus = evt_cu_count();

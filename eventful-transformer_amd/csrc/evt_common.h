@@ -122,17 +122,19 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // instructions per max step (copy, v_mov_b32_dpp, a canonicalising v_max x, x, x, v_max) and ~90 hazard nops in the fused attention
 // kernel's statistics pass.  Per row the operations and their order are those of wave_max_dpp / wave_sum_dpp: same bits.
 // Hazards (inline asm is invisible to hipcc's hazard recognizer): a DPP operand needs two wait states behind the VALU write of
-// its register -- NROW >= 3 rows interleaved provide them between steps; s_nop 1 in front of the first and behind the last step.
-#define EVT_DPP_ROWS_STEP(OP, CTRL)                                                                                  \
-  _Pragma("unroll") for (int r = 0; r < NROW; ++r) asm volatile(OP " %0, %0, %0 " CTRL : "+v"(v[r]));
+// its register.  Between steps the NROW >= 3 interleaved rows provide them (each row's next step is at least two VALU instructions
+// behind its previous one, and nothing can be scheduled in between: the statements are volatile and ordered); in front of the FIRST
+// step the producer of v[r] is compiler-scheduled code, so every row's first step carries its own `s_nop 1` INSIDE its asm string --
+// the guarantee does not depend on where the scheduler puts the producer.  s_nop 1 behind the last step covers the readlane.
+#define EVT_DPP_ROWS_STEP(PRE, OP, CTRL)                                                                             \
+  _Pragma("unroll") for (int r = 0; r < NROW; ++r) asm volatile(PRE OP " %0, %0, %0 " CTRL : "+v"(v[r]));
 #define EVT_DPP_ROWS_ALL(OP)                                                                                         \
-  asm volatile("s_nop 1");                                                                                           \
-  EVT_DPP_ROWS_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                                      \
-  EVT_DPP_ROWS_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                                      \
-  EVT_DPP_ROWS_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xe")                                                      \
-  EVT_DPP_ROWS_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xc")                                                      \
-  EVT_DPP_ROWS_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                                   \
-  EVT_DPP_ROWS_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                                   \
+  EVT_DPP_ROWS_STEP("s_nop 1\n\t", OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                         \
+  EVT_DPP_ROWS_STEP("", OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                                  \
+  EVT_DPP_ROWS_STEP("", OP, "row_shr:4 row_mask:0xf bank_mask:0xe")                                                  \
+  EVT_DPP_ROWS_STEP("", OP, "row_shr:8 row_mask:0xf bank_mask:0xc")                                                  \
+  EVT_DPP_ROWS_STEP("", OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                               \
+  EVT_DPP_ROWS_STEP("", OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                               \
   asm volatile("s_nop 1");
 template <int NROW>
 __device__ __forceinline__ void wave_max_dpp_rows(float* v) {

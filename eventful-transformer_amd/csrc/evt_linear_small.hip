@@ -324,8 +324,7 @@ int evt_launch_split_small(const LinArgs& a, hipStream_t s) {
   const int live = counted_ ? (int)std::min<int64_t>(M, 512) : (int)M;   // planning figure for the tile choice
   // tile: 64x64 unless that leaves fewer than ~128 workgroups (graph-replayed launches at M = 256, us incl. the ~1.5 us
   // boundary, 64x64 / 32x32: QKV 12.2 / 14.0, MLP-1 12.7 / 16.0, projection 11.3 / 6.6, MLP-2 24.8 / 13.1; MLP-2 as
-  // 64x64 with K split four ways over workgroups + finish pass: 16.5).  No K split over workgroups by default;
-  // EVT_SMALL_KS > 1 forces one (64x64 tiles, partial planes + splitk_finish_kernel), EVT_SMALL_TILE the tile.
+  // 64x64 with K split four ways over workgroups + finish pass: 16.5).  No K split over workgroups.
   int bm = 64, ks = 1;
   auto wgs = [&](int b) { return ((live + b - 1) / b) * ((a.Nout + b - 1) / b); };
   if (wgs(64) < 128) bm = 32;

@@ -398,9 +398,12 @@ def gemm_kernel_name():
 # GEMM arithmetic of K3/K7: "split" = bf16 hi/lo planes, 3 bf16 MFMAs per fp32 product, fp32 accumulate
 # (~1e-5 relative to fp32, ~5x the fp32-MFMA rate); "f32" = exact fp32-input MFMA.  EVT_GEMM overrides.
 GEMM_MODE = os.environ.get("EVT_GEMM", "split")
-QK_SPLIT = os.environ.get("EVT_QK_SPLIT", "1" if GEMM_MODE == "split" else "0") != "0"   # K4 on the bf16x3 split MFMA
-DENSE_FUSED = os.environ.get("EVT_DENSE_FUSED", "1") != "0"   # K8 (evt_attention_dense) vs the K4+K5+K6 chain
-FUSED_QK = os.environ.get("EVT_FUSED_QK", "1") != "0"         # gated frames: q.k^T inside K5+K6 (no K4, no state traffic)
+# Score arithmetic of the attention kernels follows the GEMM mode: bf16 hi + lo split products, or exact fp32-input MFMA.
+QK_SPLIT = GEMM_MODE == "split"
+# Module constants, not environment switches: the tests set FUSED_QK = False to run the K4 + stored-state chain -- the path of
+# every shape the in-kernel-score kernels do not cover -- on a shape they do cover, and compare.
+FUSED_QK = True          # gated frames: q.k^T inside K5+K6 / K9 / K10 (no K4, no score-state traffic)
+DENSE_FUSED = True       # dense / windowed attention of <= 256-token groups in one launch (K8) instead of the K4 + K5 + K6 chain
 
 
 def split_weight(W):
@@ -556,10 +559,7 @@ def fused_qk_fits(N, Nk, D, H, kcap):
     return FUSED_QK and D == 64 * H and N == Nk and 0 < N <= 256 and kcap > 0
 
 
-STREAM_QK = os.environ.get("EVT_STREAM_QK", "1") != "0"   # global blocks with N > 256: in-kernel scores (evt_attention_stream)
-
-
-STREAM_MIN_N = int(os.environ.get("EVT_STREAM_MIN_N", "257"))
+STREAM_MIN_N = 257   # evt_attention_stream takes more than 256 tokens (K8 / K10 / the in-LDS QK mode cover the rest)
 
 
 LDS_PER_CU = 160 * 1024
@@ -569,14 +569,11 @@ def attention_stream_fits(N, D, H, store=EVT_F32, gh=0, gw=0):
     """evt_attention_stream: head dim 64, more than 256 tokens (K8 / the in-LDS QK mode cover the rest), and a 32-row tile with
     the rel-pos terms of a gh x gw key grid inside a CU's LDS (evt_attention_stream_lds_bytes; larger grids take the
     evt_qk + evt_softmax_av_gated path)."""
-    if not (STREAM_QK and FUSED_QK and D == 64 * H and STREAM_MIN_N <= N <= 32767):   # (32-bit offsets into a head's N x N reference)
+    if not (FUSED_QK and D == 64 * H and STREAM_MIN_N <= N <= 32767):   # (32-bit offsets into a head's N x N reference)
         return False
     return 0 < load().evt_attention_stream_lds_bytes(store, gh, gw) <= LDS_PER_CU
 
 
-# One stream: the three preparations of a gated evt_attention_stream frame (rel-pos terms, key plane, value gate) as ONE launch
-# (evt_stream_prep).  EVT_STREAM_PREP=0: three launches.
-STREAM_PREP = os.environ.get("EVT_STREAM_PREP", "1") != "0"
 
 
 def prefetch(t, sink):
@@ -586,8 +583,7 @@ def prefetch(t, sink):
 
 
 # One stream: the selection launches carry prefetch riders for the weight planes of a gated linear a few launches ahead
-# (evt_select_prefetch_next).  EVT_PREFETCH=0 turns it off; used below PREFETCH_MAX_ROWS token rows per launch.
-PREFETCH = os.environ.get("EVT_PREFETCH", "1") != "0"
+# (evt_select_prefetch_next), below PREFETCH_MAX_ROWS token rows per launch.
 PREFETCH_MAX_ROWS = 8192
 
 
@@ -607,7 +603,7 @@ def k_split_plane(qkv, B, H, N, gh=0, gw=0):
 
 
 def stream_prep_fits(D, H, kcap, has_rel):
-    return STREAM_PREP and QK_SPLIT and has_rel and D == 64 * H and kcap > 0 and kcap % 8 == 0
+    return QK_SPLIT and has_rel and D == 64 * H and kcap > 0 and kcap % 8 == 0
 
 
 def stream_prep(qkv, rel_y, rel_x, terms, idx, count, kcap, v_state, v_delta_t, v_old_t, B, H, N, D, gh, gw, qw, store, kv=None, Nk=None):
@@ -701,8 +697,8 @@ def attention_dense_fits(N, D, H):
 
 def attention_dense_resident(N, D, H, store, gh=0, gw=0, qk_split=None):
     """True when an evt_attention_dense launch of this shape without state outputs runs the resident kernel (the one that can
-    also emit the next gate's per-head delta norms, `norm_ref` / `norm_parts`).  EVT_DENSE_TILED=1 forces the tiled kernel."""
-    if D != 64 * H or os.environ.get("EVT_DENSE_TILED", "0") not in ("", "0"):
+    also emit the next gate's per-head delta norms, `norm_ref` / `norm_parts`)."""
+    if D != 64 * H:
         return False
     return bool(load().evt_attention_dense_resident(N, gh, gw, store, int(QK_SPLIT if qk_split is None else qk_split)))
 

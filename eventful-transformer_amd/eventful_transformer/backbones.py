@@ -1,6 +1,5 @@
 """ViT backbone (API of the reference's backbones.py): position encoding, then a stack of blocks
 chosen BY CLASS NAME from `eventful_transformer.blocks` (backbones.py:46-59)."""
-import os
 
 import torch.nn as nn
 
@@ -63,7 +62,7 @@ class ViTBackbone(ExtendedModule):
         return x.materialize() if isinstance(x, blocks.PendingSum) else x
 
 
-CHAIN_BLOCKS = os.environ.get("EVT_CHAIN_BLOCKS", "1") != "0"
+CHAIN_BLOCKS = True   # (module constant: block chaining through PendingSum; tests may turn it off to compare)
 
 
 def _hooked(module):

@@ -29,7 +29,6 @@ pooled cells by `evt_pool_index`, and K4/K5/K6 run with Nq != Nk.  `ats_fraction
 blocks.py:150-181) runs off the fast path (`_ats_attention`) and, like the reference, only when batch == heads.
 Not implemented: pooling inside windowed blocks and ATS combined with pooling / windows (raise).
 """
-import os
 from math import prod, sqrt
 
 import torch
@@ -55,14 +54,14 @@ LN_EPS = 1e-6
 # q.k^T state update: above this fraction of changed state entries the whole product is recomputed instead of the
 # row + column panels (measured break-even ~0.68 of the entries, i.e. k/N ~ 0.43)
 QK_FULL_RATIO = 0.7
-FUSE_PROJ_NORM = os.environ.get("EVT_FUSE_PROJ_NORM", "1") != "0"   # projection-gate delta norm from the fused attention epilogue
-PROJ_FROM_STATE = os.environ.get("EVT_PROJ_FROM_STATE", "1") != "0"   # bf16 cast: projection reads the A.v state, no fp32 attention output
-# Windowed / dense blocks (resident K8): the same norm from K8's epilogue.  One stream: 1.84 vs 1.81 ms per 672^2 frame (the
-# epilogue's reference reads and the 12-partial selection cost what the 6 us row pass did); eight streams 6.37 vs 6.41 ms --
-# used from FUSE_DENSE_NORM_ROWS token rows per launch on (EVT_FUSE_DENSE_NORM_ROWS=0: always).
-FUSE_DENSE_NORM_ROWS = int(os.environ.get("EVT_FUSE_DENSE_NORM_ROWS", "8192"))
-STREAM_POOLED = os.environ.get("EVT_STREAM_POOLED", "1") != "0"   # pool_size blocks with > 256 tokens on evt_attention_stream (0: K4 + K5+K6 chain)
-REL_TERMS = os.environ.get("EVT_REL_TERMS", "1") != "0"   # rel-pos terms by evt_rel_terms (one launch) vs inside the fused kernel
+# The fused attention kernels emit the projection gate's delta norm per head from their epilogue, and with a bf16 cast the
+# projection reads the A.v state (no fp32 attention output).  Windowed / dense blocks (resident K8) emit the same norm from
+# FUSE_DENSE_NORM_ROWS token rows per launch on (one stream: 1.84 vs 1.81 ms per 672^2 frame -- the epilogue's reference reads and
+# the 12-partial selection cost what the 6 us row pass did; eight streams 6.37 vs 6.41 ms).
+FUSE_DENSE_NORM_ROWS = 8192
+# Module constant, not an environment switch: the tests set it to False to run pooled blocks with > 256 tokens on the K4 + K5+K6
+# chain (the path of the grids whose tile does not fit evt_attention_stream) and compare.
+STREAM_POOLED = True
 # Diagnostic tap: a callable (block, gate tag, idx (B,cap) int32, count or None) invoked after every fused gate selection
 # with the DEVICE index list (scratch memory: clone to keep).  bench.py's self-check records the timed run's index sets
 # through it -- unlike forward hooks it leaves the launch sequence (block chaining included) untouched.
@@ -75,12 +74,9 @@ def _norm_order(gate):
 
 
 def _PREFETCH_MAP(blk, nxt):
-    """gate tag -> the linears whose weight planes its selection launch prefetches.  EVT_PREFETCH_MAP=late: one launch ahead
-    (measured worse: the riders of two linears outlast the selection); default: three to five launches ahead.  Also measured
-    worse: a second range with the gate reference the next row pass compares against (5.4 MB, written a frame ago):
-    672^2 1.65 vs 1.62 ms, 1024^2 2.55 vs 2.51."""
-    if os.environ.get("EVT_PREFETCH_MAP", "early") == "late":
-        return {"projection": (blk.mlp_1,), "mlp": (blk.mlp_2, None if nxt is None else nxt.qkv)}
+    """gate tag -> the linears whose weight planes its selection launch prefetches: three to five launches ahead.  Measured worse:
+    one launch ahead (the riders of two linears outlast the selection); a second range with the gate reference the next row pass
+    compares against (5.4 MB, written a frame ago): 672^2 1.65 vs 1.62 ms, 1024^2 2.55 vs 2.51."""
     return {"qkv": (blk.mlp_1,), "projection": (blk.mlp_2,), "mlp": (None if nxt is None else nxt.qkv,)}
 
 
@@ -490,7 +486,7 @@ class EventfulTokenwiseBlock(Block):
             # the qkv gate of blocks with a q.k^T state also wants the complement list (K4 skips re-written rows)
             rest = self._ws("idx_rest", (B, N), torch.int32, c) if (tag == "qkv" and self._wants_rest) else None
             self._rest = rest if tag == "qkv" else self._rest
-            if _native.PREFETCH and B * N <= _native.PREFETCH_MAX_ROWS:
+            if B * N <= _native.PREFETCH_MAX_ROWS:
                 # one stream: the single-workgroup selection launch also pulls the weight planes of the gated linears one or two
                 # launches ahead into the memory-side cache (MLP-1 behind the projection gate; MLP-2 and the NEXT block's QKV
                 # behind the MLP gate -- close to their use: the attention state of a 1024^2 frame would evict them) -- a
@@ -641,7 +637,7 @@ class EventfulTokenwiseBlock(Block):
         # partials): no separate pass over the attention output -- as in the global blocks' fused attention kernels.
         pg = self.projection_gate
         norm = None
-        if FUSE_PROJ_NORM and B * N >= FUSE_DENSE_NORM_ROWS and not pg.first and pg.p is not None and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 \
+        if B * N >= FUSE_DENSE_NORM_ROWS and not pg.first and pg.p is not None and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 \
                 and self._dense_norm_fusable(N):
             norm = (pg.p, self._ws("norm_parts", (B, N, self.heads), torch.float32, qkv))
         ats = self._attention_dense(qkv, B, N, attn, norm=norm)
@@ -860,20 +856,20 @@ class EventfulBlock(EventfulMatmul1Block):
             # The projection gate's delta norm ||attn - p||^2 comes out of the same epilogue, per head (the select kernel
             # adds the H partials): no separate pass over the attention output.
             pg = self.projection_gate
-            fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
+            fuse_norm = not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
             nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
             # bf16 `matmul_2_cast`: the attention output IS the A.v state (out == pv.float()).  When the projection then runs
             # on the persistent GEMM (which takes bf16 activations: half the bytes, no split, two MFMAs of three), it reads the
             # state directly and this launch does not write the fp32 copy at all.
             state_src = False
-            if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+            if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                     and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
                 cap_p = pg.policy.capacity(N)
                 state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
             # rel-pos terms of all query tokens once per frame (evt_rel_terms): each 32-row workgroup of the fused kernel
             # would otherwise re-read 32 x (gh + gw) table rows (head dim 64, un-pooled key grid only)
             terms = None
-            if ry is not None and dh == 64 and REL_TERMS:
+            if ry is not None and dh == 64:
                 terms = self._ws("rel_terms", (B, H, N, gh + gw), torch.float32, qkv)
                 _native.rel_terms(qkv, ry, rx, B, H, N, D, gh, gw, qw, terms)
             _native.softmax_av_gated(product, ag.p, idx_k, count_k, cap_k, v_delta, v_old, acc._state,
@@ -925,10 +921,10 @@ class EventfulBlock(EventfulMatmul1Block):
             acc.matmul.count_product(B * H * N * dh, N)
             return attn, None, None
         pg = self.projection_gate
-        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
+        fuse_norm = not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
         state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
-        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+        if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                 and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
             cap_p = pg.policy.capacity(N)
             state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
@@ -1004,10 +1000,10 @@ class EventfulBlock(EventfulMatmul1Block):
             _native.v_gate(kv, idx_k, count_k, B, Nk, D, cap_k, vg._state, v_delta, v_old, store, True, transposed=True,
                            v_offset=D, v_rs=2 * D)
         pg = self.projection_gate
-        fuse_norm = FUSE_PROJ_NORM and not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
+        fuse_norm = not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
         state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
-        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+        if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                 and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
             cap_p = pg.policy.capacity(N)
             state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0

@@ -84,10 +84,12 @@ class FrameGraphs:
         for m in self.model.modules():
             pol = getattr(m, "policy", None)
             if pol is not None:
-                sig.append((type(pol).__name__,) + tuple(sorted((k, v) for k, v in vars(pol).items()
-                                                                if isinstance(v, (int, float, bool, str, type(None))))))
+                # scalars by value; anything else (a tuple, a tensor-valued threshold) by its repr, so that replacing it re-captures
+                sig.append((type(pol).__name__,) + tuple(sorted((k, v if isinstance(v, (int, float, bool, str, type(None))) else repr(v))
+                                                                for k, v in vars(pol).items())))
         for t in list(self.model.parameters()) + list(self.model.buffers()):
-            sig.append((t.data_ptr(), t._version, t.dtype, str(t.device)))
+            # (inference tensors have no version counter: reading it raises -- their storage cannot be edited in place either)
+            sig.append((t.data_ptr(), -1 if t.is_inference() else t._version, t.dtype, str(t.device)))
         return tuple(sig)
 
     def _owns_model_state(self):

@@ -41,23 +41,12 @@ else:
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 lib = n.load()
-if hasattr(lib, "evt_debug_prof_pipe") and os.environ.get("EVT_GEMM_PIPE", "1") != "0":   # the one-wave-per-SIMD kernel (evt_linear_pipe.hip)
-    lib.evt_debug_prof_pipe.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-    assert lib.evt_debug_prof_pipe(buf) == 0
-    v = [buf[q] for q in range(8)]
-    tot = sum(v)
-    print(f"{a.shape}: wave 0 of workgroup 8, total {tot} ticks")
-    for q, nm in enumerate(["refresh + fetch-side bookkeeping", "wait: loads of the next k-tile, fragment reads", "first k-half (MFMA + staging)",
-                            "barrier", "second k-half (MFMA + reads)", "epilogue"]):
-        print(f"   {nm:48s} {v[q]:12d}  {100.0 * v[q] / max(tot, 1):5.1f} %")
-    sys.exit(0)
-lib.evt_debug_prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-assert lib.evt_debug_prof(buf) == 0
-names = ["stage (after the load wait)", "bookkeeping+fetch issue", "barrier before multiply", "epilogue", "multiply", "barrier after multiply", "wait for the loads", "loop"]
-for w, label in ((0, "wave 0 (stage first)"), (1, "wave 4 (multiply first)")):
-    v = [buf[w * 8 + q] for q in range(8)]
-    tot = sum(v)
-    print(f"{label}: total {tot} ticks")
-    for q, nm in enumerate(names):
-        if v[q]:
-            print(f"   {nm:28s} {v[q]:12d}  {100.0 * v[q] / tot:5.1f} %")
+# the persistent 256-row kernel (evt_linear_pipe.hip, 8 waves); needs a -DEVT_PROF build (EVT_LIB)
+lib.evt_debug_prof_pipe.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+assert lib.evt_debug_prof_pipe(buf) == 0
+v = [buf[q] for q in range(8)]
+tot = sum(v)
+print(f"{a.shape}: wave 0 of workgroup 8, total {tot} ticks")
+for q, nm in enumerate(["refresh + fetch-side bookkeeping", "wait: loads of the next k-tile, fragment reads", "first k-half (MFMA + staging)",
+                        "barrier", "second k-half (MFMA + reads)", "epilogue"]):
+    print(f"   {nm:48s} {v[q]:12d}  {100.0 * v[q] / max(tot, 1):5.1f} %")

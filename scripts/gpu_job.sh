@@ -35,24 +35,17 @@ case $what in
       echo "== rep $rep --overlap $ov" | tee -a $OUT/overlap.txt
       timeout 900 python bench.py --no-other --no-cpu-baseline --no-check --no-exact --no-kernel-events --overlap $ov 2>/dev/null | tail -1 | cut -c1-260 | tee -a $OUT/overlap.txt
     done; done ;;
-  sharp_ab)    # bf16 cast + sharp attention, projection-gate agreement: split-precision q.k^T (default) vs exact fp32 q.k^T vs all-fp32 GEMMs
-    for cfg in "EVT_QK_SPLIT=1" "EVT_QK_SPLIT=0" "EVT_GEMM=f32"; do
-      echo "== $cfg" | tee -a $OUT/sharp_ab.txt
-      rm -f $OUT/sharp_tmp.txt
-      env $cfg EVT_PARITY_SUMMARY=$PWD/$OUT/sharp_tmp.txt timeout 900 python -m pytest tests/test_gpu_blocks.py -m gpu -q -k "sharp_bf16_projection" 2>&1 | tail -2 | tee -a $OUT/sharp_ab.txt
-      cat $OUT/sharp_tmp.txt | tee -a $OUT/sharp_ab.txt
-    done ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
   kbench)
     python scripts/kbench.py 2>&1 | tee $OUT/kbench.txt ;;
   kbench=*)
     python scripts/kbench.py ${what#kbench=} 2>&1 | tee -a $OUT/kbench.txt ;;
-  vd_batch)    # ViTDet 672^2: streams per GPU as one batch, and the windowed blocks' fused projection norm on / off
-    for fuse in 1 0; do for b in 1 8; do
-      echo "== EVT_FUSE_PROJ_NORM=$fuse batch $b" | tee -a $OUT/vd_batch.log
-      EVT_FUSE_PROJ_NORM=$fuse python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log
-    done; done
+  vd_batch)    # ViTDet 672^2: streams per GPU as one batch
+    for b in 1 8; do
+      echo "== batch $b" | tee -a $OUT/vd_batch.log
+      python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --graphs --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log
+    done
     for b in 16 32 64; do
       echo "== batch $b" | tee -a $OUT/vd_batch.log
       python scripts/bench_vitdet.py --grid 42 --policy topk --k 256 --batch $b 2>&1 | tail -1 | cut -c1-260 | tee -a $OUT/vd_batch.log

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-5 GEMM work, run ON the GPU box: correctness of the one-wave-per-SIMD kernel (evt_linear_pipe.hip) under every forced
-# tile, then per-launch times against the round-2 kernel (EVT_GEMM_PIPE=0).   $1 = tag, rest = steps (check, kb, kbv=<lib variants>)
+# GEMM work, run ON the GPU box: correctness of the persistent 256-row kernel (evt_linear_pipe.hip, 8 waves) under every forced
+# tile, then per-launch times.   $1 = tag, rest = steps (check, kb, kbv=<lib variants>)
 set -u
 TAG=$1; shift
 OUT=gpurun_out/$TAG
@@ -10,17 +10,17 @@ KB=${KB:-"linear_qkv,linear_qkv_nop,linear_proj_bf16,linear_mlp1_gelu,linear_mlp
 for what in "$@"; do
 case $what in
   check)
-    for waves in ${WAVES:-8 4}; do for mode in 2 3 4; do
-      echo "== forced tile mode $mode, $waves waves" | tee -a $OUT/check.txt
-      EVT_PIPE_WAVES=$waves EVT_GEMM_BIG=$mode EVT_GEMM=split EVT_GEMM_SMALL=0 timeout 600 python tests/big_tile_check.py 2>&1 | tail -4 | grep -v amdgpu.ids | tee -a $OUT/check.txt
-    done; done ;;
+    for mode in 2 3 4; do
+      echo "== forced tile mode $mode" | tee -a $OUT/check.txt
+      EVT_GEMM_BIG=$mode EVT_GEMM=split EVT_GEMM_SMALL=0 timeout 600 python tests/big_tile_check.py 2>&1 | tail -4 | grep -v amdgpu.ids | tee -a $OUT/check.txt
+    done ;;
   kb)
     python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt ;;
   kbv=*)   # build variants under scripts/probes/bin/libevt_<v>.so
-    for v in $(echo ${what#kbv=} | tr ',' ' '); do for w in ${KBW:-8}; do
-      echo "== variant $v, $w waves" | tee -a $OUT/kb.txt
-      EVT_PIPE_WAVES=$w EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
-    done; done ;;
+    for v in $(echo ${what#kbv=} | tr ',' ' '); do
+      echo "== variant $v" | tee -a $OUT/kb.txt
+      EVT_LIB=$PWD/scripts/probes/bin/libevt_$v.so python scripts/kbench.py --clips 256 --only $KB 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kb.txt
+    done ;;
   prof=*)  # phase profile of the pipe kernel (variant library built with -DEVT_PROF): prof=<variant>
     for shp in qkv mlp1 mlp2 proj; do
       EVT_LIB=$PWD/scripts/probes/bin/libevt_${what#prof=}.so python scripts/gemm_prof.py --shape $shp 2>&1 | grep -v amdgpu.ids | tee -a $OUT/prof.txt
@@ -48,11 +48,11 @@ case $what in
       find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "p_counter_collection.csv" -delete; rm -rf $OUT/pmc_${tag}_*
     done
     ;;
-  tiles)   # forced tile shapes on the headline launches (EVT_GEMM_BIG: 2 = 256x256, 4 = 256x192, 3 = 256x128), 8 and 4 waves
-    for w in 8 4; do for mode in 2 4 3; do
-      echo "== EVT_GEMM_BIG=$mode, $w waves" | tee -a $OUT/tiles.txt
-      EVT_PIPE_WAVES=$w EVT_GEMM_BIG=$mode python scripts/kbench.py --clips 256 --only linear_qkv,linear_mlp1_gelu,mlp 2>&1 | grep -v "amdgpu.ids\|^#" | tee -a $OUT/tiles.txt
-    done; done ;;
+  tiles)   # forced tile shapes on the headline launches (EVT_GEMM_BIG: 2 = 256x256, 4 = 256x192, 3 = 256x128)
+    for mode in 2 4 3; do
+      echo "== EVT_GEMM_BIG=$mode" | tee -a $OUT/tiles.txt
+      EVT_GEMM_BIG=$mode python scripts/kbench.py --clips 256 --only linear_qkv,linear_mlp1_gelu,mlp 2>&1 | grep -v "amdgpu.ids\|^#" | tee -a $OUT/tiles.txt
+    done ;;
   gl)      # the kernel-level GEMM tests
     timeout 900 python -m pytest tests -m gpu -q -x -k "gated_linear or gated_mlp or big_tiles or operating_point" 2>&1 | tail -5 | tee -a $OUT/gl.txt ;;
   *) echo "unknown step $what" ;;

@@ -767,7 +767,7 @@ def test_pooled_eventful_block_on_the_stream_kernel(cast, policy, rel):
                 for t in range(4):
                     ys.append(blk(xs[t].to(DEV)).cpu())
             from eventful_transformer import _native
-            on_stream = pooled_stream and _native.STREAM_QK and _native.FUSED_QK   # (EVT_STREAM_QK=0 / EVT_FUSED_QK=0: the chain)
+            on_stream = pooled_stream and _native.FUSED_QK
             assert (getattr(blk.matmul_gate, "_state_t", None) is not None) == on_stream
             if on_stream:
                 assert blk.matmul_gate._state_t.shape == (1, 2, 81, 324) and blk.matmul_gate.p.shape == (1, 2, 324, 81)
