@@ -44,6 +44,7 @@ namespace {
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (native vector: arrays of HIP's uint4 struct can end up in scratch memory)
 
 constexpr int DH = 64;
 constexpr int KPB = DH + 8;   // bf16 pitch of a K plane row (144 B: conflict-free ds_read_b128 over 16-lane groups)
@@ -121,20 +122,34 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
   unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
 #endif
 
+  // ---- value planes and selection masks start as zeros (the columns of keys that are not selected STAY zero) ----------------
+  {
+    uint4* z = reinterpret_cast<uint4*>(smem + L::k_bytes);
+    constexpr int ZN = (int)((2 * L::v_plane + L::mask_bytes) / 16);
+    for (int e = tid; e < ZN; e += NTH) z[e] = make_uint4(0u, 0u, 0u, 0u);
+  }
+
   // ---- requests.  Everything the workgroup reads from HBM / L2 is asked for here, oldest first in the order of its use (vmcnt
-  //      retires in order): index list -> K rows -> q rows -> (index list back) value rows + value reference -> gate reference tiles.
+  //      retires in order): index list -> q rows -> K rows -> (index list back) value rows + value reference; the gate reference tiles
+  //      and the A.v state rows follow behind the second barrier.  Every load instruction of the phase addresses whole 64-byte lines: what a CU pays for a load is the
+  //      number of separate lines its 64 lanes touch (q rows read straight into MFMA fragments were 64 lines of 16 useful bytes per
+  //      instruction -- a third of all the line requests of the workgroup).
+  const int32_t* ix = first ? nullptr : a.idx + (int64_t)b * a.kcap;
   int vj[IT];   // key of this thread's value piece `it` (-1: none)
-  if (first) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) { const int p = (tid + NTH * it) >> 4; vj[it] = p < a.N ? p : -1; }
-  } else {
-    const int32_t* ix = a.idx + (int64_t)b * a.kcap;
+  for (int it = 0; it < IT; ++it) {
+    const int p = (tid + NTH * it) >> 4;
+    if (first) vj[it] = p < a.N ? p : -1;
+    else { const int j = ix[min(p, a.kcap - 1)]; vj[it] = p < cnt ? j : -1; }   // clamped: branch-free
+  }
+  const int i0 = wave_s * 32, iq = i0 + lr;
+  const bool wave_on = i0 < a.N, q_on = iq < a.N;
+  // q rows of the wave, coalesced: 16 lanes x 16 bytes per row, four rows per instruction
+  f32x4 qg[8];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int p = (tid + NTH * it) >> 4;
-      const int j = ix[min(p, a.kcap - 1)];   // clamped: branch-free
-      vj[it] = p < cnt ? j : -1;
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int r = (lane >> 4) + 4 * i;
+    qg[i] = *reinterpret_cast<const f32x4*>(clip + ((uint32_t)min(i0 + r, a.N - 1) * rs_b + (uint32_t)(lane & 15) * 16u));
   }
   f32x4 kr[IT];
 #pragma unroll
@@ -143,14 +158,16 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
     const f32x4 x = *reinterpret_cast<const f32x4*>(clip + ((uint32_t)min(j, a.N - 1) * rs_b + (uint32_t)(a.D + c4 * 4) * 4u));
     kr[it] = j < a.N ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const int i0 = wave_s * 32, iq = i0 + lr;
-  const bool wave_on = i0 < a.N, q_on = iq < a.N;
-  f32x4 qraw[8];   // channels 16 s + 8 lh + {0..3, 4..7} (s = piece / 2)
-  {
-    const char* qrow = clip + (uint32_t)min(iq, a.N - 1) * rs_b;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) qraw[m] = *reinterpret_cast<const f32x4*>(qrow + (uint32_t)(16 * (m >> 1) + 8 * lh + 4 * (m & 1)) * 4u);
-  }
+  // gate reference tiles of this wave's query rows: tile (wave, kb) = 2 KB, piece t of a lane = its 8 keys of MFMA step (kb, t)
+  // Padding is neither read nor written: rows past N of the last row tile (their lanes read lane 0's piece, branch-free, and do
+  // not store), and the second 16-key piece of the last key block when it holds no key (N % 32 in 1..16) -- at N = 197 that is
+  // 18 % of the tile bytes.
+  uint4 oa[NB][2];
+  char* const tile0 = reinterpret_cast<char*>(a.a_tiles) + ((int64_t)bh * NT * NT + (int64_t)min(wave_s, NT - 1) * NT) * 2048;
+  char* const tiles = tile0 + lane * 16;                       // stores (lanes with a query row only)
+  const char* const tiles_ld = tile0 + (q_on ? lane : 0) * 16;
+  const bool half_empty = (a.N & 31) != 0 && (a.N & 31) <= 16;
+  auto piece_on = [&](int kb, int t) __attribute__((always_inline)) { return kb < NT && !(t == 1 && kb == NT - 1 && half_empty); };   // wave-uniform
   f32x4 vr[IT];
   uint2 vs[IT];   // the value reference of the same 4 channels (gated frames)
   T* const vst = reinterpret_cast<T*>(a.v_state) + ((int64_t)b * a.N * a.D + h * DH);
@@ -161,27 +178,45 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
     vs[it] = make_uint2(0u, 0u);
     if (!first) vs[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(vst) + (uint32_t)(jc * a.D + c4 * 4) * 2u);
   }
-  // gate reference tiles of this wave's query rows: tile (wave, kb) = 2 KB, piece t of a lane = its 8 keys of MFMA step (kb, t)
-  uint4 oa[NB][2];
-  char* const tiles = reinterpret_cast<char*>(a.a_tiles) + ((int64_t)bh * NT * NT + (int64_t)min(wave_s, NT - 1) * NT) * 2048 + lane * 16;
-  if (!first) {
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
-      if (kb < NT) {
-        oa[kb][0] = *reinterpret_cast<const uint4*>(tiles + kb * 2048);
-        oa[kb][1] = *reinterpret_cast<const uint4*>(tiles + kb * 2048 + 1024);
-      }
-  }
-  GT_TICK(0);   // requests issued
+  GT_TICK(0);   // zero fill + requests issued
 
-  // ---- value planes and selection masks start as zeros (the columns of keys that are not selected STAY zero) ----------------
-  {
-    uint4* z = reinterpret_cast<uint4*>(smem + L::k_bytes);
-    constexpr int ZN = (int)((2 * L::v_plane + L::mask_bytes) / 16);
-    for (int e = tid; e < ZN; e += NTH) z[e] = make_uint4(0u, 0u, 0u, 0u);
+  // ---- q rows -> MFMA fragments through a wave-private LDS block (inside the K plane region, which is written behind the barrier
+  //      below): rows at pitch 68 floats, the fragment reads of 16 rows cover the 64 banks once.  q / self.scale (blocks.py:514; a
+  //      power-of-two scale makes the reciprocal multiply exact), split into bf16 hi | lo. ---------------------------------------
+  const float inv_scale = 1.0f / a.scale;
+  const bool pow2 = (inv_scale * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
+  bf16x8_t qh[4], ql[4];
+  if (wave_on) {   // (a wave without query rows has no staging block: the region only holds NB of them)
+    constexpr int QP = DH + 4;
+    static_assert((size_t)NB * 32 * QP * 4 <= L::k_bytes, "the q staging blocks fit the K plane region");
+    float* qst = reinterpret_cast<float*>(smem) + (size_t)wave * 32 * QP;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(qst + ((lane >> 4) + 4 * i) * QP + 4 * (lane & 15)) = qg[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    f32x4 qraw[8];   // channels 16 s + 8 lh + {0..3, 4..7} (s = piece / 2)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) qraw[m] = *reinterpret_cast<const f32x4*>(qst + lr * QP + 16 * (m >> 1) + 8 * lh + 4 * (m & 1));
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float4 q0 = make_float4(qraw[2 * s4][0], qraw[2 * s4][1], qraw[2 * s4][2], qraw[2 * s4][3]);
+      float4 q1 = make_float4(qraw[2 * s4 + 1][0], qraw[2 * s4 + 1][1], qraw[2 * s4 + 1][2], qraw[2 * s4 + 1][3]);
+      if (pow2) {
+        q0.x *= inv_scale; q0.y *= inv_scale; q0.z *= inv_scale; q0.w *= inv_scale;
+        q1.x *= inv_scale; q1.y *= inv_scale; q1.z *= inv_scale; q1.w *= inv_scale;
+      } else {
+        q0.x /= a.scale; q0.y /= a.scale; q0.z /= a.scale; q0.w /= a.scale;
+        q1.x /= a.scale; q1.y /= a.scale; q1.z /= a.scale; q1.w /= a.scale;
+      }
+      bf16x4_t h0, l0, h1, l1;
+      split4(q0, &h0, &l0);
+      split4(q1, &h1, &l1);
+      qh[s4] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      ql[s4] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   }
-  __syncthreads();
-  GT_TICK(1);   // zero fill + barrier
+  __syncthreads();   // zero fill complete; every wave holds its q fragments (the K planes overwrite the staging blocks)
+  GT_TICK(1);   // q fragments + barrier
 
   // ---- K rows -> bf16 hi | lo planes (key-major) -----------------------------------------------------------------------------
 #pragma unroll
@@ -222,28 +257,29 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
   }
   __syncthreads();   // the last workgroup barrier: K planes, value planes and masks are resident
   GT_TICK(2);   // planes written + barrier
-  if (!wave_on) return;
-
-  // ---- q / self.scale (blocks.py:514; a power-of-two scale makes the reciprocal multiply exact), split into bf16 hi | lo ------
-  const float inv_scale = 1.0f / a.scale;
-  const bool pow2 = (inv_scale * a.scale == 1.0f) && ((__float_as_uint(a.scale) & 0x007fffffu) == 0u);
-  bf16x8_t qh[4], ql[4];
+  // Second wave of requests, for the data that is not needed before pass 2 / the epilogue: the gate reference tiles of this wave's
+  // query rows and its A.v state rows.  Asked for here instead of in the prologue they fly during the score products, the softmax and
+  // pass 1 -- a CU sustains only so many outstanding lines (~45 KB in flight: the prologue's 255 KB took 11 us at 22 GB/s while the
+  // memory pipe idled through the 12 us of arithmetic that followed), so spreading the requests over the workgroup's life is what
+  // raises the bytes per second, not issuing them earlier.
+  // A.v state rows of the epilogue, coalesced (8 lanes x 16 bytes per row of this head, 8 rows per instruction): they reach the
+  // lanes that own the channels through the wave's LDS block (below).  Read straight into the accumulator layout -- 4 channels of
+  // 32 different rows per instruction -- every 8-byte piece was a line request of its own: with the next gate's reference and the
+  // state stores, 63 % of all the line requests of a workgroup.
+  T* const pvb = reinterpret_cast<T*>(a.pv) + ((int64_t)b * a.N * a.D + h * DH);
+  u32x4 pvc[4];
+  if (!first) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    float4 q0 = make_float4(qraw[2 * s][0], qraw[2 * s][1], qraw[2 * s][2], qraw[2 * s][3]);
-    float4 q1 = make_float4(qraw[2 * s + 1][0], qraw[2 * s + 1][1], qraw[2 * s + 1][2], qraw[2 * s + 1][3]);
-    if (pow2) {
-      q0.x *= inv_scale; q0.y *= inv_scale; q0.z *= inv_scale; q0.w *= inv_scale;
-      q1.x *= inv_scale; q1.y *= inv_scale; q1.z *= inv_scale; q1.w *= inv_scale;
-    } else {
-      q0.x /= a.scale; q0.y /= a.scale; q0.z /= a.scale; q0.w /= a.scale;
-      q1.x /= a.scale; q1.y /= a.scale; q1.z /= a.scale; q1.w /= a.scale;
-    }
-    bf16x4_t h0, l0, h1, l1;
-    split4(q0, &h0, &l0);
-    split4(q1, &h1, &l1);
-    qh[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    ql[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    for (int i = 0; i < 4; ++i)
+      pvc[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(pvb) + (uint32_t)(min(i0 + (lane >> 3) + 8 * i, a.N - 1) * a.D + (lane & 7) * 8) * 2u);
+  }
+  // (the tiles go out behind the state rows: vmcnt retires in order, and the state rows are wanted first -- behind the next barrier)
+  if (!first) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (piece_on(kb, t)) oa[kb][t] = *reinterpret_cast<const uint4*>(tiles_ld + kb * 2048 + t * 1024);
   }
 
   // ---- S^T = K (q / scale)^T: block kb = keys 32 kb .. + 31; lane (lr, lh), register r = 4 g + e holds key 32 kb + 8 g + 4 lh + e
@@ -253,7 +289,7 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
   for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
-    if (kb < NT) {
+    if (kb < NT && wave_on) {
       const __bf16* kh_row = Khi + (size_t)(32 * kb + lr) * KPB + 8 * lh;
       const __bf16* kl_row = Klo + (size_t)(32 * kb + lr) * KPB + 8 * lh;
 #pragma unroll
@@ -266,7 +302,18 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
       }
     }
   }
-  GT_TICK(3);   // q fragments + S^T products
+  // Every wave is done with the K planes: from here on the region is ONE PRIVATE BLOCK PER WAVE (32 rows x 288 bytes), through which
+  // the epilogue's rows travel between whole-line global accesses and the accumulator layout.  No wave waits for another again.
+  __syncthreads();
+  if (!wave_on) return;
+  constexpr int EPB = 144, EPF = 272;   // row pitch of the block in bytes: 64 store-type elements + 8, 64 floats + 4
+  static_assert(32 * EPF <= 32 * KPB * 4 && (size_t)NB * 32 * KPB * 4 <= L::k_bytes, "one epilogue block per wave inside the K region");
+  char* const eb = reinterpret_cast<char*>(smem) + (size_t)wave * 32 * KPB * 4;
+  if (!first) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(eb + ((lane >> 3) + 8 * i) * EPB + (lane & 7) * 16) = pvc[i];
+  }
+  GT_TICK(3);   // S^T products + barrier
 
   // ---- softmax of the lane's row (its other half sits in lane ^ 32) --------------------------------------------------------
   float mx = -INFINITY;
@@ -310,6 +357,17 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
         AN[kb][t] = make_uint4(HT::pack2(S[kb][8 * t + 0] * rinv, S[kb][8 * t + 1] * rinv), HT::pack2(S[kb][8 * t + 2] * rinv, S[kb][8 * t + 3] * rinv),
                                HT::pack2(S[kb][8 * t + 4] * rinv, S[kb][8 * t + 5] * rinv), HT::pack2(S[kb][8 * t + 6] * rinv, S[kb][8 * t + 7] * rinv));
 
+  // the next gate's reference rows of this head, coalesced (16 lanes x 16 bytes per row, 4 rows per instruction)
+  f32x4 nrc[8];
+  auto load_nref = [&]() __attribute__((always_inline)) {
+    const char* nb = reinterpret_cast<const char*>(a.norm_ref + ((int64_t)b * a.N * a.D + h * DH));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      nrc[i] = *reinterpret_cast<const f32x4*>(nb + (uint32_t)(min(i0 + (lane >> 4) + 4 * i, a.N - 1) * a.D + (lane & 15) * 4) * 4u);
+  };
+
+  if (a.norm_ref != nullptr) load_nref();   // (the score registers are free again: lands during the two passes)
+
   // ---- pass 1: O1^T = Vd^T a~^T.  MFMA step (kb, t) contracts keys 32 kb + 16 t + 4 lh' + {0..3, 8..11} -- the keys of a lane's
   //      registers 8 t .. 8 t + 7 of block kb -- against the plane's row pieces at the same keys.  First frame: the probabilities
   //      are also the new gate reference (their packing IS the tile layout). --------------------------------------------------
@@ -327,12 +385,13 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
   for (int kb = 0; kb < NB; ++kb)
     if (kb < NT) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int k0 = 32 * kb + 16 * t + 4 * lh;
+      for (int t = 0; t < 2; ++t)
+        if (piece_on(kb, t)) {
+          const int k0 = 32 * kb + 16 * t + 4 * lh;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) O[d] = HT::mfma(vfrag(Vd, d, k0), AN[kb][t], O[d]);
-        if (first) *reinterpret_cast<uint4*>(tiles + kb * 2048 + t * 1024) = AN[kb][t];
-      }
+          for (int d = 0; d < 2; ++d) O[d] = HT::mfma(vfrag(Vd, d, k0), AN[kb][t], O[d]);
+          if (first && q_on) *reinterpret_cast<uint4*>(tiles + kb * 2048 + t * 1024) = AN[kb][t];
+        }
     }
   GT_TICK(5);   // pass 1
   // round(a~ . dv~), packed: lane (query lr, lh), word 2 g + w of tile d = channels 32 d + 8 g + 4 lh + 2 w, + 1
@@ -342,28 +401,16 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
 #pragma unroll
     for (int w = 0; w < 8; ++w) r1[d][w] = HT::pack2(O[d][2 * w], O[d][2 * w + 1]);
 
-  // A.v state rows of the epilogue: requested here, they land during pass 2
-  T* const pvrow = reinterpret_cast<T*>(a.pv) + ((int64_t)b * a.N + min(iq, a.N - 1)) * a.D + h * DH + 4 * lh;
-  uint2 pvr[2][4];
-  if (!first) {
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pvr[d][g] = *reinterpret_cast<const uint2*>(pvrow + 32 * d + 8 * g);
-  }
-  const int64_t orow = ((int64_t)b * a.N + min(iq, a.N - 1)) * a.D + h * DH + 4 * lh;   // element offset of the lane's channels in (B,N,D)
-  f32x4 nrr[2][4];   // the next gate's reference at the lane's channels (norm_ref)
-  auto load_nref = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) nrr[d][g] = *reinterpret_cast<const f32x4*>(a.norm_ref + orow + 32 * d + 8 * g);
-  };
-
-  if (a.norm_ref != nullptr) load_nref();   // (lands during pass 2)
-
   // ---- pass 2 (gated frames): da~ = round(a~ - ref), O2^T = Vo^T da~^T, ref = selected ? a~ : ref ------------------------------
   if (!first) {
+    // The epilogue's loads (the next gate's reference: requested in front of pass 1) are claimed HERE, while no store is in
+    // flight: the tile stores below sit in exec-masked blocks hipcc cannot count, so the first wait behind them is vmcnt(0) -- in the
+    // epilogue that would be a whole store round trip in the open.
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (a.norm_ref != nullptr) asm volatile("" : "+v"(nrc[4 * d + g]));
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -372,7 +419,8 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
     for (int kb = 0; kb < NB; ++kb)
       if (kb < NT) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t)
+          if (piece_on(kb, t)) {
           const uint4 an = AN[kb][t], old = oa[kb][t];
           const uint4 m = *reinterpret_cast<const uint4*>(msk + ((kb * 2 + t) * 2 + lh) * 4);
           uint4 ad, nw;
@@ -387,14 +435,38 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
           const int k0 = 32 * kb + 16 * t + 4 * lh;
 #pragma unroll
           for (int d = 0; d < 2; ++d) O[d] = HT::mfma(vfrag(Vo, d, k0), ad, O[d]);
-          *reinterpret_cast<uint4*>(tiles + kb * 2048 + t * 1024) = nw;
+          if (q_on) *reinterpret_cast<uint4*>(tiles + kb * 2048 + t * 1024) = nw;
         }
       }
   }
   GT_TICK(6);   // pass 2
 
-  // ---- epilogue: pv = round(round(pv + round(O1)) + round(O2)) (first frame: pv = round(O1)); out = pv; heads merged ---------
+  // ---- epilogue: pv = round(round(pv + round(O1)) + round(O2)) (first frame: pv = round(O1)); out = pv; heads merged.  Lane (query
+  //      lr, lh) owns channels 32 d + 8 g + 4 lh + 0..3; rows move between that layout and whole-line global accesses through `eb`.
+  auto wave_sync = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
+  const uint32_t ech = (uint32_t)(4 * lh);
+  uint2 pvr[2][4];
+  f32x4 nrr[2][4];
+  if (!first) {
+    wave_sync();
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pvr[d][g] = *reinterpret_cast<const uint2*>(eb + lr * EPB + (32 * d + 8 * g + ech) * 2);
+  }
+  if (a.norm_ref != nullptr) {
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(eb + ((lane >> 4) + 4 * i) * EPF + (lane & 15) * 16) = nrc[i];
+    wave_sync();
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) nrr[d][g] = *reinterpret_cast<const f32x4*>(eb + lr * EPF + (32 * d + 8 * g + ech) * 4);
+  }
+  wave_sync();
   float ss = 0.f;
+  uint2 res[2][4];
 #pragma unroll
   for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -407,16 +479,38 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
         w0 = HT::pack2(HT::lo(w0) + HT::lo(s0), HT::hi(w0) + HT::hi(s0));
         w1 = HT::pack2(HT::lo(w1) + HT::lo(s1), HT::hi(w1) + HT::hi(s1));
       }
-      const f32x4 v = {HT::lo(w0), HT::hi(w0), HT::lo(w1), HT::hi(w1)};
-      if (q_on) {
-        *reinterpret_cast<uint2*>(pvrow + 32 * d + 8 * g) = make_uint2(w0, w1);
-        if (a.out_f32 != nullptr) *reinterpret_cast<f32x4*>(a.out_f32 + orow + 32 * d + 8 * g) = v;
-      }
+      res[d][g] = make_uint2(w0, w1);
+      *reinterpret_cast<uint2*>(eb + lr * EPB + (32 * d + 8 * g + ech) * 2) = res[d][g];
       if (a.norm_ref != nullptr) {
-        const float e0 = v[0] - nrr[d][g][0], e1 = v[1] - nrr[d][g][1], e2 = v[2] - nrr[d][g][2], e3 = v[3] - nrr[d][g][3];
+        const float e0 = HT::lo(w0) - nrr[d][g][0], e1 = HT::hi(w0) - nrr[d][g][1], e2 = HT::lo(w1) - nrr[d][g][2], e3 = HT::hi(w1) - nrr[d][g][3];
         ss += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
       }
     }
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    if (i0 + row < a.N)
+      *reinterpret_cast<uint4*>(reinterpret_cast<char*>(pvb) + (uint32_t)((i0 + row) * a.D + (lane & 7) * 8) * 2u) =
+          *reinterpret_cast<const uint4*>(eb + row * EPB + (lane & 7) * 16);
+  }
+  if (a.out_f32 != nullptr) {   // launch-uniform; NULL: the caller reads the (identical) values from the A.v state
+    wave_sync();
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(eb + lr * EPF + (32 * d + 8 * g + ech) * 4) =
+            (f32x4){HT::lo(res[d][g].x), HT::hi(res[d][g].x), HT::lo(res[d][g].y), HT::hi(res[d][g].y)};
+    wave_sync();
+    char* const ob = reinterpret_cast<char*>(a.out_f32 + ((int64_t)b * a.N * a.D + h * DH));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (lane >> 4) + 4 * i;
+      if (i0 + row < a.N)
+        *reinterpret_cast<f32x4*>(ob + (uint32_t)((i0 + row) * a.D + (lane & 15) * 4) * 4u) = *reinterpret_cast<const f32x4*>(eb + row * EPF + (lane & 15) * 16);
+    }
+  }
   if (a.norm_ref != nullptr) {
     // the other half of the head's channels sits in lane ^ 32; lane half 0 writes the (token, head) partial (evt_select_*_sq adds
     // the H partials of a token in index order)

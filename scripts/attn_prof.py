@@ -85,7 +85,7 @@ if a.gated:
     lib = n.load()
     lib.evt_debug_prof_gated.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
     assert lib.evt_debug_prof_gated(buf) == 0
-    names = ["requests issued", "zero fill + barrier", "planes written (K split, value gate) + barrier", "q fragments + S^T products",
+    names = ["zero fill + requests issued", "q fragments (through LDS) + barrier", "planes written (K split, value gate) + barrier", "S^T products",
              "softmax", "pack + pass 1 (a~ . dv~)", "pass 2 (A gate, da~ . v_old, tile stores)", "epilogue"]
     tot = sum(buf[q] for q in range(8))
     print(f"K10 gated frame: wave 0 of one workgroup: {tot} ticks")
