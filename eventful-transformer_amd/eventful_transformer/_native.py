@@ -327,8 +327,11 @@ def norm_order(order):
 
 def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=None, eps=1e-6, c_out=None, p=None,
              norms=None, order=2):
-    _check(load().evt_row_pass_ord(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
-                                   _p(norms), rows, D, norm_order(order), _stream()))
+    # "rows" family (bench.py): algorithmic bytes = every (rows, D) fp32 tensor the pass reads or writes, once (+ the norms)
+    tensors = 1 + (res is not None) + (sum_out is not None) + (c_out is not None) + (p is not None)
+    _timed("rows", 4.0 * rows * D * tensors + (4.0 * rows if norms is not None else 0.0),
+           lambda: _check(load().evt_row_pass_ord(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
+                                                  _p(norms), rows, D, norm_order(order), _stream())))
 
 
 def select_topk(norms, B, N, k, idx, rest=None, parts=0):
@@ -356,8 +359,9 @@ def scatter_rows(x, buf, idx, count, B, N, F, kcap):
 
 
 # bench.py brackets every launch of a workload's dominant kernel family with HIP events on the launch stream:
-# set_kernel_events("gemm" | "attn", list) -> entries (start_event, end_event, algorithmic work, launches), where
-# work is FLOP for "gemm" (K3/K7) and bytes for "attn" (the global-block attention kernels K5+K6 / K8).
+# set_kernel_events("gemm" | "attn" | "rows", list) -> entries (start_event, end_event, algorithmic work, launches), where
+# work is FLOP for "gemm" (K3/K7), bytes for "attn" (the EventfulBlock attention kernels K5+K6 / K8 / K9 / K10) and bytes for "rows"
+# (the HBM-bound row kernels: row passes -- residual add, LayerNorm, delta norm, gather-free -- and the stand-alone value gate).
 _EVENTS = {}
 
 
@@ -513,9 +517,12 @@ def v_gate(qkv, idx, count, B, N, D, kcap, v_state, v_delta, v_old, store, gated
     off = 2 * D if v_offset is None else v_offset
     rs = 3 * D if v_rs is None else v_rs
     pad = None if pad_row is None else _ptr_off(pad_row, off)
-    _check(load().evt_v_gate(_ptr_off(qkv, off), rs, _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta),
-                             _p(v_old), store, int(gated), int(transposed), _p(tok_map), groups_per_clip, clip_rows,
-                             pad, _stream()))
+    es = 4 if store == EVT_F32 else 2
+    n_rows = B * (kcap if gated else N)   # (capacity for a device-side count: the launch is priced by its list, the kernel skips dead rows)
+    _timed("rows", n_rows * D * (4.0 + (4.0 * es if gated else 1.0 * es)),
+           lambda: _check(load().evt_v_gate(_ptr_off(qkv, off), rs, _p(idx), _p(count), B, N, D, kcap, _p(v_state), _p(v_delta),
+                                            _p(v_old), store, int(gated), int(transposed), _p(tok_map), groups_per_clip, clip_rows,
+                                            pad, _stream())))
 
 
 def pool_kv(qkv, B, qh, qw, D, p0, p1, kv):

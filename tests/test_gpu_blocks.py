@@ -348,7 +348,11 @@ def test_vivit_b_sharp_bf16_projection_gates(golden_dir):
     state, not the split arithmetic.  The reference arithmetic itself, re-run at another ATen thread count, does not re-order these
     sums (`selfdiff` all false) and offers no noise floor of its own.  Required: EVERY qkv / mlp gate at margin >= 1e-3 bit-equal
     (2592 of them), projection gates: at least 70 % of those at margin >= 1e-3 (>= 60 checked), the table by margin bar reported.
-    The strict projection-gate claim is the fp32-mode test (test_vivit_b_teacher_forced[sharp]: 68 / 68)."""
+    The strict projection-gate claim is the fp32-mode test (test_vivit_b_teacher_forced[sharp]: 68 / 68).
+    ROUND 6: what the 79 % is made of was then measured (test_vivit_b_sharp_bf16_projection_gates_state_forced, below): with every
+    block-frame started from the oracle's state the HIP projection gates equal the oracle's on 554 / 554 sets at margin >= 1e-4 -- and the
+    oracle run on the GPU box's CPU reproduces these GOLDEN sets (the same arithmetic, run on the build machine, free-running) on only
+    381 / 548.  The rate below is the drift of the bf16 states between two machines' fp32 summation orders, not the kernels' arithmetic."""
     g = H.load_npz(os.path.join(golden_dir, "vivit_b_sharp_clips.npz"))
     k, cast, steps = int(g["k"]), "bfloat16", int(g["steps"])
     margins_all, idx_all = g["margins"], g["idx"]
@@ -400,7 +404,9 @@ def test_vivit_b_sharp_bf16_projection_gates_state_forced(golden_dir):
     arithmetic of that one block-frame.  Beside it, under the identical protocol, an ORACLE TWIN with the reference's rounding points
     and another summation order (_ExactSumTwin: fp64 accumulation, one rounding per op result): the rate at which THAT disagrees with the
     reference is what the order of fp32 additions alone does to these near-tied, bf16-quantised deltas.  Required: qkv / mlp gates at
-    margin >= 1e-3 all equal; the HIP path's projection-gate agreement at margin >= 1e-4 not below the twin's by more than 3 points."""
+    margin >= 1e-3 all equal; EVERY projection-gate set at an in-situ margin >= 1e-4 equal to the oracle's (the north_star's "bit-exact
+    gate indices" in the headline's own arithmetic mode); at >= 1e-5 no more than two sets behind the twin.  Measured beside it: how often
+    the oracle run in situ (this machine's CPU) reproduces the GOLDEN sets of the same arithmetic run on the build machine."""
     g = H.load_npz(os.path.join(golden_dir, "vivit_b_sharp_clips.npz"))
     k, cast, steps = int(g["k"]), "bfloat16", int(g["steps"])
     margins_all, idx_all = g["margins"], g["idx"]
@@ -443,8 +449,10 @@ def test_vivit_b_sharp_bf16_projection_gates_state_forced(golden_dir):
              f"(same arithmetic on two machines, free-running): {gold}; HIP vs the golden run: {hip_gold}; qkv + mlp gates at margin >= 1e-3 (HIP vs "
              f"in situ): {other[1]}/{other[0]}")
     assert other[0] >= 300 and other[1] == other[0], other
-    assert hip[1e-3][0] >= 200, hip
-    assert hip[1e-3][1] / hip[1e-3][0] >= tw[1e-3][1] / tw[1e-3][0] - 0.03, (hip, tw)
+    # observed: 554 / 554 at margin >= 1e-4 (573 / 574 at >= 1e-5) for the HIP path AND for the twin; the in-situ oracle agrees with the
+    # golden run (another machine's BLAS summation order, free-running) on 381 / 548 -- the "79 %" of the test above is that drift
+    assert hip[1e-4][0] >= 300 and hip[1e-4][1] == hip[1e-4][0], hip
+    assert hip[1e-5][1] >= tw[1e-5][1] - 2, (hip, tw)
 
 
 _STATE_SLOTS = ("qkv_gate", "qkv_accumulator", "projection_gate", "projection_accumulator", "mlp_gate", "mlp_accumulator", "v_gate",
@@ -624,6 +632,7 @@ def test_timing_configs_vitdet(golden_dir, case, grid, k, pool, stride):
     idx_gold, margins = view["idx"], view["margins"]
     gi_of = {"qkv": 0, "projection": 1, "mlp": 2}
     st = {"n": 0, "equal": 0, "checked": 0, "checked_equal": 0, "differ": []}
+    buckets = {lo: [0, 0] for lo in (0.0, 1e-6, 1e-5, 1e-4, 1e-3)}   # reference margin in [lo, next lo): [sets, equal]
 
     def tap(_blk, tag, idx, count):
         n = st["n"]
@@ -708,6 +717,7 @@ def test_vitdet_672_topk(golden_dir, monkeypatch, dense_norm_rows, forced):
     gi_of = {"qkv": 0, "projection": 1, "mlp": 2}
     bar = 1e-4 if forced else 1e-3
     st = {"n": 0, "equal": 0, "checked": 0, "checked_equal": 0, "differ": []}
+    buckets = {lo: [0, 0] for lo in (0.0, 1e-6, 1e-5, 1e-4, 1e-3)}   # reference margin in [lo, next lo): [sets, equal]
 
     def tap(_blk, tag, idx, count):
         n = st["n"]
@@ -718,6 +728,9 @@ def test_vitdet_672_topk(golden_dir, monkeypatch, dense_norm_rows, forced):
         same = torch.equal(idx[0].cpu().long(), want)
         m = float(margins[t, bi, gi])
         st["equal"] += same
+        lo = max(b_ for b_ in buckets if m >= b_)
+        buckets[lo][0] += 1
+        buckets[lo][1] += same
         if m >= bar:
             st["checked"] += 1
             st["checked_equal"] += same
@@ -734,7 +747,8 @@ def test_vitdet_672_topk(golden_dir, monkeypatch, dense_norm_rows, forced):
     finally:
         evt_blocks.INDEX_TAP = None
     H.report(f"    [{'teacher-forced' if forced else 'free-running'}, dense_norm_rows={dense_norm_rows}] gate index sets equal to the "
-             f"reference's: {st['equal']}/{st['n']}; at reference margin >= {bar:.0e}: {st['checked_equal']}/{st['checked']}; differing "
+             f"reference's: {st['equal']}/{st['n']}; at reference margin >= {bar:.0e}: {st['checked_equal']}/{st['checked']}; by reference margin "
+             f"bucket [lo, next) (sets, equal): { {f'{lo:.0e}': v for lo, v in buckets.items()} }; differing "
              f"sets (frame, block, gate, reference margin): {[(t, b, g_, f'{m:.1e}') for t, b, g_, m in st['differ']]}")
     assert st["n"] == idx_gold.shape[0] * 36 == 72
     assert st["checked"] >= (60 if forced else 50) and st["checked_equal"] == st["checked"], st
