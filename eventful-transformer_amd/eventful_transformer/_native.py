@@ -28,6 +28,8 @@ ABI_SYMBOLS = (
     "evt_gated_linear_workspace_bytes", "evt_gated_linear_big_tile", "evt_gated_mlp", "evt_split_weights", "evt_split_weights_bytes", "evt_qk", "evt_softmax_gate", "evt_v_gate", "evt_av", "evt_softmax_av_gated", "evt_rel_terms", "evt_pool_kv", "evt_pool_index",
     "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
     "evt_attention_gated", "evt_attention_gated_fits", "evt_attention_gated_tile_bytes",
+    "evt_gate_cols", "evt_scatter_cols", "evt_gate_rows_any", "evt_move_rows_any", "evt_gather_rows_map", "evt_scatter_rows_map",
+    "evt_ats_scores", "evt_ats_stabilize",
 )
 
 
@@ -183,6 +185,14 @@ def _bind(lib):
         "evt_attention_stream": [POINTER(AttnStreamDesc), P],
         "evt_stream_prep": [POINTER(StreamPrepDesc), P],
         "evt_attention_gated": [POINTER(AttnGatedDesc), P],
+        "evt_gate_cols": [P, P, P, P, I, I, I, I, I, P, P, I, P],
+        "evt_scatter_cols": [P, P, P, P, I, I, I, I, I, P],
+        "evt_gate_rows_any": [P, P, P, P, I, I, I, I, I, P, P, I, P],
+        "evt_move_rows_any": [P, P, I, I, I, I, I, I, I, P, P],
+        "evt_gather_rows_map": [P, P, P, I, I, I, I, I, P, P],
+        "evt_scatter_rows_map": [P, P, I, I, I, I, P, P],
+        "evt_ats_scores": [P, P, c_int64, c_int64, c_int64, I, I, I, I, I, P, P],
+        "evt_ats_stabilize": [P, P, I, I, I, P, P],
         "evt_av": [POINTER(AvDesc), P],
     }
     for name, argtypes in sigs.items():
@@ -695,6 +705,43 @@ def attention_gated(qkv, a_tiles, v_state, pv, B, H, N, D, scale, store, first, 
         per_row = 2.0 * es * H * N + 4.0 * D + 2.0 * es * D
         fixed = B * (8.0 * N * D + 2.0 * es * N * D + out_b)
         _timed("attn", fixed + (B * kcap * per_row if count is None else 0.0), call, count=count, per_row=per_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# Index-structured operations off the fused path (evt_gather.hip, evt_ats.hip): stand-alone gates / buffers, window partition, ATS
+# ------------------------------------------------------------------------------------------------
+def gate_cols(c, p, idx, count, Bp, R, N, kcap, c_tilde=None, e_tilde=None, update_p=True):
+    _check(load().evt_gate_cols(_p(c), _p(p), _p(idx), _p(count), Bp, R, N, kcap, store_code(c.dtype), _p(c_tilde), _p(e_tilde), int(update_p), _stream()))
+
+
+def scatter_cols(x, buf, idx, count, Bp, R, N, kcap):
+    _check(load().evt_scatter_cols(_p(x), _p(buf), _p(idx), _p(count), Bp, R, N, kcap, store_code(buf.dtype), _stream()))
+
+
+def gate_rows_any(c, p, idx, count, Bp, N, F, kcap, c_tilde=None, e_tilde=None, update_p=True):
+    _check(load().evt_gate_rows_any(_p(c), _p(p), _p(idx), _p(count), Bp, N, F, kcap, store_code(c.dtype), _p(c_tilde), _p(e_tilde), int(update_p), _stream()))
+
+
+def move_rows_any(x, index_map, B, N, F, n, out, rep=1, scatter=False):
+    _check(load().evt_move_rows_any(_p(x), _p(index_map), B, N, F, n, rep, int(scatter), store_code(x.dtype), _p(out), _stream()))
+
+
+def gather_rows_map(x, index_map, B, N, F, n_out, out, pad_row=None, map_per_batch=False):
+    _check(load().evt_gather_rows_map(_p(x), _p(index_map), _p(pad_row), B, N, F, n_out, int(map_per_batch), _p(out), _stream()))
+
+
+def scatter_rows_map(x, index_map, B, n_in, N, F, out):
+    _check(load().evt_scatter_rows_map(_p(x), _p(index_map), B, n_in, N, F, _p(out), _stream()))
+
+
+def ats_scores(a, v, B, H, N, dh, scores):
+    """a (B,H,N,N) contiguous, v (B,H,N,dh) any strides with contiguous channels, same dtype -> scores (H,N) fp32."""
+    assert a.dtype == v.dtype and a.is_contiguous() and v.stride(-1) == 1
+    _check(load().evt_ats_scores(_p(a), _p(v), v.stride(0), v.stride(1), v.stride(2), B, H, N, dh, store_code(a.dtype), _p(scores), _stream()))
+
+
+def ats_stabilize(last, now, rows, n, N, out):
+    _check(load().evt_ats_stabilize(_p(last), _p(now), rows, n, N, _p(out), _stream()))
 
 
 def attention_dense_fits(N, D, H):

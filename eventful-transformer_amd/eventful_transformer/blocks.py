@@ -59,6 +59,7 @@ QK_FULL_RATIO = 0.7
 # FUSE_DENSE_NORM_ROWS token rows per launch on (one stream: 1.84 vs 1.81 ms per 672^2 frame -- the epilogue's reference reads and
 # the 12-partial selection cost what the 6 us row pass did; eight streams 6.37 vs 6.41 ms).
 FUSE_DENSE_NORM_ROWS = 8192
+PROJ_FROM_STATE = True   # (module constant: tests/big_tile_check.py turns it off to compare with the fp32-output path, bit for bit)
 # Module constant, not an environment switch: the tests set it to False to run pooled blocks with > 256 tokens on the K4 + K5+K6
 # chain (the path of the grids whose tile does not fit evt_attention_stream) and compare.
 STREAM_POOLED = True
@@ -165,7 +166,6 @@ class Block(ExtendedModule):
         self.gelu = nn.GELU()
         self.mlp_2 = CountedLinear(in_features=dim * mlp_ratio, out_features=dim)
         self._wmap = None
-        self._wpool_index = None
         self._norm_fusable = {}
 
     # ---------------------------------------------------------------------------------------------
@@ -173,6 +173,7 @@ class Block(ExtendedModule):
     # ---------------------------------------------------------------------------------------------
     def reset_self(self):
         self.last_ats_indices = None
+        self._last_ats_i32 = None
 
     def _store_dtype(self):
         return torch.float32 if self.matmul_2_cast is None else getattr(torch, self.matmul_2_cast)
@@ -234,35 +235,40 @@ class Block(ExtendedModule):
         return ln.weight, ln.bias
 
     # -- adaptive token sampling (blocks.py:150-181, 378-391, 196-203) --------------------------------
-    # Off the fast path: the q.k^T / softmax / A.v contractions still run on K4 / K5 / K6, the token scoring and index
-    # bookkeeping (a few thousand scalars) are ATen ops on the HIP device, and the selection stays on the device
-    # (the reference moves it to the CPU for `_stabilize_ats_indices`).  The reference sums its scores over the
-    # BATCH axis (`scores.sum(dim=-3)` on a (B, H, N) tensor, blocks.py:163), so -- like the reference -- this only
-    # runs when batch == heads: clip b then keeps the tokens ranked by head b's scores summed over all clips.
+    # Off the fast path: the q.k^T / softmax / A.v contractions run on K4 / K5 / K6, the token scoring on evt_ats_scores, the
+    # selection on evt_select_topk, the stabilisation on evt_ats_stabilize, the row gathers on evt_gather_rows_map /
+    # evt_move_rows_any -- and the selection stays on the device (the reference moves it to the CPU for
+    # `_stabilize_ats_indices`).  The reference sums its scores over the BATCH axis (`scores.sum(dim=-3)` on a (B, H, N)
+    # tensor, blocks.py:163), so -- like the reference -- this only runs when batch == heads: clip b then keeps the tokens ranked by
+    # head b's scores summed over all clips.
     def _ats_select(self, a, v):
         """a (B,H,N,N) probabilities, v (B,H,N,dh) (both already in the dtype the reference scores in) -> (H, n) int64."""
         B, H, N = a.shape[0], a.shape[1], a.shape[2]
         if B != H:
             raise RuntimeError(f"ats_fraction: the reference's adaptive token sampling sums its scores over the batch axis "
                                f"(blocks.py:163) and only runs when batch == heads; got batch {B}, heads {H}")
-        raw = a[..., 0] * torch.linalg.vector_norm(v, dim=-1)
-        scores = raw / raw[..., 1:].sum(dim=-1, keepdim=True)
-        scores[..., 0] = float("inf")
-        scores = scores.sum(dim=-3)
+        scores = self._ws("ats_scores", (H, N), torch.float32, a)
+        _native.ats_scores(a if a.is_contiguous() else a.contiguous(), v, B, H, N, v.shape[-1], scores)
         n_select = int(self.ats_fraction * (N - 1)) + 1
-        index = scores.topk(n_select, sorted=False)[1].sort(dim=-1)[0]
-        last = self.last_ats_indices
-        if last is not None:  # keep every surviving token at last frame's position (blocks.py:378-391)
-            gone = ~(last.unsqueeze(-1) == index.unsqueeze(-2)).any(dim=-1)
-            fresh = ~(index.unsqueeze(-1) == last.unsqueeze(-2)).any(dim=-1)
-            index = last.masked_scatter(gone, index[fresh])   # per row #gone == #fresh, both in ascending order
-        self.last_ats_indices = index
-        return index
+        now = self._ws("ats_now", (H, n_select), torch.int32, a)
+        _native.select_topk(scores, H, N, n_select, now)          # ascending lists (blocks.py:380 sorts them)
+        index32 = torch.empty((H, n_select), dtype=torch.int32, device=a.device)
+        last = self.__dict__.get("_last_ats_i32")
+        if last is not None and self.last_ats_indices is not None:   # keep every surviving token at last frame's position (blocks.py:378-391)
+            _native.ats_stabilize(last, now, H, n_select, N, index32)
+        else:
+            index32.copy_(now)
+        self._last_ats_i32 = index32
+        self.last_ats_indices = index32.long()
+        return self.last_ats_indices
 
-    @staticmethod
-    def _ats_rows(x, index):
+    def _ats_rows(self, x, index):
         """x (B, N, F) -> rows index[b] of clip b: (B, n, F) (`_gather_ats_skip`, blocks.py:196-203)."""
-        return x.gather(dim=1, index=index.unsqueeze(-1).expand(-1, -1, x.shape[-1])).contiguous()
+        B, N, F = x.shape
+        n = index.shape[-1]
+        out = torch.empty((B, n, F), dtype=x.dtype, device=x.device)
+        _native.gather_rows_map(x if x.is_contiguous() else x.contiguous(), self._last_ats_i32, B, N, F, n, out, map_per_batch=True)
+        return out
 
     def _heads_v(self, qkv, B, N):
         """Value heads (B,H,N,dh) as a view of the packed (B,N,3D) buffer (blocks.py:248-255)."""
@@ -295,7 +301,10 @@ class Block(ExtendedModule):
         a = a32 if sdt == torch.float32 else a32.to(sdt)
         v = v.to(sdt) if sdt != torch.float32 else v.clone()
         index = self._ats_select(a, v)
-        a = a.gather(dim=2, index=index.view(B, 1, -1, 1).expand(-1, H, -1, N))
+        n_sel = index.shape[-1]
+        a_rows = torch.empty((B, H, n_sel, N), dtype=a.dtype, device=a.device)
+        _native.move_rows_any(a if a.is_contiguous() else a.contiguous(), self._last_ats_i32, B * H, N, N, n_sel, a_rows, rep=H)   # rows index[b] of every head of clip b
+        a = a_rows
         idx_v = None if self._ats_idx_k is None else self._ats_idx_k
         v_n, v_d, index_v = self.v_gate(v, forced_index=idx_v)
         a_n, a_d, _ = self.matmul_gate(a, forced_index=index_v)
@@ -356,8 +365,8 @@ class Block(ExtendedModule):
     def _attention_window_pooled(self, qkv, B, N, out, tok_map):
         """window_size together with pool_size (Block._forward_attention, blocks.py:205-240: `_partition_windows` in the qkv domain,
         then `_pool_tokens` on the WINDOW grid, blocks.py:308).  No reference config uses the combination, so it is kept simple:
-        the windows are gathered into contiguous groups (padding tokens = the qkv bias row, blocks.py:270-283; index ops on the
-        device), every window is pooled like a small clip (evt_pool_kv) and runs through the q.k^T / softmax / A.v launches with
+        the windows are gathered into contiguous groups (padding tokens = the qkv bias row, blocks.py:270-283;
+        evt_gather_rows_map / evt_scatter_rows_map), every window is pooled like a small clip (evt_pool_kv) and runs through the q.k^T / softmax / A.v launches with
         pooled keys; the rows are copied back to their tokens."""
         D, H = self.dim, self.heads
         dh = D // H
@@ -370,15 +379,9 @@ class Block(ExtendedModule):
         p0, p1 = self.pool_size
         assert d0 % p0 == 0 and d1 % p1 == 0, "token pooling needs a window size divisible by the pool size, as in the reference"
         nk = (d0 // p0) * (d1 // p1)
-        if self._wpool_index is None or self._wpool_index[0].device != qkv.device:
-            flat = tok_map.reshape(-1).long()
-            valid = (flat >= 0).nonzero().flatten()
-            self._wpool_index = (flat.clamp(min=0), (flat < 0).nonzero().flatten(), valid, flat[valid])
-        src, pad_pos, valid_pos, valid_tok = self._wpool_index
+        # windows as contiguous groups: rows through the window map, padding tokens = the qkv bias row (blocks.py:270-283)
         wq = self._ws("window_qkv", (B, gpc * n, 3 * D), torch.float32, qkv)
-        torch.index_select(qkv, 1, src, out=wq)
-        if pad_pos.numel():
-            wq[:, pad_pos] = self.qkv.bias
+        _native.gather_rows_map(qkv, tok_map, B, N, 3 * D, gpc * n, wq, pad_row=self.qkv.bias)
         wq = wq.view(G, n, 3 * D)
         kv = self._ws("pooled_kv", (G, nk, 2 * D), torch.float32, qkv)
         _native.pool_kv(wq, G, d0, d1, D, p0, p1, kv)
@@ -394,7 +397,7 @@ class Block(ExtendedModule):
         self._v_full(wq, kv, G, n, nk, v_s, store)
         _native.av(a_s, v_s, nk, G, H, n, nk, D, store, out_f32=out_w.view(G, n, D))
         self.matmul.count_product(G * H * n * dh, nk)
-        out.index_copy_(1, valid_tok, out_w.index_select(1, valid_pos))
+        _native.scatter_rows_map(out_w, tok_map, B, gpc * n, N, D, out)   # un-window: padding rows dropped (blocks.py:346-376)
 
     def _dense_norm_fusable(self, N):
         """True when `_attention_dense` runs the resident K8 kernel for this block (windowed or one group of <= 256 tokens, head dim
@@ -862,7 +865,7 @@ class EventfulBlock(EventfulMatmul1Block):
             # on the persistent GEMM (which takes bf16 activations: half the bytes, no split, two MFMAs of three), it reads the
             # state directly and this launch does not write the fp32 copy at all.
             state_src = False
-            if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+            if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                     and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
                 cap_p = pg.policy.capacity(N)
                 state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
@@ -924,7 +927,7 @@ class EventfulBlock(EventfulMatmul1Block):
         fuse_norm = not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
         state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
-        if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                 and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
             cap_p = pg.policy.capacity(N)
             state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0
@@ -1003,7 +1006,7 @@ class EventfulBlock(EventfulMatmul1Block):
         fuse_norm = not pg.first and isinstance(pg.policy, _NormPolicy) and pg.policy.order == 2 and pg.p is not None
         nparts = self._ws("norm_parts", (B, N, H), torch.float32, qkv) if fuse_norm else None
         state_src = False   # bf16 cast: the projection reads the A.v state (see _forward_attention)
-        if fuse_norm and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
+        if fuse_norm and PROJ_FROM_STATE and sdt == torch.bfloat16 and not isinstance(pg, SimpleSTGTGate) \
                 and self.projection.split_planes() is not None and pg.policy.fixed_count(N) is not None:
             cap_p = pg.policy.capacity(N)
             state_src = _native.gated_linear_big_tile(D, True, N, D, True, N, False, B, cap_p, D, D) != 0

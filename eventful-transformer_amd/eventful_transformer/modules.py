@@ -11,8 +11,9 @@ Each class keeps the reference's constructor, call signature, return values and 
 
 Inside `blocks.py` the fused path drives the same kernels directly on the packed token buffer and
 uses these modules only as the owners of the per-clip state.  Column-structured gates/buffers
-called stand-alone (the reference only ever uses them through EventfulBlock, where K5 does the
-work) and non-fp32 / non-contiguous stand-alone inputs are served by ATen-on-HIP gather/scatter.
+called stand-alone (the reference only ever uses them through EventfulBlock, where the fused
+attention kernels do the work) and non-fp32 / non-contiguous stand-alone inputs run on the generic
+kernels evt_gate_cols / evt_scatter_cols / evt_gate_rows_any / evt_move_rows_any.
 
 Index tensors returned to Python are int64 and ascending.
 """
@@ -22,7 +23,6 @@ from eventful_transformer import _native
 from eventful_transformer.base import ExtendedModule
 from eventful_transformer.counting import CountedMatmul
 from eventful_transformer.policies import _NormPolicy
-from eventful_transformer.utils import expand_col_index, expand_row_index
 
 
 def _rows_fast(*tensors):
@@ -107,16 +107,6 @@ class _GateBase(ExtendedModule):
         index = self.policy(c - self.p, dim=-1)
         return _index_i32(index, lead, c.device), None, index
 
-    def _apply_policy(self, x, forced_index):
-        """ATen-path helper with the reference's return convention (modules.py:154-164)."""
-        dim = -2 if self.structure == "row" else -1
-        if forced_index is None:
-            index = self.policy(x, dim=(-1 if self.structure == "row" else -2))
-        else:
-            index = forced_index
-        wide = expand_row_index(index, x.shape) if self.structure == "row" else expand_col_index(index, x.shape)
-        return dim, wide, index
-
 
 class TokenGate(_GateBase):
     """Token gate: forwards the tokens that changed most since they were last forwarded
@@ -148,11 +138,28 @@ class TokenGate(_GateBase):
             e_t = torch.empty_like(c_t) if want_delta else None
             _native.gate_gather_update(c, self.p, idx, count, Bp, N, D, cap, c_tilde=c_t, e_tilde=e_t, update_p=True)
             return c_t, e_t, index
-        e = c - self.p
-        dim, wide, index = self._apply_policy(e, forced_index)
-        c_t = c.gather(dim=dim, index=wide)
-        e_t = e.gather(dim=dim, index=wide) if want_delta else None
-        self.p.scatter_(dim=dim, index=wide, src=c_t)
+        return self._incremental_any(c, forced_index, want_delta, update_p=True)
+
+    def _incremental_any(self, c, forced_index, want_delta, update_p):
+        """Any other structure / element type / layout: the policy sees the delta tensor as in the reference (modules.py:149), the
+        gather, the delta and the reference update run on evt_gate_rows_any / evt_gate_cols (fp32 / bf16 / fp16)."""
+        row = self.structure == "row"
+        if c.dtype not in _native._STORE_OF:
+            raise NotImplementedError(f"MI355X build: gates take float32 / bfloat16 / float16 tensors, not {c.dtype}")
+        index = forced_index if forced_index is not None else self.policy(c - self.p, dim=(-1 if row else -2))
+        cc = c if c.is_contiguous() else c.contiguous()
+        if not self.p.is_contiguous() or self.p.dtype != c.dtype:   # (the first frame kept a reference to its input, whatever its layout)
+            self.p = self.p.to(c.dtype).contiguous()
+        lead, R, L = tuple(c.shape[:-2]), c.shape[-2], c.shape[-1]
+        idx = _index_i32(index, lead, c.device)
+        Bp, k = idx.shape
+        shape = lead + ((k, L) if row else (R, k))
+        c_t = torch.empty(shape, dtype=c.dtype, device=c.device)
+        e_t = torch.empty(shape, dtype=c.dtype, device=c.device) if want_delta else None
+        if row:
+            _native.gate_rows_any(cc, self.p, idx, None, Bp, R, L, k, c_tilde=c_t, e_tilde=e_t, update_p=update_p)
+        else:
+            _native.gate_cols(cc, self.p, idx, None, Bp, R, L, k, c_tilde=c_t, e_tilde=e_t, update_p=update_p)
         return c_t, e_t, index
 
     def forward_incremental(self, c, forced_index=None):
@@ -200,8 +207,7 @@ class SimpleSTGTGate(_GateBase):
             c_t = torch.empty(tuple(lead) + (cap, D), dtype=torch.float32, device=c.device)
             _native.gate_gather_update(c, None, idx, count, Bp, N, D, cap, c_tilde=c_t, update_p=False)
         else:
-            index = self.policy(c - self.p, dim=-1)
-            c_t = c.gather(dim=-2, index=expand_row_index(index, c.shape))
+            c_t, _, index = TokenGate._incremental_any(self, c, None, False, update_p=False)
         self.p = c
         return c_t, index
 
@@ -233,10 +239,19 @@ class TokenBuffer(ExtendedModule):
             lead, N, F = self.b.shape[:-2], self.b.shape[-2], self.b.shape[-1]
             idx = _index_i32(index, lead, x.device)
             _native.scatter_rows(x, self.b, idx, None, idx.shape[0], N, F, idx.shape[1])
-        elif self.structure == "row":
-            self.b.scatter_(dim=-2, index=expand_row_index(index, self.b.shape), src=x)
-        else:
-            self.b.scatter_(dim=-1, index=expand_col_index(index, self.b.shape), src=x)
+        else:   # any other structure / element type / layout: evt_move_rows_any / evt_scatter_cols
+            if self.b.dtype not in _native._STORE_OF:
+                raise NotImplementedError(f"MI355X build: buffers hold float32 / bfloat16 / float16 tensors, not {self.b.dtype}")
+            if not self.b.is_contiguous():
+                self.b = self.b.contiguous()
+            lead, R, L = tuple(self.b.shape[:-2]), self.b.shape[-2], self.b.shape[-1]
+            idx = _index_i32(index, lead, x.device)
+            xc = x.to(self.b.dtype)
+            xc = xc if xc.is_contiguous() else xc.contiguous()
+            if self.structure == "row":
+                _native.move_rows_any(xc, idx, idx.shape[0], R, L, idx.shape[1], self.b, scatter=True)
+            else:
+                _native.scatter_cols(xc, self.b, idx, None, idx.shape[0], R, L, idx.shape[1])
         return self.b
 
     def reset_self(self):

@@ -51,8 +51,9 @@ extern "C" {
                                     in every configuration;
                                  9: evt_attention_gated (+ _fits, _tile_bytes): the attention of EventfulBlock for <= 256 tokens,
                                     one workgroup per (clip, head), value gate included, gate reference in a tiled layout;
-                                    evt_gate_cols / evt_scatter_cols (column-structured stand-alone gate / buffer),
-                                    evt_ats_scores / evt_ats_stabilize (adaptive token sampling), evt_gather_rows_map */
+                                    evt_gate_cols / evt_scatter_cols / evt_gate_rows_any / evt_move_rows_any (stand-alone gates and
+                                    buffers of any structure and element type), evt_gather_rows_map / evt_scatter_rows_map (window
+                                    partition with padding), evt_ats_scores / evt_ats_stabilize (adaptive token sampling) */
 
 /* Exported symbols (the library is built with -fvisibility=hidden). */
 #if defined(__GNUC__)
@@ -571,6 +572,47 @@ EVT_API int evt_attention_gated(const evt_attn_gated_desc* d, void* stream);
 EVT_API int evt_attention_gated_fits(int32_t N, int32_t D, int32_t H, int32_t store, int32_t qk_split);
 /* Bytes of the tiled gate reference. */
 EVT_API int64_t evt_attention_gated_tile_bytes(int32_t B, int32_t H, int32_t N);
+
+
+/* ------------------------------------------------------------------------------------------ *
+ * ABI 9.  The index-structured operations of the reference's modules that are NOT on the fused path -- stand-alone gates /
+ * buffers of either structure and any element type, the window partition with padding, adaptive token sampling -- as kernels
+ * (they ran on ATen gather / scatter / index kernels before).  `dtype` is an evt_dtype: the element type of the tensors.
+ * ------------------------------------------------------------------------------------------ */
+/* TokenGate / TokenDeltaGate with structure="col" (modules.py:154-164, 187-201): c, p are (Bp * R, N) -- Bp index rows, R tensor
+ * rows per index row (e.g. Bp = B * H, R = N for an attention matrix) -- idx (Bp, kcap); c~ / e~ (nullable) are (Bp * R, kcap):
+ * c~ = c[:, idx]; e~ = (c - p)[:, idx] in dtype arithmetic; update_p: p[:, idx] = c~. */
+EVT_API int evt_gate_cols(const void* c, void* p, const int32_t* idx, const int32_t* count, int32_t Bp, int32_t R, int32_t N,
+                          int32_t kcap, int32_t dtype, void* c_tilde, void* e_tilde, int32_t update_p, void* stream);
+/* TokenBuffer with structure="col" (modules.py:90-96): buf[:, idx] = x, x (Bp * R, kcap), buf (Bp * R, N). */
+EVT_API int evt_scatter_cols(const void* x, void* buf, const int32_t* idx, const int32_t* count, int32_t Bp, int32_t R, int32_t N,
+                             int32_t kcap, int32_t dtype, void* stream);
+/* Row-structured gate for any element type / row length (the fp32, F % 4 == 0 fast path is evt_gate_gather_update):
+ * c, p (Bp, N, F); idx (Bp, kcap); c~ / e~ (Bp, kcap, F). */
+EVT_API int evt_gate_rows_any(const void* c, void* p, const int32_t* idx, const int32_t* count, int32_t Bp, int32_t N, int32_t F,
+                              int32_t kcap, int32_t dtype, void* c_tilde, void* e_tilde, int32_t update_p, void* stream);
+/* Rows of a (B, N, F) tensor through an index map (B / rep, n), entries < 0 skipped: scatter = 0: out (B, n, F), out[b][i] =
+ * x[b][map[b / rep][i]]; scatter = 1: x (B, n, F), out (B, N, F), out[b][map[b / rep][i]] = x[b][i] (TokenBuffer rows,
+ * modules.py:86-88; the row gather of the ATS path, blocks.py:196-203).  Any element type and row length. */
+EVT_API int evt_move_rows_any(const void* x, const int32_t* map, int32_t B, int32_t N, int32_t F, int32_t n, int32_t rep, int32_t scatter,
+                              int32_t dtype, void* out, void* stream);
+/* fp32 rows, F % 4 == 0, 16-byte pieces: out (B, n_out, F), out[b][i] = map[..][i] >= 0 ? x[b][map[..][i]] : pad_row (zeros when
+ * NULL); map is (n_out) shared by the batch or, map_per_batch = 1, (B, n_out).  The window partition of the qkv buffer with its
+ * padding tokens (blocks.py:257-301) and `_gather_ats_skip` (blocks.py:196-203). */
+EVT_API int evt_gather_rows_map(const float* x, const int32_t* map, const float* pad_row, int32_t B, int32_t N, int32_t F, int32_t n_out,
+                                int32_t map_per_batch, float* out, void* stream);
+/* The inverse for un-windowing (blocks.py:346-376): x (B, n_in, F), out (B, N, F), out[b][map[i]] = x[b][i], map[i] < 0 dropped. */
+EVT_API int evt_scatter_rows_map(const float* x, const int32_t* map, int32_t B, int32_t n_in, int32_t N, int32_t F, float* out, void* stream);
+
+/* Adaptive token sampling, scoring (blocks.py:150-170): a (B,H,N,N) probabilities and v (B,H,N,dh) values (element strides v_bs,
+ * v_hs, v_rs; channels contiguous), both of `dtype`; scores (H, N) fp32 = sum over the BATCH axis (blocks.py:163: batch must equal
+ * heads downstream) of a[b,h,n,0] * ||v[b,h,n,:]|| / sum_{n' >= 1}(...), every intermediate rounded to `dtype` where the
+ * reference's op sequence rounds it; scores[:, 0] = +inf.  Selection: evt_select_topk on the scores (ascending lists). */
+EVT_API int evt_ats_scores(const void* a, const void* v, int64_t v_bs, int64_t v_hs, int64_t v_rs, int32_t B, int32_t H, int32_t N,
+                           int32_t dh, int32_t dtype, float* scores, void* stream);
+/* `_stabilize_ats_indices` (blocks.py:378-391): last, now (rows, n) ascending lists over N tokens -> out = last with the entries that
+ * are not in `now` replaced, in order, by the entries of `now` that are not in `last`. */
+EVT_API int evt_ats_stabilize(const int32_t* last, const int32_t* now, int32_t rows, int32_t n, int32_t N, int32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

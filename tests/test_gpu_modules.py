@@ -117,6 +117,68 @@ def test_col_gate_and_buffers_standalone():
             assert torch.equal(st.p.cpu(), xs[t])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_gates_and_buffers_of_any_structure_and_dtype(dtype):
+    """Stand-alone gates / buffers off the fp32 row fast path -- column structure, 16-bit element types, odd row lengths, a
+    non-contiguous first input (the reference keeps a REFERENCE to it, modules.py:140) -- on evt_gate_cols / evt_scatter_cols /
+    evt_gate_rows_any / evt_move_rows_any, against the oracle's gather / delta / scatter in the same dtype (bit-equal: the delta is one
+    subtraction rounded to the dtype)."""
+    from eventful_transformer import modules
+    g_ = torch.Generator().manual_seed(11)
+    for structure, shape in (("col", (2, 3, 9, 13)), ("row", (2, 3, 13, 7)), ("row", (3, 11, 6))):
+        k = 4
+        tokens = shape[-1] if structure == "col" else shape[-2]
+        lead = shape[:1]
+        c0 = torch.randn(*shape, generator=g_).to(dtype)
+        c1 = torch.randn(*shape, generator=g_).to(dtype)
+        c2 = torch.randn(*shape, generator=g_).to(dtype)
+        forced = [torch.stack([torch.randperm(tokens, generator=g_)[:k].sort()[0] for _ in range(lead[0])]) for _ in range(2)]
+        gate, slot = modules.TokenDeltaGate(structure=structure), O.Slot()
+        # first input handed over as a permuted (non-contiguous) view of a transposed tensor
+        first_dev = c0.transpose(-1, -2).contiguous().to(DEV).transpose(-1, -2)
+        assert not first_dev.is_contiguous()
+        gate(first_dev)
+        O.token_delta_gate(slot, c0.clone(), None, structure=structure)
+        for c, f in ((c1, forced[0]), (c2, forced[1])):
+            out = gate(c.clone().to(DEV), forced_index=f.to(DEV))
+            ref = O.token_delta_gate(slot, c.clone(), None, forced=f, structure=structure)
+            assert out[0].dtype == dtype and torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1])
+            assert torch.equal(gate.p.cpu(), slot.t)
+        buf, sb = modules.TokenBuffer(structure=structure), O.Slot()
+        buf(c0.clone().to(DEV), None)
+        O.token_buffer(sb, c0.clone(), None, structure=structure)
+        xs = (torch.randn(*(shape[:-1] + (k,)), generator=g_) if structure == "col" else torch.randn(*(shape[:-2] + (k, shape[-1])), generator=g_)).to(dtype)
+        out = buf(xs.to(DEV), forced[0].to(DEV))
+        ref = O.token_buffer(sb, xs, forced[0], structure=structure)
+        assert out is buf.b and torch.equal(out.cpu(), ref)
+
+
+def test_row_map_kernels_window_partition_and_back():
+    """evt_gather_rows_map / evt_scatter_rows_map: the window partition of a token buffer with padding tokens (map < 0 -> the pad row)
+    and its inverse (padding dropped), and a per-batch map (the ATS row gather); evt_move_rows_any with heads sharing a clip's map."""
+    from eventful_transformer import _native as n, blocks
+    B, F = 2, 24
+    tok_map = blocks._window_map((7, 5), (3, 3), torch.device(DEV))          # (windows, 9), -1 = padding
+    x = torch.randn(B, 35, F, device=DEV)
+    pad = torch.randn(F, device=DEV)
+    out = torch.full((B, tok_map.numel(), F), float("nan"), device=DEV)
+    n.gather_rows_map(x, tok_map, B, 35, F, tok_map.numel(), out, pad_row=pad)
+    flat = tok_map.reshape(-1).long()
+    want = torch.where((flat >= 0)[None, :, None], x[:, flat.clamp(min=0)], pad[None, None, :].expand(B, flat.numel(), F))
+    assert torch.equal(out, want)
+    back = torch.zeros(B, 35, F, device=DEV)
+    n.scatter_rows_map(out, tok_map, B, tok_map.numel(), 35, F, back)
+    assert torch.equal(back, x)
+    per = torch.stack([torch.randperm(35)[:6].sort()[0] for _ in range(B)]).int().to(DEV)
+    got = torch.empty(B, 6, F, device=DEV)
+    n.gather_rows_map(x, per, B, 35, F, 6, got, map_per_batch=True)
+    assert torch.equal(got, torch.stack([x[b, per[b].long()] for b in range(B)]))
+    a = torch.randn(B, 3, 35, 35, device=DEV).to(torch.bfloat16)     # heads of a clip share its map
+    rows = torch.empty(B, 3, 6, 35, device=DEV, dtype=torch.bfloat16)
+    n.move_rows_any(a, per, B * 3, 35, 35, 6, rows, rep=3)
+    assert torch.equal(rows, torch.stack([a[b][:, per[b].long()] for b in range(B)]))
+
+
 def test_matmul_buffer_and_accumulator_standalone():
     from eventful_transformer import modules
     B, Hh, N, dh, k = 2, 3, 21, 16, 6
