@@ -419,7 +419,7 @@ def test_vivit_b_sharp_bf16_projection_gates_state_forced(golden_dir):
     gold = {b_: [0, 0] for b_ in bars}     # the in-situ oracle vs the golden reference run (another machine), by the golden margin
     hip_gold = {b_: [0, 0] for b_ in bars}
     other = [0, 0]
-    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:24]
+    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:14]   # (24 clips: 554 / 554; 14 keep the test near 100 s)
     for c in want:
         model.backbone.reset()
         bb.reset()
