@@ -363,7 +363,7 @@ def test_vivit_b_sharp_bf16_projection_gates(golden_dir):
     other = [0, 0]
     worst_all, worst_differing = 0.0, 0.0
     # the projection gates with a large margin are rare (~3 %): replay the clips that hold one, until 70 of them have been seen
-    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()]
+    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:32]   # (all 70: the table in DESIGN.md section 3; 32 keep the test near a minute)
     seen = 0
     for c in want:
         model.backbone.reset()
