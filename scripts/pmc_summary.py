@@ -6,7 +6,7 @@ import collections, csv, glob, hashlib, json, os, re, sys
 out, B = sys.argv[1], int(sys.argv[2])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = ["gated_linear_split_kernel<0", "gated_linear_split_kernel<1", "gated_linear_kernel<0", "gated_linear_kernel<1",
-         "softmax_av_gated_kernel", "qk_kernel", "qk_split_kernel", "row_pass_kernel", "v_gate_t_kernel", "v_gate_kernel", "select_kernel",
+         "attn_gated_kernel", "softmax_av_gated_kernel", "qk_kernel", "qk_split_kernel", "row_pass_kernel", "v_gate_t_kernel", "v_gate_kernel", "select_kernel",
          "av_kernel", "softmax_gate_kernel", "split_weights_kernel", "attn_dense_kernel", "splitk_finish_kernel"]
 
 

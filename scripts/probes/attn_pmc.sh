@@ -1,4 +1,6 @@
-# Hardware counters of the fused attention launch (scripts/kbench.py --only softmax_av_fused_qk_norm_noout), separate passes.
+# Hardware counters of the gated attention launch K10 (scripts/kbench.py --only gated_resident_norm_noout), separate passes.
+# ($1 = kbench case, $2 = kernel-name substring: defaults below; the round-5 kernel: softmax_av_fused_qk_norm_noout softmax_av_gated)
+CASE=${1:-gated_resident_norm_noout}; KERN=${2:-attn_gated}
 OUT=gpurun_out/attn_pmc; mkdir -p $OUT; export TMPDIR=/tmp
 i=0
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
@@ -11,7 +13,7 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
          "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/kbench.py --clips 256 --only softmax_av_fused_qk_norm_noout > $GRAFT_REPO_ROOT/$OUT/pmc_$i.log 2>&1) || echo "pass $i ($c) failed" | tee -a $OUT/pmc.txt
+  (cd /tmp && rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/scripts/kbench.py --clips 256 --only $CASE > $GRAFT_REPO_ROOT/$OUT/pmc_$i.log 2>&1) || echo "pass $i ($c) failed" | tee -a $OUT/pmc.txt
 done
-python scripts/pmc_kernel.py $OUT softmax_av_gated 2>&1 | tee -a $OUT/pmc.txt
+python scripts/pmc_kernel.py $OUT $KERN 2>&1 | tee -a $OUT/pmc.txt
 find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "p_counter_collection.csv" -delete

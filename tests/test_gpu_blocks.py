@@ -81,6 +81,55 @@ def test_reset_and_state_attributes():
         assert torch.equal(a, b)  # deterministic (I7)
 
 
+@pytest.mark.parametrize("cast,grid,has_cls,policy", [("bfloat16", (6, 6), True, ("thr", 1.0)), ("float16", (9, 7), False, ("topk", 20)),
+                                                      ("bfloat16", (16, 16), False, ("topk", 100)), ("float16", (5, 5), True, ("thr", 1e9))])
+def test_eventful_block_on_the_resident_attention_kernel(cast, grid, has_cls, policy):
+    """EventfulBlock at head dim 64 with a 16-bit cast and no relative position runs its attention on evt_attention_gated (K10: value
+    gate + scores + softmax + A gate + both accumulator products in one launch, `matmul_gate.p` tiled): block outputs against the oracle
+    over 5 frames -- the threshold policy (variable, device-side count; batch 1 as in the reference, also a threshold nothing passes),
+    top-k with and without a class token, N = 256 -- and the per-clip state through the reference's attribute names: `matmul_gate.p`
+    (read through the tiled layout), `v_gate.p`, `matmul_accumulator_2.product`, the lazily refreshed `matmul_accumulator_1.product`."""
+    dim, heads = 128, 2
+    N = grid[0] * grid[1] + int(has_cls)
+    B = 1 if policy[0] == "thr" else 3
+    params = O.make_block_params(dim, 4, seed=51, std=0.06, head_dim=64)
+    blk = H.product_block("EventfulBlock", params, dim, heads, grid, matmul_2_cast=cast)
+    ob = O.BlockOracle("EventfulBlock", params, dim, heads, grid, matmul_2_cast=cast)
+    ob.set_policy(H.oracle_policy(policy))
+    forced = policy[0] == "topk"   # top-k: decisions teacher-forced gate by gate (a near-tie at a downstream gate would fork the two runs);
+    if forced:                     # threshold: free-running -- the variable, device-side count is the point (margins are wide on this stream)
+        for gn in ("qkv_gate", "projection_gate", "mlp_gate", "v_gate", "matmul_gate"):
+            getattr(blk, gn).policy = _ForcedPolicy(policy[1])
+    else:
+        H.product_policy(blk, policy)
+    xs = O.make_token_stream(B, N, dim, 5, policy[1] if policy[0] == "topk" else 12, seed=52, small=0.01)   # (wide margins at the qkv gate)
+    sdt = getattr(torch, cast)
+    with torch.inference_mode():
+        for t in range(5):
+            y_ref = ob.forward(xs[t].clone())
+            if forced and t > 0:
+                for gn, tk in (("qkv_gate", "qkv_index"), ("projection_gate", "projection_index"), ("mlp_gate", "mlp_index")):
+                    getattr(blk, gn).policy.force = ob.trace[tk].sort(dim=-1)[0].to(DEV)
+            y = blk(xs[t].to(DEV)).cpu()
+            err = float((y - y_ref).abs().max())
+            assert err <= 2e-3, (cast, t, err)
+            assert blk.matmul_gate._tiles is not None   # the resident kernel took the block
+        p = blk.matmul_gate.p
+        assert p.shape == (B, heads, N, N) and p.dtype == sdt
+        atol_p = 4e-3 if cast == "bfloat16" else 5e-4
+        assert torch.allclose(p.float().cpu(), ob.s["matmul_gate"].t.float(), atol=atol_p)
+        assert blk.v_gate.p.shape == (B, heads, N, 64)
+        assert torch.allclose(blk.v_gate.p.float().cpu(), ob.s["v_gate"].t.float(), atol=2 * atol_p * float(ob.s["v_gate"].t.float().abs().max()))
+        assert blk.matmul_accumulator_2.product.shape == (B, heads, N, 64)
+        q, k, _ = blk.qkv_accumulator.b.cpu().view(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        assert torch.allclose(blk.matmul_accumulator_1.product.cpu(), (q / 8.0) @ k.transpose(-2, -1), atol=2e-4)
+        # assigning the logical tensor writes the tiles; the next frame then runs from that state
+        blk.matmul_gate.p = ob.s["matmul_gate"].t.to(DEV)
+        assert torch.equal(blk.matmul_gate.p.cpu(), ob.s["matmul_gate"].t)
+    blk.reset()
+    assert blk.matmul_gate.p is None and blk.matmul_gate._tiles is None
+
+
 @pytest.mark.parametrize("order", [1, float("inf")])
 @pytest.mark.parametrize("kind,cast", [("EventfulBlock", "bfloat16"), ("EventfulTokenwiseBlock", None)])
 def test_blocks_with_l1_and_linf_norm_policies(kind, cast, order):
