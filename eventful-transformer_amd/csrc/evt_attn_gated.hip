@@ -10,8 +10,9 @@
 // Why.  The 32-row kernel (evt_attn_fused.hip) re-reads a head's keys for each of its 7 row tiles and every workgroup lives through
 // a chain of dependent round trips (index list -> keys -> scores -> 2-byte gathers of the reference -> ...) that three workgroups
 // per CU cannot hide: 0.29 of the HBM roofline, VALU-issue and latency bound (profiles/r05/attn_pmc_counters.txt).  Here a head's
-// keys (bf16 hi | lo planes) and its value operands enter LDS ONCE, every global load of the workgroup is requested before the first
-// one is consumed, and after two barriers no wave waits for another:
+// keys (bf16 hi | lo planes) and its value operands enter LDS ONCE, the workgroup's requests are spread over its life (what the staging
+// needs in the prologue, the rest behind the second barrier and in front of pass 1), and behind three workgroup barriers (q fragments
+// taken / planes resident / score products done) no wave waits for another:
 //
 //   * scores TRANSPOSED on v_mfma_f32_32x32x16_bf16 (A = 32 keys from LDS, B = the wave's 32 query rows): a lane owns ONE query
 //     row and 16 keys per 32-key block, the 32 x N score block stays in registers, row max / sum are in-lane + one exchange;
@@ -24,7 +25,9 @@
 //     wave reads / rewrites a tile with two 1 KB loads / stores (the 32-row kernel: 2-byte gathers and scattered 2-byte stores);
 //     matmul_gate.p is exposed as the logical (B,H,N,N) tensor by the host (modules.py of this package);
 //   * the value gate (evt_v_gate, a launch of its own before) runs in the staging phase: the head's 64 channels of the selected
-//     value rows are read, gated against v_ref and written into the planes directly -- its (B,D,kcap) outputs never exist.
+//     value rows are read, gated against v_ref and written into the planes directly -- its (B,D,kcap) outputs never exist;
+//   * every global access is whole cache lines: q rows, A.v state rows, the next gate's reference and the outputs move between
+//     16-byte-per-lane coalesced accesses and the accumulator layout through wave-private LDS blocks inside the K-plane region.
 //
 // 16-bit store types only (the reference's `matmul_2_cast`: products of bf16 / fp16 operands are exact on the matrix cores, fp32
 // accumulate, every rounding point of the reference kept), head dim 64, split-precision scores (q, k as bf16 hi + lo, three MFMAs
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(NB <= 4 ? 256 : 512, NB <= 4 ? 2 : 1) void attn_gat
 
   // ---- requests.  Everything the workgroup reads from HBM / L2 is asked for here, oldest first in the order of its use (vmcnt
   //      retires in order): index list -> q rows -> K rows -> (index list back) value rows + value reference; the gate reference tiles
-  //      and the A.v state rows follow behind the second barrier.  Every load instruction of the phase addresses whole 64-byte lines: what a CU pays for a load is the
+  //      and the A.v state rows follow behind the second barrier.  Every load instruction of the phase addresses whole cache lines: what a CU pays for a load is the
   //      number of separate lines its 64 lanes touch (q rows read straight into MFMA fragments were 64 lines of 16 useful bytes per
   //      instruction -- a third of all the line requests of the workgroup).
   const int32_t* ix = first ? nullptr : a.idx + (int64_t)b * a.kcap;
