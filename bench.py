@@ -867,6 +867,14 @@ def pmc_traffic(clips, frames, k, cast, gemm_mode):
             n = sum(kr["launches"] for kr in gl)
             util = {"mfma_util_pmc": round(sum(kr["mfma_util_pmc"] * kr["launches"] for kr in gl) / n, 4),
                     "clock_ghz_pmc": round(sum(kr["clock_ghz_profiled"] * kr["launches"] for kr in gl) / n, 3)} if n else {}
+            # HBM-side bytes per launch of the other two kernel families of the step, from the same counter passes
+            fam = {}
+            for name, key in (("attn_gated_kernel", "attn"), ("row_pass_kernel", "rows")):
+                rows_ = [kr for kr in pmc["kernels"] if kr["kernel"].startswith(name) and "hbm_bytes_per_launch" in kr]
+                nl = sum(kr["launches"] for kr in rows_)
+                if nl:
+                    fam[key] = int(sum(kr["hbm_bytes_per_launch"] * kr["launches"] for kr in rows_) / nl)
+            util["family_traffic"] = fam
             return pmc["gated_linear_hbm_bytes_per_launch"], os.path.relpath(path, ROOT), util
         except Exception:
             continue
@@ -1186,6 +1194,10 @@ def time_workload(w, steps, warmup, world, device, events_on=True, graphs=False)
                 roofline["pass"] = (f"one SERIAL pass of the step behind the timed region (batches one after the other, {w['serial_pass_s']:.3f} s): "
                                     f"in the timed region {len(lanes)} batches are in flight on {len(lanes)} HIP streams and a launch's "
                                     "event time would include the other stream's kernels")
+            fam_traffic = pmc_util.pop("family_traffic", {}) if pmc_util else {}
+            for key, famname in (("attn", "attention_family"), ("rows", "rows_family")):
+                if w.get(famname) is not None:
+                    w[famname]["traffic"] = fam_traffic.get(key)   # HBM bytes per launch (PMC, same file as roofline.traffic) or null
             if pmc_util:   # counter-measured (same PMC file): SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x 1024 SIMDs)
                 roofline.update(pmc_util)
                 roofline["mfma_util_note"] = ("matrix-pipe busy fraction of the launch's shader cycles at the sustained clock "
