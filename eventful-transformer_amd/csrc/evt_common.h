@@ -34,9 +34,13 @@ static inline int evt_current_device() {   // -1: outside the per-device tables 
   if (hipGetDevice(&dev) != hipSuccess) return -1;
   return dev >= 0 && dev < EVT_MAX_DEVICES ? dev : -1;
 }
-// Compute units of the current device (cached per device; 256 if the runtime does not say).
+// Compute units a persistent launch sizes its grid for: the calling thread's budget (evt_set_cu_budget: the launch goes to a
+// stream with a CU mask), else the CUs of the current device (cached per device; 256 if the runtime does not say).
+int evt_cu_budget();   // evt_core.hip: thread-local, 0 = none
 static inline int evt_cu_count() {
   static std::atomic<int> cus[EVT_MAX_DEVICES];
+  const int budget = evt_cu_budget();
+  if (budget > 0) return budget;
   int dev = evt_current_device();
   if (dev >= 0 && cus[dev].load(std::memory_order_relaxed) > 0) return cus[dev].load(std::memory_order_relaxed);
   int real = 0, n = 0;

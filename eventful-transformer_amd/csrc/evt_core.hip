@@ -36,6 +36,14 @@ int evt_check_launch(const char* what) {
   return EVT_OK;
 }
 
+static thread_local int g_cu_budget = 0;
+int evt_cu_budget() { return g_cu_budget; }
+extern "C" int evt_set_cu_budget(int32_t cus) {
+  if (cus < 0) return evt_fail(EVT_ERR_BAD_ARG, "evt_set_cu_budget: cus=%d", (int)cus);
+  g_cu_budget = cus;
+  return EVT_OK;
+}
+
 extern "C" int evt_version(void) { return EVT_ABI_VERSION; }
 extern "C" const char* evt_last_error_string(void) { return g_err; }
 extern "C" const char* evt_target_arch(void) { return "gfx950"; }

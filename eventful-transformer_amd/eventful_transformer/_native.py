@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "evt_attention_dense", "evt_attention_stream", "evt_attention_stream_lds_bytes", "evt_attention_stream_key_blocks", "evt_stream_prep", "evt_prefetch", "evt_select_prefetch_next", "evt_attention_dense_resident",
     "evt_attention_gated", "evt_attention_gated_fits", "evt_attention_gated_tile_bytes",
     "evt_gate_cols", "evt_scatter_cols", "evt_gate_rows_any", "evt_move_rows_any", "evt_gather_rows_map", "evt_scatter_rows_map",
-    "evt_ats_scores", "evt_ats_stabilize",
+    "evt_ats_scores", "evt_ats_stabilize", "evt_set_cu_budget",
 )
 
 
@@ -742,6 +742,13 @@ def ats_scores(a, v, B, H, N, dh, scores):
 
 def ats_stabilize(last, now, rows, n, N, out):
     _check(load().evt_ats_stabilize(_p(last), _p(now), rows, n, N, _p(out), _stream()))
+
+
+def set_cu_budget(cus):
+    """Persistent launches of this host thread size their grids for `cus` compute units (a stream with a CU mask); 0: the whole device."""
+    lib = load()
+    lib.evt_set_cu_budget.argtypes = [c_int32]
+    _check(lib.evt_set_cu_budget(int(cus)))
 
 
 def attention_dense_fits(N, D, H):

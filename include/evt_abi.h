@@ -78,6 +78,10 @@ EVT_API int evt_version(void);
 EVT_API const char* evt_last_error_string(void);
 /* Compile-time target of the embedded code object, e.g. "gfx950". */
 EVT_API const char* evt_target_arch(void);
+/* ABI 9.  Compute units the calling thread's persistent launches (the 256-row gated linear, evt_attention_stream's tile choice) size their
+ * grids for: set it to the number of CUs in a stream's CU mask (hipExtStreamCreateWithCUMask) before launching into that stream, 0 = the
+ * whole device (default).  Thread-local; nothing else changes -- the library never creates streams. */
+EVT_API int evt_set_cu_budget(int32_t cus);
 
 /* ABI 6.  Reads `bytes` (16-byte aligned pointer) of a read-only operand -- a CountedLinear's weight planes (evt_split_weights) --
  * into the memory-side cache ahead of the launch that streams them; `sink` = 4 writable bytes (never written in practice: it keeps
