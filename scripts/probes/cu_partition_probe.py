@@ -113,6 +113,8 @@ t_m = timed([(full, mem_a, 0)], a.iters)[0]
 s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 both = lambda ga, ma: (lambda: (ga(), ma()))   # noqa: E731
 t_ts = timed([(s1, both(gemms_a, mem_a), 0), (s2, both(gemms_b, mem_b), 0)], a.iters)
+t_op = timed([(s1, both(gemms_a, mem_a), 0), (s2, (lambda: (mem_b(), gemms_b())), 0)], a.iters)   # the second stream starts in the other phase
+print(f"# two unmasked streams, the second one starting with its memory-bound kernels (opposite phase): {max(t_op):.0f} us per pair = {max(t_op) / 2:.0f} us each")
 print(f"# B={B}: GEMMs of a block-frame alone on the chip {t_g:.0f} us, memory-bound kernels alone {t_m:.0f} us, serial sum {t_g + t_m:.0f} us; "
       f"two batches on two unmasked streams: {max(t_ts):.0f} us per pair of block-frames = {max(t_ts) / 2:.0f} us each")
 for gc in [int(v) for v in a.gemm_cus.split(",")]:
