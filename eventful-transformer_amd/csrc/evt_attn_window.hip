@@ -117,16 +117,20 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
     return r < 0 ? a.pad_row : clip + (int64_t)r * rs;
   };
 
-  // ---- this wave's 32 query rows: B-operand fragments straight from HBM / L2 (their latency hides behind the staging) ----
+  // ---- this wave's 32 query rows, COALESCED (16 lanes x 16 bytes per row, four rows per instruction): they reach the MFMA fragment
+  //      layout -- and the rel-pos items below, which need the q rows of ANY wave -- through one LDS block per wave inside the K plane
+  //      region, which is written later.  (Read straight into B-operand fragments, an instruction touched 64 separate lines for
+  //      16 useful bytes each, and the rel-pos items read every q row twice more the same way: round 6, as in evt_attn_gated.hip.)
   const int i0 = (blockIdx.x * NW + wave) * 32, iq = i0 + lr;
   const bool wave_on = i0 < a.N, q_on = iq < a.N;
-  float4 qraw[8];   // SPLIT: channels 16 s + 8 lh + {0..3, 4..7} (s = piece / 2);  exact: channels 8 m + 4 lh + 0..3 (m = piece)
+  constexpr int QP = DH + 4;   // row pitch (floats) of a q block: the fragment reads of 16 consecutive rows cover the 64 banks once
+  float* const qblocks = reinterpret_cast<float*>(kreg);
+  f32x4 qg[8];
   if (wave_on) {
-    const float* qrow = q_on ? row_ptr(iq) + h * DH : a.pad_row;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int ch = SPLIT ? 16 * (m >> 1) + 8 * lh + 4 * (m & 1) : 8 * m + 4 * lh;
-      qraw[m] = q_on ? *reinterpret_cast<const float4*>(qrow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 8; ++i) {
+      const int r = i0 + (lane >> 4) + 4 * i;
+      qg[i] = r < a.N ? *reinterpret_cast<const f32x4*>(row_ptr(r) + h * DH + 4 * (lane & 15)) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
 
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
   const int nqy = (a.qw + 15) >> 4, nty = (a.gh + 15) >> 4, nqx = (qh_ + 15) >> 4, ntx = (a.gw + 15) >> 4;
   const int items_y = rel ? qh_ * nqy * nty : 0, items = rel ? items_y + a.qw * nqx * ntx : 0;
   auto frag_chan = [&](int m) __attribute__((always_inline)) { return SPLIT ? 32 * (m >> 1) + 8 * kg + 4 * (m & 1) : 16 * kg + 4 * m; };
-  f32x4 tf[BS][4], qf[BS][4];
-  int it_qi[BS], it_e[BS];   // lane's query token (-1: none), lane's table slot in the terms row (-1: none)
+  f32x4 tf[2 * BS][4], qf[BS][4];   // table rows of two batches (the next one is in flight while this one is consumed); q fragments from LDS
+  int it_qi[2 * BS], it_e[2 * BS], it_q[2 * BS];   // lane's query token (-1: none), lane's table slot in the terms row (-1: none), the token whose q row it reads
   auto load_item = [&](int it, int u) __attribute__((always_inline)) {
     const bool isy = it < items_y;
     const int x = isy ? it : it - items_y;
@@ -155,15 +159,18 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
     it_qi[u] = ql < qn ? qtok : -1;
     it_e[u] = tl < tn ? (isy ? tl : a.gh + tl) : -1;
     const float* trow_ = (isy ? a.rel_y + ((int64_t)sel * a.gh + min(tl, tn - 1)) * DH : a.rel_x + ((int64_t)sel * a.gw + min(tl, tn - 1)) * DH);
-    const float* qrow_ = row_ptr(ql < qn ? qtok : 0) + h * DH;
+    it_q[u] = ql < qn ? qtok : 0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      tf[u][m] = *reinterpret_cast<const f32x4*>(trow_ + frag_chan(m));
-      qf[u][m] = *reinterpret_cast<const f32x4*>(qrow_ + frag_chan(m));
-    }
+    for (int m = 0; m < 4; ++m) tf[u][m] = *reinterpret_cast<const f32x4*>(trow_ + frag_chan(m));
+  };
+  auto item_q = [&](int u) __attribute__((always_inline)) {   // the item's query fragments from the q blocks (token t: block t / 32, row t % 32)
+    const float* qrow_ = qblocks + (size_t)it_q[u] * QP;   // (one workgroup per (group, head): every token's block is here)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qf[u % BS][m] = *reinterpret_cast<const f32x4*>(qrow_ + frag_chan(m));
   };
   auto consume_item = [&](int u) __attribute__((always_inline)) {
     // D[i = table row 4 kg' + r][j = query l15]: lane (l15, kg) holds rows 4 kg + r of ITS query column
+    item_q(u);
     f32x4_acc acc = {0.f, 0.f, 0.f, 0.f};
     if (SPLIT) {
 #pragma unroll
@@ -171,8 +178,8 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
         bf16x4_t th0, tl0, th1, tl1, qh0, ql0, qh1, ql1;
         split4(make_float4(tf[u][2 * s2][0], tf[u][2 * s2][1], tf[u][2 * s2][2], tf[u][2 * s2][3]), &th0, &tl0);
         split4(make_float4(tf[u][2 * s2 + 1][0], tf[u][2 * s2 + 1][1], tf[u][2 * s2 + 1][2], tf[u][2 * s2 + 1][3]), &th1, &tl1);
-        split4(make_float4(qf[u][2 * s2][0], qf[u][2 * s2][1], qf[u][2 * s2][2], qf[u][2 * s2][3]), &qh0, &ql0);
-        split4(make_float4(qf[u][2 * s2 + 1][0], qf[u][2 * s2 + 1][1], qf[u][2 * s2 + 1][2], qf[u][2 * s2 + 1][3]), &qh1, &ql1);
+        split4(make_float4(qf[u % BS][2 * s2][0], qf[u % BS][2 * s2][1], qf[u % BS][2 * s2][2], qf[u % BS][2 * s2][3]), &qh0, &ql0);
+        split4(make_float4(qf[u % BS][2 * s2 + 1][0], qf[u % BS][2 * s2 + 1][1], qf[u % BS][2 * s2 + 1][2], qf[u % BS][2 * s2 + 1][3]), &qh1, &ql1);
         const bf16x8_t th = __builtin_shufflevector(th0, th1, 0, 1, 2, 3, 4, 5, 6, 7), tl = __builtin_shufflevector(tl0, tl1, 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8_t qh8 = __builtin_shufflevector(qh0, qh1, 0, 1, 2, 3, 4, 5, 6, 7), ql8 = __builtin_shufflevector(ql0, ql1, 0, 1, 2, 3, 4, 5, 6, 7);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl, qh8, acc, 0, 0, 0);
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[u][m][c], qf[u][m][c], acc, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[u][m][c], qf[u % BS][m][c], acc, 0, 0, 0);
     }
     // the table slot of row 4 kg + r is the `e` of lane (4 kg + r): fetch it from that lane
 #pragma unroll
@@ -192,22 +199,22 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
       if (it_qi[u] >= 0 && e >= 0) terms[it_qi[u] * TP + e] = acc[r];
     }
   };
-  auto load_batch = [&](int n) __attribute__((always_inline)) {   // items wave + NW (BS n + u)
+  auto load_batch = [&](int n, int par) __attribute__((always_inline)) {   // items wave + NW (BS n + u) -> register set `par`
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
       const int it = wave + NW * (BS * n + u);
-      if (it < items) load_item(it, u);   // wave-uniform
+      if (it < items) load_item(it, par * BS + u);   // wave-uniform
     }
   };
-  auto consume_batch = [&](int n) __attribute__((always_inline)) {
+  auto consume_batch = [&](int n, int par) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
       const int it = wave + NW * (BS * n + u);
-      if (it < items) consume_item(u);
+      if (it < items) consume_item(par * BS + u);
     }
   };
   const int batches = rel ? (items - wave + NW * BS - 1) / (NW * BS) : 0;   // of this wave
-  if (batches > 0) load_batch(0);
+  if (batches > 0) load_batch(0, 0);
   // K rows (key-major; split mode: bf16 hi | lo planes) and V rows (transposed: [channel][key], four consecutive keys of one
   // channel per store)
   constexpr int KIT = (MAXB * 32 * 16 + NT - 1) / NT, VIT = (MAXB * 8 * 16 + NT - 1) / NT;
@@ -229,8 +236,34 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
     }
   }
   WN_TICK(1);   // requests issued
-  if (batches > 0) consume_batch(0);
-  if (batches > 1) load_batch(1);
+  // q rows -> the wave's block -> this lane's B-operand fragments (SPLIT: channels 16 s + 8 lh + {0..3, 4..7}, s = piece / 2;
+  // exact: channels 8 m + 4 lh + 0..3, m = piece)
+  float4 qraw[8];
+  if (wave_on) {
+    float* qst = qblocks + (size_t)wave * 32 * QP;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(qst + ((lane >> 4) + 4 * i) * QP + 4 * (lane & 15)) = qg[i];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int ch = SPLIT ? 16 * (m >> 1) + 8 * lh + 4 * (m & 1) : 8 * m + 4 * lh;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qst + lr * QP + ch);
+      qraw[m] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();   // every q block is staged (the rel-pos items read any of them)
+  // rel-pos items: table rows from global (a batch ahead), q fragments from the blocks
+  for (int n = 0; n < batches; n += 2) {   // (two batches per trip: the register set of a batch is a compile-time index)
+    if (n + 1 < batches) load_batch(n + 1, 1);
+    consume_batch(n, 0);
+    if (n + 1 < batches) {
+      if (n + 2 < batches) load_batch(n + 2, 0);
+      consume_batch(n + 1, 1);
+    }
+  }
+  WN_TICK(3);   // rel-pos items
+  if (rel) __syncthreads();   // (launch-uniform) every wave is done with the q blocks: the K planes overwrite them
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
     const int e = tid + NT * it, j = e >> 4, c4 = e & 15;
@@ -266,13 +299,8 @@ __global__ __launch_bounds__(64 * NW) void attn_window_kernel(const DenseArgs a)
       }
     }
   }
-  WN_TICK(2);   // first rel-pos batch, K / V planes written
-  for (int n = 1; n < batches; ++n) {
-    if (n > 1) load_batch(n);
-    consume_batch(n);
-  }
-  WN_TICK(3);   // rel-pos items
-  __syncthreads();   // the ONLY workgroup barrier after the window map: K, V^T and the rel-pos terms are resident
+  WN_TICK(2);   // K / V planes written
+  __syncthreads();   // K, V^T and the rel-pos terms are resident: behind this barrier no wave waits for another
   WN_TICK(4);   // barrier
   if (!wave_on) return;
 

@@ -78,11 +78,18 @@ def main():
         o1 = torch.empty(1, N, D, device=dev)
         hidden = torch.empty(cap, 4 * D, device=dev)
         wmap_blocks = None
+        # the windowed blocks' attention (K8 resident): the frame's 14 x 14 windows (672^2: 3 x 3; 1024^2: 5 x 5 on the padded 70 x 70 grid), rel-pos, fp32
+        wG = 9 if name == "672" else 25
+        wqkv = torch.randn(wG, 196, 3 * D, device=dev, generator=g)
+        wout = torch.empty(wG, 196, D, device=dev)
+        wry = torch.randn(14, 14, dh, device=dev, generator=g) * 0.2
+        wrx = torch.randn(14, 14, dh, device=dev, generator=g) * 0.2
         kernels = {
             "stream": lambda: n.attention_stream(qkv, apT, pv, Bn, H, N, D, 8.0, store, False, rel_terms=terms, gh=gh, gw=gw, idx=idx,
                                                  count=count, kcap=cap, v_delta_t=vd, v_old_t=vo, out_f32=o32, norm_ref=pref, norm_parts=parts),
             "stream_first": lambda: n.attention_stream(qkv, apT, pv, Bn, H, N, D, 8.0, store, True, rel_terms=terms, gh=gh, gw=gw,
                                                        v_state=vp, out_f32=o32),
+            "window": lambda: n.attention_dense(wqkv, wG, H, 196, D, 8.0, n.EVT_F32, out_f32=wout, rel_y=wry, rel_x=wrx, gh=14, gw=14, qw=14),
             "rel_terms": lambda: n.rel_terms(qkv, ry, rx, 1, H, N, D, gh, gw, gw, terms),
             "v_gate_t": lambda: n.v_gate(qkv, idx, count, 1, N, D, cap, vp, vd, vo, store, True, transposed=True),
             "select": (lambda: n.select_threshold(norms, 1, N, 0.9, cap, sel, cnt, rest)) if thr else (lambda: n.select_topk(norms, 1, N, k, sel, rest)),
