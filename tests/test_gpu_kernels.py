@@ -1075,6 +1075,63 @@ def test_attention_gated_resident_matches_oracle(cast, N, k):
         n.attention_gated(torch.empty(1, 300, 3 * D, device=DEV), tiles, vp, pv, 1, H, 300, D, scale, store, True, out_f32=out)
 
 
+@pytest.mark.parametrize("cast,N,counts", [("bfloat16", 100, (0, 7, 100)), ("float16", 197, (197, 0, 1)), ("bfloat16", 33, (33, 32, 0))])
+def test_attention_gated_resident_ragged_device_counts(cast, N, counts):
+    """evt_attention_gated with a DIFFERENT device-side count per clip (the threshold policy's case, policies.py:58-68): a clip whose
+    gate selects nothing (its state must not move: modules.py:187-201 with an empty index), one that selects every key, and one in
+    between, in the same launch; the index slots behind a clip's count hold garbage tokens that must not be read as selected."""
+    n = native()
+    B, H, dh, scale = len(counts), 2, 64, 8.0
+    D = H * dh
+    sdt = getattr(torch, cast)
+    store = n.store_code(sdt)
+    g = torch.Generator().manual_seed(N * 7 + sum(counts))
+    slots = [(O.Slot(), O.Slot(), O.Slot()) for _ in range(B)]
+    tiles = n.gated_tiles_empty(B, H, N, sdt, DEV)
+    vp = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    out = torch.empty(B, N, D, device=DEV)
+    tol = 2e-2 if cast == "bfloat16" else 3e-3
+    for t in range(3):
+        buf = torch.randn(B, N, 3 * D, generator=g) * 1.5
+        idx_cap = torch.randint(0, N, (B, N), generator=g).int()      # garbage behind the counts
+        refs, lists = [], []
+        for b in range(B):
+            c = counts[(b + t) % B] if t else N                           # the counts rotate over the clips from frame to frame
+            idx = torch.randperm(N, generator=g)[:c].sort()[0]
+            lists.append(idx)
+            idx_cap[b, :c] = idx.int()
+            q, kk, v = buf[b:b + 1].view(1, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+            a = ((q / scale) @ kk.transpose(-2, -1)).softmax(dim=-1).to(sdt)
+            v = v.to(sdt)
+            vs, ag, acc = slots[b]
+            forced = idx.unsqueeze(0) if t else None
+            v_n, v_d, _ = O.token_delta_gate(vs, v, None, forced=forced)
+            a_n, a_d, _ = O.token_delta_gate(ag, a, None, forced=forced, structure="col")
+            refs.append(O.BlockOracle._merge(O.av_accumulator(acc, a_n, v_n, a_d, v_d)).float())
+        ref = torch.cat(refs)
+        before = (pv.clone(), tiles.clone(), vp.clone())
+        if t == 0:
+            n.attention_gated(buf.to(DEV), tiles, vp, pv, B, H, N, D, scale, store, True, out_f32=out)
+        else:
+            count = torch.tensor([len(l) for l in lists], dtype=torch.int32, device=DEV)
+            n.attention_gated(buf.to(DEV), tiles, vp, pv, B, H, N, D, scale, store, False, idx=idx_cap.to(DEV), count=count, kcap=N, out_f32=out)
+            for b in range(B):
+                if len(lists[b]) == 0:   # nothing selected: the clip's three states are untouched, bit for bit
+                    for was, now in zip(before, (pv, tiles, vp)):
+                        assert torch.equal(was[b].view(torch.int16), now[b].view(torch.int16)), (cast, t, b)
+        got_v = torch.stack([vp[b].view(N, H, dh).permute(1, 0, 2).float().cpu() for b in range(B)])
+        want_v = torch.cat([slots[b][0].t.float() for b in range(B)])
+        assert torch.equal(got_v, want_v), (cast, t)
+        want_p = torch.cat([slots[b][1].t.float() for b in range(B)])
+        got_p = n.tiles_to_logical(tiles, N).float().cpu()
+        assert torch.allclose(got_p, want_p, atol={"bfloat16": 4e-3, "float16": 5e-4}[cast]), (cast, t)
+        err = float((out.cpu() - ref).abs().max())
+        bar = max(tol, (1 if t == 0 else 2) * float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        assert err <= bar, (cast, N, t, err, bar)
+        assert torch.equal(out.cpu(), pv.float().cpu())
+
+
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
                                              (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True),
                                              ("bfloat16", 512, 64, 100, True), (None, 350, 70, 60, True), (None, 280, 20, 50, True),
