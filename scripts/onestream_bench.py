@@ -98,6 +98,8 @@ def main():
             "proj": lambda: n.gated_linear(c, D, idx, N, Wp, b1, o1, D, idx, N, count, p, 1, cap, D, D, W_split=sp),
             "mlp": lambda: n.gated_mlp(c, D, idx, N, W1, b4, W2, b1, hidden, o1, D, count, p, 1, cap, D, 4 * D, W1_split=s1, W2_split=s2),
         }
+        one = torch.zeros(64, device=dev)
+        kernels["null"] = lambda: one.add_(1.0)   # launch floor of a back-to-back chain (one 64-element ATen kernel)
         if Bn == 1:   # the same QKV / MLP launches cycling through 40 different weight sets (~1.1 GB: colder than any cache)
             cold = [(n.split_weight(torch.randn(3 * D, D, device=dev, generator=g) * 0.02), n.split_weight(torch.randn(4 * D, D, device=dev, generator=g) * 0.02),
                      n.split_weight(torch.randn(D, 4 * D, device=dev, generator=g) * 0.02)) for _ in range(40)]
