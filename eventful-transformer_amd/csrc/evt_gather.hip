@@ -114,6 +114,7 @@ extern "C" int evt_gate_cols(const void* c, void* p, const int32_t* idx, const i
   EVT_REQUIRE(Bp >= 0 && R > 0 && N > 0 && kcap >= 0, EVT_ERR_BAD_ARG, "evt_gate_cols: bad sizes");
   const int64_t total = (int64_t)Bp * R * kcap;
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   const dim3 grid((unsigned)((total + 255) / 256));
   EVT_DISPATCH_STORE(dtype, T, {
     hipLaunchKernelGGL(gate_cols_kernel<T>, grid, dim3(256), 0, evt_stream(stream), (const T*)c, (T*)p, idx, count, total, R, N, kcap,
@@ -128,6 +129,7 @@ extern "C" int evt_scatter_cols(const void* x, void* buf, const int32_t* idx, co
   EVT_REQUIRE(Bp >= 0 && R > 0 && N > 0 && kcap >= 0, EVT_ERR_BAD_ARG, "evt_scatter_cols: bad sizes");
   const int64_t total = (int64_t)Bp * R * kcap;
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   const dim3 grid((unsigned)((total + 255) / 256));
   EVT_DISPATCH_STORE(dtype, T, {
     hipLaunchKernelGGL(scatter_cols_kernel<T>, grid, dim3(256), 0, evt_stream(stream), (const T*)x, (T*)buf, idx, count, total, R, N, kcap);
@@ -142,6 +144,7 @@ extern "C" int evt_gather_rows_map(const float* x, const int32_t* map, const flo
   EVT_REQUIRE((F & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_gather_rows_map: F=%d must be a multiple of 4", F);
   const int64_t total = (int64_t)B * n_out * (F / 4);
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   hipLaunchKernelGGL(gather_rows_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, evt_stream(stream), x, map, pad_row, total, N,
                      F / 4, n_out, map_per_batch, out);
   return evt_check_launch("evt_gather_rows_map");
@@ -153,6 +156,7 @@ extern "C" int evt_scatter_rows_map(const float* x, const int32_t* map, int32_t 
   EVT_REQUIRE((F & 3) == 0, EVT_ERR_BAD_SHAPE, "evt_scatter_rows_map: F=%d must be a multiple of 4", F);
   const int64_t total = (int64_t)B * n_in * (F / 4);
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   hipLaunchKernelGGL(scatter_rows_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, evt_stream(stream), x, map, total, n_in, N,
                      F / 4, out);
   return evt_check_launch("evt_scatter_rows_map");
@@ -165,6 +169,7 @@ extern "C" int evt_gate_rows_any(const void* c, void* p, const int32_t* idx, con
   EVT_REQUIRE(Bp >= 0 && N > 0 && F > 0 && kcap >= 0, EVT_ERR_BAD_ARG, "evt_gate_rows_any: bad sizes");
   const int64_t total = (int64_t)Bp * kcap * F;
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   const dim3 grid((unsigned)((total + 255) / 256));
   EVT_DISPATCH_STORE(dtype, T, {
     hipLaunchKernelGGL(gate_rows_any_kernel<T>, grid, dim3(256), 0, evt_stream(stream), (const T*)c, (T*)p, idx, count, total, N, F, kcap,
@@ -179,6 +184,7 @@ extern "C" int evt_move_rows_any(const void* x, const int32_t* map, int32_t B, i
   EVT_REQUIRE(B >= 0 && N > 0 && F > 0 && n >= 0 && rep > 0, EVT_ERR_BAD_ARG, "evt_move_rows_any: bad sizes");
   const int64_t total = (int64_t)B * n * F;
   if (total == 0) return EVT_OK;
+  EVT_REQUIRE(total < (1ll << 39), EVT_ERR_BAD_SHAPE, "%s: %lld elements exceed one launch's grid (2^31 workgroups of 256)", __func__, (long long)total);
   const dim3 grid((unsigned)((total + 255) / 256));
   EVT_DISPATCH_STORE(dtype, T, {
     hipLaunchKernelGGL(move_rows_any_kernel<T>, grid, dim3(256), 0, evt_stream(stream), (const T*)x, map, total, N, F, n, rep, scatter, (T*)out);
