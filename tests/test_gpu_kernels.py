@@ -1132,6 +1132,53 @@ def test_attention_gated_resident_ragged_device_counts(cast, N, counts):
         assert torch.equal(out.cpu(), pv.float().cpu())
 
 
+def test_resident_attention_kernels_are_repeatable_under_load():
+    """Race check for the two resident attention kernels, whose waves reuse LDS regions across barriers (the q / epilogue blocks
+    inside the K planes): 25 runs of the same launch at the headline's occupancy (3 workgroups per CU queued) must agree bit for bit
+    -- evt_attention_gated (gated frame, N = 197, k = 128, bf16) on cloned states, evt_attention_dense's resident form (196-token
+    windows with rel-pos, fp32)."""
+    n = native()
+    H, dh, N, k, B = 12, 64, 197, 128, 64
+    D = H * dh
+    g = torch.Generator(device=DEV).manual_seed(5)
+    sdt = torch.bfloat16
+    store = n.store_code(sdt)
+    buf = torch.randn(B, N, 3 * D, device=DEV, generator=g)
+    tiles0 = n.gated_tiles_empty(B, H, N, sdt, DEV)
+    vp0 = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    pv0 = torch.empty(B, N, D, dtype=sdt, device=DEV)
+    n.attention_gated(buf, tiles0, vp0, pv0, B, H, N, D, 8.0, store, True)
+    buf2 = buf + 0.3 * torch.randn(B, N, 3 * D, device=DEV, generator=g)
+    idx = torch.stack([torch.randperm(N, device=DEV, generator=g)[:k].sort()[0] for _ in range(B)]).int()
+    ref_next = torch.randn(B, N, D, device=DEV, generator=g)
+    first = None
+    for _ in range(25):
+        tiles, vp, pv = tiles0.clone(), vp0.clone(), pv0.clone()
+        out = torch.empty(B, N, D, device=DEV)
+        parts = torch.empty(B, N, H, device=DEV)
+        n.attention_gated(buf2, tiles, vp, pv, B, H, N, D, 8.0, store, False, idx=idx, kcap=k, out_f32=out, norm_ref=ref_next, norm_parts=parts)
+        got = (tiles.view(torch.int16), vp.view(torch.int16), pv.view(torch.int16), out, parts)
+        if first is None:
+            first = got
+            assert torch.isfinite(out).all() and torch.isfinite(parts).all()
+        else:
+            for a_, b_ in zip(first, got):
+                assert torch.equal(a_, b_)
+    G = 72
+    wqkv = torch.randn(G, 196, 3 * D, device=DEV, generator=g)
+    ry = torch.randn(14, 14, dh, device=DEV, generator=g) * 0.2
+    rx = torch.randn(14, 14, dh, device=DEV, generator=g) * 0.2
+    first = None
+    for _ in range(25):
+        wout = torch.empty(G, 196, D, device=DEV)
+        n.attention_dense(wqkv, G, H, 196, D, 8.0, n.EVT_F32, out_f32=wout, rel_y=ry, rel_x=rx, gh=14, gw=14, qw=14)
+        if first is None:
+            first = wout
+            assert torch.isfinite(wout).all()
+        else:
+            assert torch.equal(first, wout)
+
+
 @pytest.mark.parametrize("cast,N,gw,k,rel", [(None, 260, 13, 40, True), ("bfloat16", 324, 18, 100, True), ("float16", 288, 16, 64, False),
                                              (None, 1764, 42, 256, True), ("bfloat16", 1024, 32, 333, True),
                                              ("bfloat16", 512, 64, 100, True), (None, 350, 70, 60, True), (None, 280, 20, 50, True),
