@@ -48,7 +48,7 @@ if a.dense is not None:
         buf = (ctypes.c_ulonglong * 12)()
         lib.evt_debug_prof_window.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
         assert lib.evt_debug_prof_window(buf) == 0
-        names = ["window map + q requests", "K staging", "V staging", "rel-pos items", "barrier", "q fragments + S^T products",
+        names = ["window map + q requests", "K / V / table requests issued", "K / V planes written", "q blocks + barrier + rel-pos items", "barrier", "S^T products",
                  "rel-pos adds + masks + row max", "exps + row sum", "P conversion + P.V", "epilogue"]
         tot = sum(buf[q] for q in range(10))
         print(f"K8 resident, window launch: wave 0 of one workgroup: {tot} ticks (100 MHz: {tot / 100:.1f} us)")
