@@ -185,10 +185,15 @@ template <typename T> struct Store;
 template <> struct Store<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }
   static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
-  static __device__ __forceinline__ float round(float v) { return v; }
+  // The identity -- but OPAQUE to the compiler.  "Rounded to the store type" marks a rounding point of the reference (softmax
+  // probabilities, products: blocks.py:183-189, modules.py:187-201, 285-295); with an fp32 store type nothing happens there, and hipcc
+  // (-ffp-contract=fast) looked through it: `an = round(e * rinv); ad = round(an - old)` became ad = fma(e, rinv, -old), i.e. the
+  // product's rounding residual instead of an exact 0 for an unchanged probability -- every frame added ~1e-9 to every element of the
+  // fp32 A.v state of a clip whose input did not change (found by tests/test_gpu_properties.py: the state never reached a fixed point).
+  static __device__ __forceinline__ float round(float v) { asm("" : "+v"(v)); return v; }
   static __device__ __forceinline__ void round4(const float* x, float* out, float* back) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { out[r] = x[r]; if (back) back[r] = x[r]; }
+    for (int r = 0; r < 4; ++r) { const float v = round(x[r]); out[r] = v; if (back) back[r] = v; }
   }
 };
 template <> struct Store<bf16_t> {
