@@ -88,6 +88,71 @@ def test_constant_input_reaches_a_bit_stable_fixed_point(cast):
     assert float(err.max()) <= 0.2, (cast, float(err.max()))
 
 
+@pytest.mark.parametrize("cast,tol", [(None, 3e-4), ("bfloat16", 2e-2)])
+def test_selecting_every_token_reproduces_the_dense_pass(cast, tol):
+    """r = N: every gate forwards every token, so each frame's output must be the dense pass over that frame (the delta
+    formulas are exact in exact arithmetic: a_new v_new - a_old v_old = a_new dv + da v_old, modules.py:285-295) -- 256 clips, 3
+    gated frames, every gated kernel at its largest row count.  Bars: fp32 mode 3e-4 (the accumulator carries one fp32 rounding per
+    update); with the bf16 cast the A.v accumulator is a bf16 tensor that takes two ROUNDED increments per frame where the dense pass
+    rounds once (2^-8 relative of |A.v| ~ 0.3 each, through the projection and 12 blocks): 2e-2."""
+    from eventful_transformer import policies
+    bb, _ = _model(cast)
+    H.set_policies(bb, policies.TokenNormTopK, k=N)
+    xs = [_tokens(30)]
+    for t in range(3):
+        xs.append(xs[-1] + 0.25 * _tokens(31 + t))
+    worst = 0.0
+    with torch.inference_mode():
+        bb.reset()
+        ys = [bb(x).clone() for x in xs]
+        for t, x in enumerate(xs):
+            bb.reset()
+            dense = bb(x)
+            assert torch.isfinite(ys[t]).all()
+            err = float((ys[t] - dense).abs().max())
+            worst = max(worst, err)
+            assert err <= tol, (cast, t, err)
+            if t == 0:
+                assert torch.equal(ys[0], dense)
+    H.report(f"full-size r = N ({cast or 'fp32'}, B={B}): gated frames against the dense pass of the same frame, max |diff| {worst:.2e} (bar {tol:g})")
+
+
+def _block_states(bb):
+    out = []
+    for blk in bb.blocks:
+        mg = blk.matmul_gate
+        out += [blk.qkv_gate.p, blk.qkv_accumulator.b, blk.v_gate._state, mg._tiles if mg._tiles is not None else mg.p,
+                blk.matmul_accumulator_2._state, blk.projection_gate.p, blk.projection_accumulator.b, blk.mlp_gate.p, blk.mlp_accumulator.b]
+    return out
+
+
+@pytest.mark.parametrize("cast", [None, "bfloat16"])
+def test_selecting_nothing_leaves_every_state_untouched(cast):
+    """Threshold policy with an unreachable threshold: every device-side count is 0 in every gate of every clip, and then no gate
+    reference, token buffer, attention reference or A.v accumulator of any block may change by a single bit (modules.py:149-160,
+    187-201 with an empty index) while the inputs keep changing -- 256 clips x 12 blocks x 9 state tensors, 3 gated frames; the
+    block outputs are then x_t + the frozen buffers."""
+    from eventful_transformer import policies
+    bb, _ = _model(cast)
+    H.set_policies(bb, policies.TokenNormThreshold, threshold=1e30)
+    xs = [_tokens(40)]
+    for t in range(3):
+        xs.append(xs[-1] + 0.25 * _tokens(41 + t))
+    with torch.inference_mode():
+        bb.reset()
+        y0 = bb(xs[0]).clone()
+        before = [s.clone() for s in _block_states(bb)]
+        for x in xs[1:]:
+            y = bb(x)
+            assert torch.isfinite(y).all()
+            now = _block_states(bb)
+            assert len(now) == len(before) == 12 * 9
+            for i, (a, b) in enumerate(zip(before, now)):
+                assert a.dtype == b.dtype and torch.equal(a.view(torch.uint8), b.view(torch.uint8)), f"block {i // 9}, state {i % 9} moved with nothing selected"
+            # block outputs = the new input + frozen buffers: the whole backbone is x -> x + const
+            assert torch.allclose(y - x, y0 - xs[0], rtol=0, atol=1e-4), float(((y - x) - (y0 - xs[0])).abs().max())
+
+
 def test_clips_are_independent_of_their_batch_position():
     """Headline mode (bf16 cast), first frame + 3 gated frames: the batch permuted -> the outputs permuted, bit for bit (no clip reads
     a neighbour's rows, tiles, index lists or partial sums, wherever in the launch it sits)."""
@@ -193,3 +258,31 @@ def test_vitdet_stream_reaches_a_bit_stable_fixed_point(grid, policy, kw, cast, 
     assert torch.isfinite(y).all()
     assert stable == 3, f"ViTDet {grid}x{grid} {policy} {cast}: outputs still moving after {t} frames of a constant input"
     H.report(f"ViTDet {16 * grid}^2 one stream ({policy}, {cast or 'fp32'}): outputs bit-stable after {t - 3} frames of a constant input")
+
+
+@pytest.mark.parametrize("cast,tol", [(None, 5e-4), ("float16", 5e-3)])
+def test_vitdet_selecting_every_token_reproduces_the_dense_pass(cast, tol):
+    """r = N on the one-stream ViTDet path (672^2: 1764 tokens, windowed + global blocks, rel-pos): every gated frame must be the dense
+    pass over that frame -- evt_attention_stream with every key column selected, the small-row-count linears at 1764 rows.  fp16
+    cast: the A.v accumulator is an fp16 tensor incremented twice per frame (2^-11 relative each)."""
+    from eventful_transformer import policies
+    rel_for = lambda i: (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
+    sd = H.backbone_params(12, D, 4, 91, 14 * 14, rel_for=rel_for)
+    bb = H.product_vitdet(42, sd, cast)
+    n = 42 * 42
+    H.set_policies(bb, policies.TokenNormTopK, k=n)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    xs = [torch.randn(1, n, D, device=DEV, generator=g)]
+    for t in range(3):
+        xs.append(xs[-1] + 0.25 * torch.randn(1, n, D, device=DEV, generator=g))
+    worst = 0.0
+    with torch.inference_mode():
+        bb.reset()
+        ys = [bb(x).clone() for x in xs]
+        for t, x in enumerate(xs):
+            bb.reset()
+            dense = bb(x)
+            err = float((ys[t] - dense).abs().max())
+            worst = max(worst, err)
+            assert torch.isfinite(ys[t]).all() and err <= tol, (cast, t, err)
+    H.report(f"ViTDet 672^2 r = N ({cast or 'fp32'}): gated frames against the dense pass of the same frame, max |diff| {worst:.2e} (bar {tol:g})")
