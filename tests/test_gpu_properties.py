@@ -286,3 +286,50 @@ def test_vitdet_selecting_every_token_reproduces_the_dense_pass(cast, tol):
             worst = max(worst, err)
             assert torch.isfinite(ys[t]).all() and err <= tol, (cast, t, err)
     H.report(f"ViTDet 672^2 r = N ({cast or 'fp32'}): gated frames against the dense pass of the same frame, max |diff| {worst:.2e} (bar {tol:g})")
+
+
+_EVENTFUL_SMALL = [n_ for n_, c_ in H.small_cases().items() if c_[0] != "Block"]
+
+
+@pytest.mark.parametrize("name", _EVENTFUL_SMALL)
+def test_small_block_kinds_fixed_point_and_full_selection(name):
+    """Every block kind and option of the small golden cases (EventfulTokenwiseBlock / EventfulMatmul1Block / EventfulBlock; windows,
+    padding, rel-pos, pooled keys, STGT gate, gate_before_ln, bf16 / fp16 cast, top-k and threshold; head dim 16: the GENERIC kernels,
+    not the head-dim-64 fast paths): (a) constant input -> bit-stable outputs within 3 gates x ceil(N / k) + 3 frames, (b) with every
+    token selected each gated frame equals the block's own first-frame (dense) pass over that frame."""
+    from eventful_transformer import policies
+    case = H.small_cases()[name]
+    kind, isz, has_cls, kw, pol = case
+    params = H.small_case_params(name, case, 1234)
+    n = isz[0] * isz[1] + (1 if has_cls else 0)
+    g = torch.Generator(device=DEV).manual_seed(len(name))
+    xs = [torch.randn(3, n, H.SMALL["dim"], device=DEV, generator=g)]
+    for t in range(3):
+        xs.append(xs[-1] + 0.5 * torch.randn(3, n, H.SMALL["dim"], device=DEV, generator=g))
+    blk = H.product_block(kind, params, H.SMALL["dim"], H.SMALL["heads"], isz, **kw)
+    H.product_policy(blk, pol)
+    k = pol[1] if pol[0] == "topk" else n
+    limit = 3 * (-(-n // max(1, int(k)))) + 3
+    with torch.inference_mode():
+        blk.reset()
+        for x in xs:
+            y = blk(x).clone()
+        stable, t = 0, 0
+        while stable < 2 and t < limit + 2:
+            y2 = blk(xs[-1]).clone()
+            stable = stable + 1 if torch.equal(y, y2) else 0
+            y = y2
+            t += 1
+        assert stable == 2, f"{name}: still moving after {t} constant frames"
+        assert torch.isfinite(y).all()
+        # (b) everything selected
+        H.set_policies(blk, policies.TokenNormTopK, k=n)
+        blk.reset()
+        ys = [blk(x).clone() for x in xs]
+        cast = kw.get("matmul_2_cast")
+        tol = 2e-4 if cast is None else (2e-2 if cast == "bfloat16" else 3e-3)
+        for t_, x in enumerate(xs):
+            blk.reset()
+            dense = blk(x)
+            err = float((ys[t_] - dense).abs().max())
+            assert err <= tol, (name, t_, err)
