@@ -33,7 +33,7 @@ def _tokens(seed, scale=1.0):
     return torch.randn(B, N, D, device=DEV, generator=g) * scale
 
 
-@pytest.mark.parametrize("cast", [None, "bfloat16"])
+@pytest.mark.parametrize("cast", [None, "bfloat16", "float16"])
 def test_constant_input_reaches_a_bit_stable_fixed_point(cast):
     """Three different frames, then the SAME frame again and again.  The contracts say what must happen: a gate whose input stopped
     changing refreshes 128 then the remaining 69 tokens, after which its delta is EXACTLY zero (modules.py:149-160: e = c - p with
@@ -224,12 +224,14 @@ def test_selection_lists_and_gate_reference_at_full_size():
              f"block 0's qkv lists are top-{K} sets of the recomputed delta norms; reference rows outside the lists bit-unchanged")
 
 
-@pytest.mark.parametrize("grid,policy,kw,cast,max_frames", [(42, "TokenNormTopK", dict(k=256), None, 330),
-                                                           (64, "TokenNormThreshold", dict(threshold=1.0), "bfloat16", 120),
-                                                           (42, "TokenNormTopK", dict(k=256), "float16", 330)])
-def test_vitdet_stream_reaches_a_bit_stable_fixed_point(grid, policy, kw, cast, max_frames):
+@pytest.mark.parametrize("grid,policy,kw,cast,max_frames,pool", [(42, "TokenNormTopK", dict(k=256), None, 330, None),
+                                                                (64, "TokenNormThreshold", dict(threshold=1.0), "bfloat16", 120, None),
+                                                                (42, "TokenNormTopK", dict(k=256), "float16", 330, None),
+                                                                (42, "TokenNormTopK", dict(k=256), "float16", 330, 2)])
+def test_vitdet_stream_reaches_a_bit_stable_fixed_point(grid, policy, kw, cast, max_frames, pool):
     """The same idempotence on the one-stream ViTDet path at its full sizes (BASELINE configs 3 and 5: N = 1764 top-k 256 with the fp32
-    store type, N = 4096 under the threshold policy with the bf16 cast; plus the fp16 cast): windowed blocks on the resident K8,
+    store type, N = 4096 under the threshold policy with the bf16 cast; plus the fp16 cast, also with K / V pooled 2 x 2 in the global
+    blocks, the 'spatiotemporal' variant): windowed blocks on the resident K8,
     global blocks on evt_attention_stream (transposed gate reference, rel-pos terms, device-side counts), small-row-count gated linears.
     Top-k: ceil(1764 / 256) = 7 frames per gate, 36 gates + the attention gates' lag.  Threshold: once no delta exceeds the threshold
     nothing is selected (count 0) and nothing may move."""
@@ -237,7 +239,7 @@ def test_vitdet_stream_reaches_a_bit_stable_fixed_point(grid, policy, kw, cast, 
     from eventful_transformer import policies
     rel_for = lambda i: (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
     sd = H.backbone_params(12, D, 4, 91, 14 * 14, rel_for=rel_for)
-    bb = H.product_vitdet(grid, sd, cast)
+    bb = H.product_vitdet(grid, sd, cast, pool_size=pool)
     H.set_policies(bb, getattr(policies, policy), **kw)
     n = grid * grid
     g = torch.Generator(device=DEV).manual_seed(grid)
@@ -257,7 +259,7 @@ def test_vitdet_stream_reaches_a_bit_stable_fixed_point(grid, policy, kw, cast, 
             t += 1
     assert torch.isfinite(y).all()
     assert stable == 3, f"ViTDet {grid}x{grid} {policy} {cast}: outputs still moving after {t} frames of a constant input"
-    H.report(f"ViTDet {16 * grid}^2 one stream ({policy}, {cast or 'fp32'}): outputs bit-stable after {t - 3} frames of a constant input")
+    H.report(f"ViTDet {16 * grid}^2 one stream ({policy}, {cast or 'fp32'}{', pooled keys' if pool else ''}): outputs bit-stable after {t - 3} frames of a constant input")
 
 
 @pytest.mark.parametrize("cast,tol", [(None, 5e-4), ("float16", 5e-3)])
@@ -333,3 +335,28 @@ def test_small_block_kinds_fixed_point_and_full_selection(name):
             dense = blk(x)
             err = float((ys[t_] - dense).abs().max())
             assert err <= tol, (name, t_, err)
+
+
+def test_vivit_401_tokens_reaches_a_bit_stable_fixed_point():
+    """The EPIC-Kitchens-shaped model (BASELINE config 4's: 20 x 20 grid + class token = 401 tokens, r = 50, fp16 cast,
+    configs/time/vivit_epic_kitchens): more than 256 tokens, so its attention runs on evt_attention_stream WITHOUT a position grid and
+    with a class token (odd token count).  8 clips; ceil(401 / 50) = 9 frames per gate."""
+    from eventful_transformer import policies
+    sd = H.backbone_params(12, D, 4, 43, 401)
+    bb = H.product_vivit(sd, "float16", grid=20)
+    H.set_policies(bb, policies.TokenNormTopK, k=50)
+    g = torch.Generator(device=DEV).manual_seed(401)
+    frames = [torch.randn(8, 401, D, device=DEV, generator=g) for _ in range(3)]
+    with torch.inference_mode():
+        bb.reset()
+        for x in frames:
+            y = bb(x).clone()
+        stable, t = 0, 0
+        while stable < 3 and t < 400:
+            y2 = bb(frames[-1]).clone()
+            stable = stable + 1 if torch.equal(y, y2) else 0
+            y = y2
+            t += 1
+    assert torch.isfinite(y).all()
+    assert stable == 3, f"still moving after {t} frames of a constant input"
+    H.report(f"ViViT 401 tokens (r = 50, fp16, 8 clips): outputs bit-stable after {t - 3} frames of a constant input")
