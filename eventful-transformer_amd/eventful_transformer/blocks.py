@@ -186,6 +186,10 @@ class Block(ExtendedModule):
             raise RuntimeError(f"block input must be (batch, tokens, {self.dim}), got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise RuntimeError(f"block input must be float32, got {x.dtype}")
+        if (self.window_size is not None or self.relative_position is not None or self.pool_size is not None) \
+                and x.shape[1] != self.input_size[0] * self.input_size[1]:
+            # windows, rel-pos terms and pooled cells are laid out on the input grid (blocks.py:257-326 reshape to it and fail)
+            raise RuntimeError(f"block input has {x.shape[1]} tokens but input_size = {tuple(self.input_size)}")
         return x if x.is_contiguous() else x.contiguous()
 
     def _compute_window_padding(self):
@@ -475,6 +479,16 @@ class EventfulTokenwiseBlock(Block):
         self._wants_rest = False   # set by subclasses that keep a q.k^T product state
         self._rest = None
 
+    def _check_clip_shape(self, bn):
+        """The per-clip state (gate references, token buffers, attention states) has the first frame's (batch, tokens): the kernels
+        address it with those sizes.  The reference fails in its scatter / gather with a shape error when they change without
+        reset() (modules.py:90-96, 154-164); here it would be an out-of-bounds access, so it is an error up front."""
+        if self.qkv_gate.first:
+            self.__dict__["_clip_shape"] = bn
+        elif self.__dict__.get("_clip_shape", bn) != bn:
+            raise RuntimeError(f"{type(self).__name__}: frame of (batch, tokens) = {bn} but this clip's state was created for "
+                               f"{self.__dict__['_clip_shape']}; call reset() between clips")
+
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
     # ---------------------------------------------------------------------------------------------
@@ -651,6 +665,7 @@ class EventfulTokenwiseBlock(Block):
     def forward(self, x, _defer_output=False):
         """_defer_output (ViTBackbone only, never with hooks registered): return the block output as a PendingSum."""
         defer = _defer_output
+        self._check_clip_shape(tuple(x.shape[:2]))
         if isinstance(x, PendingSum):
             B, N, D = x.shape
             xin = self._ws("x_in", (B, N, D), torch.float32, x.src)

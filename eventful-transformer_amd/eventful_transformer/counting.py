@@ -60,7 +60,8 @@ class CountedLinear(ExtendedModule):
         loaded", utils.py:102-105,191-195) and on load_state_dict().  Other in-place writes through `weight.data` keep
         pointer and version: call reset() after them."""
         w = self.weight
-        key = (w.data_ptr(), w._version, _native.GEMM_MODE)
+        # (inference tensors -- a model built or loaded under torch.inference_mode() -- track no version: the address alone keys them)
+        key = (w.data_ptr(), -1 if w.is_inference() else w._version, _native.GEMM_MODE)
         if self._split is None or self._split[0] != key:
             self._split = (key, _native.split_weight(w))
         return self._split[1]

@@ -31,6 +31,14 @@ def _rows_fast(*tensors):
                for t in tensors)
 
 
+def _require_shape(who, what, got, want):
+    """The state tensors of a clip have the first frame's sizes and the kernels address them with those: the reference fails in its
+    gather / scatter with a shape error when a later frame differs (modules.py:90-96, 154-164); here that is an error up front instead
+    of an out-of-bounds access."""
+    if tuple(got) != tuple(want):
+        raise RuntimeError(f"{who}: {what} of shape {tuple(got)} does not fit this clip's state {tuple(want)}; call reset() between clips")
+
+
 def _index_i32(index, lead, device):
     """(…,k) int index broadcast over the leading dims `lead` -> contiguous (prod(lead), k) int32."""
     k = index.shape[-1]
@@ -68,6 +76,10 @@ class _GateBase(ExtendedModule):
             return
         self._tiles = None
         self._p = value
+
+    def _p_shape(self):
+        """Shape of the reference without materialising a tiled one."""
+        return tuple(self._tiles.shape[:2]) + (self._tiles_n, self._tiles_n) if self._tiles is not None else tuple(self._p.shape)
 
     def use_tiles(self, tiles, n):
         """The reference lives in `tiles` (evt_attention_gated layout) from now on; `p` reads / writes go through it."""
@@ -129,6 +141,7 @@ class TokenGate(_GateBase):
             self.counts["gate_flops"] += self.p.numel()
 
     def _incremental(self, c, forced_index, want_delta):
+        _require_shape(type(self).__name__, "input", c.shape, self._p_shape())
         self._count_gate()
         if self.structure == "row" and _rows_fast(c, self.p):
             idx, count, index = self._select_rows(c, forced_index)
@@ -198,6 +211,7 @@ class SimpleSTGTGate(_GateBase):
         return c, None
 
     def forward_incremental(self, c):
+        _require_shape(type(self).__name__, "input", c.shape, self._p_shape())
         if self.count_mode:
             self.counts["gate_flops"] += c.numel()
         if _rows_fast(c, self.p):
@@ -235,6 +249,9 @@ class TokenBuffer(ExtendedModule):
         return self.b
 
     def forward_incremental(self, x, index):
+        k = index.shape[-1]
+        want = tuple(self.b.shape[:-2]) + ((k, self.b.shape[-1]) if self.structure == "row" else (self.b.shape[-2], k))
+        _require_shape(type(self).__name__, f"gated tokens ({k} indices)", x.shape, want)
         if self.structure == "row" and _rows_fast(x, self.b):
             lead, N, F = self.b.shape[:-2], self.b.shape[-2], self.b.shape[-1]
             idx = _index_i32(index, lead, x.device)
@@ -316,6 +333,7 @@ class MatmulBuffer(ExtendedModule):
         qc, kr = self._operands(q, k)
         B, H, Nq, dh = qc.shape
         Nk = kr.shape[2]
+        _require_shape(type(self).__name__, "q . k^T", (B, H, Nq, Nk), self.product.shape)
         iq = _index_i32(index_q, (B,), q.device)
         ik = _index_i32(index_k, (B,), q.device)
         self.matmul.count_product(B * H * iq.shape[1] * Nk, dh)
@@ -367,6 +385,8 @@ class MatmulDeltaAccumulator(ExtendedModule):
     def forward_incremental(self, a_n_tilde, v_n_tilde, a_delta_tilde, v_delta_tilde):
         B, H, N, K = a_n_tilde.shape
         dh = v_n_tilde.shape[-1]
+        _require_shape(type(self).__name__, "A . v", (B, H, N, dh), self.product.shape)
+        _require_shape(type(self).__name__, "gated value rows", v_n_tilde.shape, (B, H, K, dh))
         if self.count_mode:
             self.counts["accumulator_flops"] += v_n_tilde.numel() + 2 * self.product.numel()
         self.matmul.count_product(B * H * N * dh, K)

@@ -99,6 +99,8 @@ class PositionEncoding(ExtendedModule):
 
     def forward(self, x):
         enc = self.sized()
+        if tuple(x.shape[-2:]) != tuple(enc.shape[-2:]):   # (the reference's `x + encoding` fails to broadcast, utils.py:66)
+            raise RuntimeError(f"PositionEncoding: input of {tuple(x.shape[-2:])} (tokens, channels) but the encoding is sized for {tuple(enc.shape[-2:])}")
         if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and enc.is_contiguous() and x.ndim == 3:
             # row pass with the (1,N,D) table broadcast over clips (utils.py:66)
             B, N, D = x.shape

@@ -35,7 +35,7 @@ class _Planes:
         self._cache = {}
 
     def get(self, tag, param, make):
-        key = (param.data_ptr(), param._version, _native.GEMM_MODE)
+        key = (param.data_ptr(), -1 if param.is_inference() else param._version, _native.GEMM_MODE)
         hit = self._cache.get(tag)
         if hit is None or hit[0] != key:
             w2 = make().contiguous()

@@ -58,7 +58,7 @@ class TubeletEmbedding(nn.Module):
         self._split = None
 
     def _planes(self, w2):
-        key = (w2.data_ptr(), self.conv.weight._version, _native.GEMM_MODE)
+        key = (w2.data_ptr(), -1 if self.conv.weight.is_inference() else self.conv.weight._version, _native.GEMM_MODE)
         if self._split is None or self._split[0] != key:
             self._split = (key, _native.split_weight(w2))
         return self._split[1]

@@ -278,3 +278,80 @@ def test_two_streams_share_a_work_lane_safely_and_overlap_with_lanes():
         for i in (0, 1):
             for t in range(3):
                 assert torch.equal(outs[i][t], want[t]), (lanes, i, t)
+
+
+def test_frames_that_do_not_fit_the_clip_state_are_errors():
+    """A later frame with another batch size or token count than the clip's first frame, without reset(): the reference fails in its
+    gather / scatter with a shape error (modules.py:90-96, 154-164; utils.py:66; blocks.py:257-326) -- the kernels would read and write
+    out of bounds (found as a GPU memory fault by scripts/probes/api_robustness_probe.py), so every entry point checks first.  After
+    reset() the new shape is fine."""
+    from eventful_transformer import modules as M, policies
+    from eventful_transformer.backbones import ViTBackbone
+    bb = ViTBackbone(block_config=dict(dim=64, heads=4, mlp_ratio=4), depth=2, position_encoding_size=(6, 6), input_size=(6, 6),
+                     block_class="EventfulBlock", has_class_token=True).eval().to(DEV)
+    H.set_policies(bb, policies.TokenNormTopK, k=12)
+    x4, x2 = torch.randn(4, 37, 64, device=DEV), torch.randn(2, 37, 64, device=DEV)
+    with torch.inference_mode():
+        bb(x4)
+        with pytest.raises(RuntimeError, match="reset"):
+            bb(x2)
+        bb.reset()
+        y = bb(x2)
+        assert torch.isfinite(bb(x2 + 0.1)).all() and y.shape == (2, 37, 64)
+        with pytest.raises(RuntimeError, match="reset"):
+            bb(x4)
+        bb.reset()
+        for n_bad in (30, 40):   # the position encoding is sized for 37 tokens
+            with pytest.raises(RuntimeError, match="PositionEncoding"):
+                bb(torch.randn(2, n_bad, 64, device=DEV))
+        # a windowed / rel-pos block lays its tokens out on input_size
+        params = O.make_block_params(64, 4, seed=3, std=0.08, rel_sizes=(3, 3), head_dim=16)
+        blk = H.product_block("EventfulTokenwiseBlock", params, 64, 4, (6, 6), window_size=(3, 3), relative_embedding_size=(8, 8))
+        H.set_policies(blk, policies.TokenNormTopK, k=12)
+        with pytest.raises(RuntimeError, match="input_size"):
+            blk(torch.randn(2, 35, 64, device=DEV))
+        blk(torch.randn(2, 36, 64, device=DEV))
+        # stand-alone modules
+        gate = M.TokenGate()
+        gate.policy = policies.TokenNormTopK(8)
+        gate(torch.randn(4, 50, 64, device=DEV))
+        with pytest.raises(RuntimeError, match="reset"):
+            gate(torch.randn(2, 50, 64, device=DEV))
+        with pytest.raises(RuntimeError, match="reset"):
+            gate(torch.randn(4, 51, 64, device=DEV))
+        dgate = M.TokenDeltaGate(structure="col")
+        dgate.policy = policies.TokenNormTopK(8)
+        dgate(torch.randn(2, 3, 20, 20, device=DEV))
+        with pytest.raises(RuntimeError, match="reset"):
+            dgate(torch.randn(2, 3, 20, 21, device=DEV), forced_index=torch.arange(8, device=DEV).expand(2, 8))
+        buf = M.TokenBuffer()
+        buf(torch.randn(4, 50, 64, device=DEV), None)
+        with pytest.raises(RuntimeError, match="reset"):
+            buf(torch.randn(2, 8, 64, device=DEV), torch.zeros(2, 8, dtype=torch.long, device=DEV))
+        with pytest.raises(RuntimeError, match="reset"):
+            buf(torch.randn(4, 9, 64, device=DEV), torch.zeros(4, 8, dtype=torch.long, device=DEV))
+        mb = M.MatmulBuffer()
+        mb(torch.randn(2, 3, 20, 16, device=DEV), torch.randn(2, 3, 16, 20, device=DEV), None, None)
+        ix = torch.arange(5, device=DEV).expand(2, 5)
+        with pytest.raises(RuntimeError, match="reset"):
+            mb(torch.randn(2, 3, 21, 16, device=DEV), torch.randn(2, 3, 16, 20, device=DEV), ix, ix)
+        acc = M.MatmulDeltaAccumulator()
+        acc(torch.rand(2, 3, 20, 20, device=DEV), torch.randn(2, 3, 20, 16, device=DEV), None, None)
+        with pytest.raises(RuntimeError, match="reset"):
+            acc(torch.rand(2, 3, 21, 5, device=DEV), torch.randn(2, 3, 5, 16, device=DEV), torch.rand(2, 3, 21, 5, device=DEV), torch.randn(2, 3, 5, 16, device=DEV))
+
+
+def test_a_model_built_under_inference_mode_runs():
+    """Weights that are inference tensors (the model constructed or loaded inside torch.inference_mode()) track no version counter;
+    the weight-plane caches key them by address alone instead of raising."""
+    from eventful_transformer import policies
+    params = O.make_block_params(64, 4, seed=3, std=0.08)
+    xs = O.make_token_stream(2, 37, 64, 3, 12, seed=4, small=0.02).to(DEV)
+    outside = H.product_block("EventfulBlock", params, 64, 4, (6, 6))
+    H.set_policies(outside, policies.TokenNormTopK, k=12)
+    with torch.inference_mode():
+        inside = H.product_block("EventfulBlock", params, 64, 4, (6, 6))
+        H.set_policies(inside, policies.TokenNormTopK, k=12)
+        assert next(inside.parameters()).is_inference()
+        for t in range(3):
+            assert torch.equal(inside(xs[t]), outside(xs[t]))
