@@ -100,6 +100,9 @@ class _GateBase(ExtendedModule):
         Bp = rows // N
         if forced_index is not None:
             return _index_i32(forced_index, lead, c.device), None, forced_index
+        if isinstance(self.policy, _NormPolicy) and getattr(self.policy, "_k", lambda n: 1)(N) == 0:   # top-k with k = 0: nothing forwarded
+            idx = torch.empty((Bp, 0), dtype=torch.int32, device=c.device)
+            return idx, None, idx.long().view(tuple(lead) + (0,))
         if isinstance(self.policy, _NormPolicy):
             norms = _native.scratch("gate_norms", (rows,), torch.float32, c.device)
             _native.row_pass(c, rows, D, p=self.p, norms=norms, order=getattr(self.policy, "order", 2))
@@ -149,7 +152,8 @@ class TokenGate(_GateBase):
             Bp, cap = idx.shape
             c_t = torch.empty(tuple(lead) + (cap, D), dtype=torch.float32, device=c.device)
             e_t = torch.empty_like(c_t) if want_delta else None
-            _native.gate_gather_update(c, self.p, idx, count, Bp, N, D, cap, c_tilde=c_t, e_tilde=e_t, update_p=True)
+            if cap:
+                _native.gate_gather_update(c, self.p, idx, count, Bp, N, D, cap, c_tilde=c_t, e_tilde=e_t, update_p=True)
             return c_t, e_t, index
         return self._incremental_any(c, forced_index, want_delta, update_p=True)
 
@@ -219,7 +223,8 @@ class SimpleSTGTGate(_GateBase):
             lead, N, D = c.shape[:-2], c.shape[-2], c.shape[-1]
             Bp, cap = idx.shape
             c_t = torch.empty(tuple(lead) + (cap, D), dtype=torch.float32, device=c.device)
-            _native.gate_gather_update(c, None, idx, count, Bp, N, D, cap, c_tilde=c_t, update_p=False)
+            if cap:
+                _native.gate_gather_update(c, None, idx, count, Bp, N, D, cap, c_tilde=c_t, update_p=False)
         else:
             c_t, _, index = TokenGate._incremental_any(self, c, None, False, update_p=False)
         self.p = c

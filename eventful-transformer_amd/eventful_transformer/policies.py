@@ -102,18 +102,32 @@ class TokenNormTopK(_NormPolicy):
     def _k(self, n_tokens):
         return self.k
 
+    # k = 0 (`topk(0)`: an empty index, policies.py:63 -- e.g. TokenNormTopFraction with fraction * N < 1): every gate forwards nothing.
+    # The fused gates take it as a device-side count of 0 over an index list of capacity 1, the route of a threshold policy that
+    # selects nothing (the kernels address index lists of at least one slot).
     def capacity(self, n_tokens):
-        return self._k(n_tokens)
+        return max(1, self._k(n_tokens))
 
     def fixed_count(self, n_tokens):
-        return self._k(n_tokens)
+        return self._k(n_tokens) or None
 
     def select_into(self, norms, B, N, idx, count, rest=None, parts=0):
         self._check_order()
         assert not parts or self.order == 2, "per-head partial squares only make an L2 norm"
+        if self._k(N) == 0:
+            count.zero_()
+            if rest is not None:
+                rest.copy_(torch.arange(N, dtype=torch.int32, device=rest.device).expand(B, N))
+            return
         _native.select_topk(norms, B, N, self._k(N), idx, rest, parts=parts)
 
     def forward(self, x, dim=-1):
+        if self._k(x.shape[-2 if dim in (-1, x.ndim - 1) else -1]) == 0:
+            _native.require_hip(x)
+            out = torch.empty(tuple(x.shape[:-2]) + (0,), dtype=torch.int64, device=x.device)
+            if getattr(self, "save_status", False):
+                self.last_input, self.last_output = x.clone(), out.clone()
+            return out
         norms, lead, N = _token_norms(x, dim, self.order)
         B = norms.numel() // N
         k = self._k(N)

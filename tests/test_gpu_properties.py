@@ -126,15 +126,16 @@ def _block_states(bb):
     return out
 
 
-@pytest.mark.parametrize("cast", [None, "bfloat16"])
-def test_selecting_nothing_leaves_every_state_untouched(cast):
-    """Threshold policy with an unreachable threshold: every device-side count is 0 in every gate of every clip, and then no gate
-    reference, token buffer, attention reference or A.v accumulator of any block may change by a single bit (modules.py:149-160,
-    187-201 with an empty index) while the inputs keep changing -- 256 clips x 12 blocks x 9 state tensors, 3 gated frames; the
-    block outputs are then x_t + the frozen buffers."""
+@pytest.mark.parametrize("cast,policy,kw", [(None, "TokenNormThreshold", dict(threshold=1e30)), ("bfloat16", "TokenNormThreshold", dict(threshold=1e30)),
+                                            ("bfloat16", "TokenNormTopK", dict(k=0)), (None, "TokenNormTopFraction", dict(fraction=0.004))])
+def test_selecting_nothing_leaves_every_state_untouched(cast, policy, kw):
+    """A policy that selects nothing -- a threshold no delta reaches (device-side counts of 0), top-k with k = 0, a fraction below
+    one token (`topk(0)`, policies.py:63,88-95) -- and then no gate reference, token buffer, attention reference or A.v accumulator
+    of any block may change by a single bit (modules.py:149-160, 187-201 with an empty index) while the inputs keep changing --
+    256 clips x 12 blocks x 9 state tensors, 3 gated frames; the block outputs are then x_t + the frozen buffers."""
     from eventful_transformer import policies
     bb, _ = _model(cast)
-    H.set_policies(bb, policies.TokenNormThreshold, threshold=1e30)
+    H.set_policies(bb, getattr(policies, policy), **kw)
     xs = [_tokens(40)]
     for t in range(3):
         xs.append(xs[-1] + 0.25 * _tokens(41 + t))
