@@ -49,6 +49,35 @@ def test_abi_argument_errors_without_gpu():
     assert _native.attention_stream_fits(4096, 768, 12, _native.EVT_BF16, 64, 64)
 
 
+def test_every_descriptor_entry_point_rejects_null_and_zeroed_descriptors_without_a_gpu():
+    """The C ABI is the drop-in boundary (include/evt_abi.h): a binding written in another language will get arguments wrong.  Every
+    entry point that takes a descriptor must answer a NULL descriptor and an all-zero descriptor (null pointers, zero sizes) with an
+    error code and a message -- before any HIP call, so this runs on a GPU-less box -- never with a crash."""
+    import ctypes
+    from eventful_transformer import _native as n
+    lib = n.load()
+    pairs = [("evt_gated_linear", n.LinearDesc), ("evt_gated_mlp", n.MlpDesc), ("evt_qk", n.QkDesc), ("evt_softmax_gate", n.SoftmaxDesc),
+             ("evt_av", n.AvDesc), ("evt_softmax_av_gated", n.SoftmaxAvDesc), ("evt_attention_dense", n.AttnDenseDesc),
+             ("evt_attention_stream", n.AttnStreamDesc), ("evt_stream_prep", n.StreamPrepDesc), ("evt_attention_gated", n.AttnGatedDesc)]
+    for name, cls in pairs:
+        fn = getattr(lib, name)
+        assert fn(None, None) < 0, name
+        assert lib.evt_last_error_string(), name
+        d = cls()
+        ctypes.memset(ctypes.byref(d), 0, ctypes.sizeof(d))
+        assert fn(ctypes.byref(d), None) < 0, f"{name} accepted an all-zero descriptor"
+        assert lib.evt_last_error_string(), name
+    # positional entry points: null pointers / non-positive sizes
+    assert lib.evt_gate_cols(None, None, None, None, 1, 1, 1, 1, n.EVT_F32, None, None, 0, None) < 0
+    assert lib.evt_scatter_cols(None, None, None, None, 1, 1, 1, 1, n.EVT_F32, None) < 0
+    assert lib.evt_gate_rows_any(None, None, None, None, 1, 1, 1, 1, n.EVT_F32, None, None, 0, None) < 0
+    assert lib.evt_ats_scores(None, None, 0, 0, 0, 1, 1, 2, 1, n.EVT_F32, None, None) < 0
+    assert lib.evt_ats_stabilize(None, None, 1, 1, 1, None, None) < 0
+    assert lib.evt_attention_gated_tile_bytes(-1, 1, 1) < 0 and lib.evt_attention_gated_tile_bytes(1, 12, 197) == 12 * 49 * 2048
+    assert lib.evt_attention_gated_fits(197, 768, 12, n.EVT_BF16, 1) == 1 and lib.evt_attention_gated_fits(257, 768, 12, n.EVT_BF16, 1) == 0
+    assert lib.evt_attention_gated_fits(197, 768, 12, n.EVT_F32, 1) == 0 and lib.evt_attention_gated_fits(197, 768, 8, n.EVT_BF16, 1) == 0
+
+
 def test_splitk_workspace_query_is_shape_only():
     """Split-K is chosen from (rows, K, Nout) alone: few-tile launches get S planes, chip-filling ones none."""
     from eventful_transformer import _native
