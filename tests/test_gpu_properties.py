@@ -361,3 +361,36 @@ def test_vivit_401_tokens_reaches_a_bit_stable_fixed_point():
     assert torch.isfinite(y).all()
     assert stable == 3, f"still moving after {t} frames of a constant input"
     H.report(f"ViViT 401 tokens (r = 50, fp16, 8 clips): outputs bit-stable after {t - 3} frames of a constant input")
+
+
+@pytest.mark.parametrize("cast", ["bfloat16", None])
+def test_tensors_beyond_4_gb_are_addressed_correctly(cast):
+    """288 GB of HBM invite resident batches far above the benchmark's 256 clips.  2 ViViT-B EventfulBlocks at 2048 clips: the first
+    frame's hidden MLP tensor is 2048 x 197 x 3072 x 4 bytes = 5 GB, the packed q/k/v token buffer 3.7 GB, the gated GEMMs run 262 144
+    rows -- past both the signed and the unsigned 32-bit byte offset.  A clip does not know which batch it runs in: the first and the
+    LAST 256 clips must equal, bit for bit, runs of just those clips (first frame + 2 gated frames)."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+    big_b = 2048
+    cfg = dict(dim=D, heads=12, mlp_ratio=4)
+    if cast:
+        cfg["matmul_2_cast"] = cast
+    bb = ViTBackbone(block_config=cfg, depth=2, position_encoding_size=(14, 14), input_size=(14, 14), block_class="EventfulBlock", has_class_token=True)
+    bb.load_state_dict(H.backbone_params(2, D, 4, 41, N))
+    bb = bb.eval().to(DEV)
+    H.set_policies(bb, policies.TokenNormTopK, k=K)
+    g = torch.Generator(device=DEV).manual_seed(big_b)
+    xs = [torch.randn(big_b, N, D, device=DEV, generator=g)]
+    for t in range(2):
+        xs.append(xs[-1] + 0.25 * torch.randn(big_b, N, D, device=DEV, generator=g))
+    with torch.inference_mode():
+        bb.reset()
+        big = [bb(x).clone() for x in xs]
+        for lo in (0, big_b - 256):
+            bb.reset()
+            for t, x in enumerate(xs):
+                small = bb(x[lo:lo + 256])
+                assert torch.isfinite(small).all()
+                assert torch.equal(small, big[t][lo:lo + 256]), (cast, lo, t, float((small - big[t][lo:lo + 256]).abs().max()))
+    del big, xs, bb
+    torch.cuda.empty_cache()
