@@ -394,3 +394,28 @@ def test_tensors_beyond_4_gb_are_addressed_correctly(cast):
                 assert torch.equal(small, big[t][lo:lo + 256]), (cast, lo, t, float((small - big[t][lo:lo + 256]).abs().max()))
     del big, xs, bb
     torch.cuda.empty_cache()
+
+
+def test_vitdet_streams_are_independent_of_their_batch_position():
+    """32 video streams in one launch on the ViTDet 672^2 path (fp32: each global block's transposed gate reference is 32 x 12 x 1764^2
+    x 4 bytes = 4.8 GB): the streams permuted -> the outputs permuted, bit for bit (first frame + 2 gated frames)."""
+    from eventful_transformer import policies
+    rel_for = lambda i: (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
+    bb = H.product_vitdet(42, H.backbone_params(12, D, 4, 91, 14 * 14, rel_for=rel_for), None)
+    H.set_policies(bb, policies.TokenNormTopK, k=256)
+    n, streams = 42 * 42, 32
+    g = torch.Generator(device=DEV).manual_seed(streams)
+    xs = [torch.randn(streams, n, D, device=DEV, generator=g)]
+    for t in range(2):
+        xs.append(xs[-1] + 0.25 * torch.randn(streams, n, D, device=DEV, generator=g))
+    perm = torch.randperm(streams, device=DEV, generator=g)
+    with torch.inference_mode():
+        bb.reset()
+        ys = [bb(x).clone() for x in xs]
+        bb.reset()
+        for t, x in enumerate(xs):
+            yp = bb(x[perm])
+            assert torch.isfinite(yp).all()
+            assert torch.equal(yp, ys[t][perm]), f"frame {t}: a stream's output depends on its batch position"
+    del bb, ys, xs
+    torch.cuda.empty_cache()
