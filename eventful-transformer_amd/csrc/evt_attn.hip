@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void av_kernel(const AvArgs a) {
 
 template <typename T>
 int launch_av(const AvArgs& a, void* stream) {
-  const int nt = a.dh / 16;
+  const int nt = (a.dh % 16) == 0 ? a.dh / 16 : 0;
   const size_t lds = (size_t)(2 * 64 * 36 + 2 * 32 * (a.dh + 4)) * sizeof(float);
   const dim3 grid((a.N + 63) / 64, a.G * a.H), block(256);
   if (grid.x == 0 || grid.y == 0) return EVT_OK;
@@ -548,9 +548,13 @@ int launch_av(const AvArgs& a, void* stream) {
   switch (nt) {
     case 1: hipLaunchKernelGGL((av_kernel<T, 1>), grid, block, lds, s, a); break;
     case 2: hipLaunchKernelGGL((av_kernel<T, 2>), grid, block, lds, s, a); break;
+    case 3: hipLaunchKernelGGL((av_kernel<T, 3>), grid, block, lds, s, a); break;   // 48
     case 4: hipLaunchKernelGGL((av_kernel<T, 4>), grid, block, lds, s, a); break;
+    case 5: hipLaunchKernelGGL((av_kernel<T, 5>), grid, block, lds, s, a); break;   // 80: ViT-H (1280 / 16)
+    case 6: hipLaunchKernelGGL((av_kernel<T, 6>), grid, block, lds, s, a); break;   // 96
+    case 7: hipLaunchKernelGGL((av_kernel<T, 7>), grid, block, lds, s, a); break;   // 112
     case 8: hipLaunchKernelGGL((av_kernel<T, 8>), grid, block, lds, s, a); break;
-    default: return evt_fail(EVT_ERR_BAD_SHAPE, "evt_av: head dim %d must be 16, 32, 64 or 128", a.dh);
+    default: return evt_fail(EVT_ERR_BAD_SHAPE, "evt_av: head dim %d must be a multiple of 16, <= 128", a.dh);
   }
   return evt_check_launch("evt_av");
 }

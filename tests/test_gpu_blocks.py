@@ -1226,3 +1226,28 @@ def test_lazy_qk_state_is_exact_when_read():
             _native.FUSED_QK = old
     for a, b_ in zip(outs[True], outs[False]):
         assert float((a - b_).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("dim,heads,cast", [(384, 8, None), (1280, 16, None), (768, 8, None), (896, 8, None), (1280, 16, "bfloat16"), (896, 8, "bfloat16"),
+                                            (384, 6, None), (1024, 16, "bfloat16")])
+def test_other_widths_and_head_dims_match_the_oracle(dim, heads, cast):
+    """The reference takes any dim / heads (blocks.py:102-116).  Widths other than ViT-B's: head dim 64 at 384 / 1024 (ViT-S / ViT-L:
+    the fast paths with other head counts and ragged GEMM column tiles) and head dims 48 / 80 (ViT-H: 1280 / 16) / 96 / 112, which
+    take the generic attention kernels (evt_qk, evt_softmax_gate, evt_av: any multiple of 16 up to 128).  One EventfulBlock, N = 197,
+    top-k 128, first frame + 2 gated frames free-running on a designed-margin stream, 2 clips against the CPU oracle."""
+    from eventful_transformer import policies
+    n, k = 197, 128
+    params = O.make_block_params(dim, 4, seed=dim, std=0.02, head_dim=dim // heads)
+    kw = dict(matmul_2_cast=cast) if cast else {}
+    ob = O.BlockOracle("EventfulBlock", params, dim, heads, (1, n), **kw)
+    ob.set_policy(lambda: O.TopK(k))
+    blk = H.product_block("EventfulBlock", params, dim, heads, (1, n), **kw)
+    H.set_policies(blk, policies.TokenNormTopK, k=k)
+    xs = O.make_token_stream(2, n, dim, 3, k, seed=dim + 1, small=0.01)
+    tol = 2e-4 if cast is None else 2e-3
+    with torch.inference_mode():
+        for t in range(3):
+            y_ref = ob.forward(xs[t])
+            y = blk(xs[t].to(DEV)).cpu()
+            err = float((y - y_ref).abs().max())
+            assert err <= tol, (dim, heads, cast, t, err)
