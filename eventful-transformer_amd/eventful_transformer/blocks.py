@@ -700,6 +700,11 @@ class EventfulMatmul1Block(EventfulTokenwiseBlock):
         idx_k, count_k, cap_k = idx, count, cap
         if kv is not None and idx is not None:
             cap_k = min(cap, Nk)
+            # Pooled image of the index list, de-duplicated PER CLIP (blocks.py:525-540).  Batch 1 -- every reference config that pools --
+            # is the reference's list exactly.  For a batch the reference's `index.unique(dim=-1)` de-duplicates COLUMNS of the (B, k)
+            # tensor (whole batch vectors), which leaves duplicate cells inside a clip's row; its accumulator then adds a duplicated
+            # key's delta twice (modules.py:285-295) and a clip's output depends on its neighbours (0.4-0.6 off its own batch-1 result on
+            # the small golden shapes).  Here a clip in a batch gets its batch-1 result (tests/test_gpu_properties.py).
             idx_k = self._ws("idx_k", (B, cap_k), torch.int32, qkv)
             count_k = self._ws("cnt_k", (B,), torch.int32, qkv)
             p0, p1 = self.pool_size
