@@ -150,6 +150,14 @@ class RelativePositionEmbedding(ExtendedModule):
         if self.y_relative is None:
             self.y_relative = self._get_relative(self.y_embedding, dim=0).contiguous()
             self.x_relative = self._get_relative(self.x_embedding, dim=1).contiguous()
+            if self.y_relative.shape[0] != self.attention_size[0] or self.x_relative.shape[0] != self.attention_size[1]:
+                # utils.py:176-183 resizes BOTH decomposed tables to attention_size (h, w): with h != w the row table comes out (w, h',
+                # dh) and the reference's einsum fails ("subscript h has size w ..."); same limitation here, said clearly
+                shapes = (tuple(self.y_relative.shape), tuple(self.x_relative.shape))
+                self.y_relative = self.x_relative = None
+                raise RuntimeError(f"RelativePositionEmbedding: resizing a {self.embedding_size} embedding to the non-square attention size "
+                                   f"{self.attention_size} yields tables {shapes}; the reference fails on this too -- use a square grid or an "
+                                   f"embedding of the attention size")
         return self.y_relative, self.x_relative
 
     def count_fused(self, batch, heads):
