@@ -472,3 +472,49 @@ def test_pooled_keys_in_a_batch_give_every_clip_its_batch_1_result(kind, isz, po
                     err = float((y[b:b + 1] - y_ref).abs().max())
                     assert err <= tol, (kind, isz, pool, cast, t, b, err)
     assert sum(followed) >= 2, followed
+
+
+def test_results_do_not_depend_on_uninitialised_memory():
+    """Every scratch buffer and state tensor is `torch.empty` memory.  Run the ViViT-B (bf16 cast, 16 clips) and ViTDet 672^2 (fp32) frames,
+    drop every cached block and scratch buffer, POISON the allocator's free blocks with NaN patterns (fp32 and bf16 quiet NaNs), build the
+    models again on that memory and run the same frames: bit-identical, finite.  (scripts/probes/poison_probe.py runs more configs and
+    patterns.)"""
+    import eventful_oracle as O
+    from eventful_transformer import policies, _native
+
+    def poison(pattern):
+        torch.cuda.empty_cache()
+        held = []
+        for mb in (1024, 256, 64, 16, 4, 1):
+            for _ in range(10):
+                held.append(torch.full((mb * 2 ** 20 // 4,), pattern, dtype=torch.int32, device=DEV))
+        for kb in (256, 32, 4):
+            for _ in range(100):
+                held.append(torch.full((kb * 256,), pattern, dtype=torch.int32, device=DEV))
+        torch.cuda.synchronize()
+        del held
+
+    def vivit():
+        bb, _ = _model("bfloat16")
+        g = torch.Generator(device=DEV).manual_seed(5)
+        xs = [torch.randn(16, N, D, device=DEV, generator=g)]
+        for t in range(2):
+            xs.append(xs[-1] + 0.25 * torch.randn(16, N, D, device=DEV, generator=g))
+        with torch.inference_mode():
+            return [bb(x).clone().cpu() for x in xs]
+
+    def vitdet():
+        rel_for = lambda i: (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
+        bb = H.product_vitdet(42, H.backbone_params(12, D, 4, 91, 14 * 14, rel_for=rel_for), None)
+        H.set_policies(bb, policies.TokenNormTopK, k=256)
+        xs = O.make_token_stream(1, 42 * 42, D, 3, 256, seed=5, small=0.01).to(DEV)
+        with torch.inference_mode():
+            return [bb(xs[t]).clone().cpu() for t in range(3)]
+
+    for fn, pattern in ((vivit, 0x7fc07fc0), (vitdet, 0x7fc00000)):
+        clean = fn()
+        _native.clear_scratch()
+        poison(pattern)
+        again = fn()
+        for a, b in zip(clean, again):
+            assert torch.isfinite(b).all() and torch.equal(a, b)
