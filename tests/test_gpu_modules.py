@@ -355,3 +355,56 @@ def test_a_model_built_under_inference_mode_runs():
         assert next(inside.parameters()).is_inference()
         for t in range(3):
             assert torch.equal(inside(xs[t]), outside(xs[t]))
+
+
+def test_host_threads_driving_models_on_their_own_streams():
+    """Four host threads, each running its own ViViT-B backbone (bf16 / fp32 / fp16 casts, different batch sizes) on its own HIP stream at
+    the same time: scratch buffers are pooled per host thread and every launch goes to the thread's current stream, so the results are
+    bit for bit those of the same models run one after the other (three repetitions)."""
+    import threading
+    from eventful_transformer import policies
+    sd = H.backbone_params(12, 768, 4, 41, 197)
+    jobs = [("bfloat16", 32, 1), (None, 8, 2), ("float16", 16, 3), ("bfloat16", 32, 4)]
+    models, data = [], []
+    for cast, b, seed in jobs:
+        bb = H.product_vivit(sd, cast)
+        H.set_policies(bb, policies.TokenNormTopK, k=128)
+        models.append(bb)
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        xs = [torch.randn(b, 197, 768, device=DEV, generator=g)]
+        for t in range(4):
+            xs.append(xs[-1] + 0.25 * torch.randn(b, 197, 768, device=DEV, generator=g))
+        data.append(xs)
+    torch.cuda.synchronize()
+    errors = []
+
+    def run(i, out, stream):
+        try:
+            with torch.inference_mode():
+                if stream is None:
+                    models[i].reset()
+                    out[i] = [models[i](x).clone() for x in data[i]]
+                else:
+                    with torch.cuda.stream(stream):
+                        models[i].reset()
+                        out[i] = [models[i](x).clone() for x in data[i]]
+                    stream.synchronize()
+        except Exception as e:   # surfaces in the main thread below
+            errors.append((i, repr(e)))
+
+    seq = {}
+    for i in range(len(jobs)):
+        run(i, seq, None)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for rep in range(3):
+        par = {}
+        threads = [threading.Thread(target=run, args=(i, par, torch.cuda.Stream())) for i in range(len(jobs))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for i in range(len(jobs)):
+            assert all(torch.equal(a, b) for a, b in zip(seq[i], par[i])), (rep, i)
