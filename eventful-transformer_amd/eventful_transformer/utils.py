@@ -101,7 +101,7 @@ class PositionEncoding(ExtendedModule):
         enc = self.sized()
         if tuple(x.shape[-2:]) != tuple(enc.shape[-2:]):   # (the reference's `x + encoding` fails to broadcast, utils.py:66)
             raise RuntimeError(f"PositionEncoding: input of {tuple(x.shape[-2:])} (tokens, channels) but the encoding is sized for {tuple(enc.shape[-2:])}")
-        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and enc.is_contiguous() and x.ndim == 3:
+        if x.is_cuda and x.dtype == torch.float32 and enc.dtype == torch.float32 and x.is_contiguous() and enc.is_contiguous() and x.ndim == 3:
             # row pass with the (1,N,D) table broadcast over clips (utils.py:66)
             B, N, D = x.shape
             out = torch.empty_like(x)
@@ -148,6 +148,7 @@ class RelativePositionEmbedding(ExtendedModule):
     def tables(self):
         """Cached (h, h', dh) and (w, w', dh) tables; rebuilt after reset() (utils.py:151-156)."""
         if self.y_relative is None:
+            _native._need_f32("RelativePositionEmbedding", y_embedding=self.y_embedding, x_embedding=self.x_embedding)
             self.y_relative = self._get_relative(self.y_embedding, dim=0).contiguous()
             self.x_relative = self._get_relative(self.x_embedding, dim=1).contiguous()
             if self.y_relative.shape[0] != self.attention_size[0] or self.x_relative.shape[0] != self.attention_size[1]:

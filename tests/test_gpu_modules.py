@@ -408,3 +408,31 @@ def test_host_threads_driving_models_on_their_own_streams():
         assert not errors, errors
         for i in range(len(jobs)):
             assert all(torch.equal(a, b) for a, b in zip(seq[i], par[i])), (rep, i)
+
+
+def test_converted_or_misplaced_models_are_errors_not_memory_faults():
+    """A model converted with .half() / .bfloat16() / .double(), or left on the CPU while the frames are on the device, would hand the
+    kernels pointers to other element sizes or to host memory (a GPU memory fault before round 6's guards): a RuntimeError that says what
+    to do instead.  train() mode without DropPath is fine (inference kernels, no dropout)."""
+    from eventful_transformer import policies
+    from eventful_transformer.backbones import ViTBackbone
+
+    def model(**kw):
+        bb = ViTBackbone(block_config=dict(dim=64, heads=4, mlp_ratio=4, **kw), depth=2, position_encoding_size=(6, 6), input_size=(6, 6),
+                         block_class="EventfulBlock", has_class_token=False).eval().to(DEV)
+        H.set_policies(bb, policies.TokenNormTopK, k=12)
+        return bb
+
+    x = torch.randn(2, 36, 64, device=DEV)
+    with torch.inference_mode():
+        want = model()(x)
+        for conv in (lambda m: m.half(), lambda m: m.bfloat16(), lambda m: m.double()):
+            with pytest.raises(RuntimeError, match="float32"):
+                conv(model())(x)
+        with pytest.raises(RuntimeError, match="float32"):
+            conv(model(relative_embedding_size=(6, 6))).blocks[0].relative_position.tables()
+        with pytest.raises(RuntimeError, match="HIP device"):
+            model().cpu()(x)
+        with pytest.raises(RuntimeError, match="HIP device"):
+            model()(x.cpu())
+        assert torch.isfinite(model().train()(x)).all() and want.shape == (2, 36, 64)
