@@ -332,6 +332,7 @@ EVT_API int evt_v_gate(const float* v, int64_t v_rs, const int32_t* idx, const i
  *   out_f32 (nullable): pv converted back to fp32 (blocks.py:393-396), (B,N,D).
  *   out_map (nullable): un-window on write (blocks.py:346-376): row (g,t) -> clip row
  *   tok_map[g*N+t]; rows mapped to padding are dropped.
+ *   Head dim D / H: any multiple of 16 up to 128 (16 .. 128; ViT-H's 80 included).
  * ------------------------------------------------------------------------------------------ */
 typedef struct evt_av_desc {
   const void* a1; const void* v1;         /* FULL: a_state (B,H,N,Nk), v_state (B,Nk,D)          */
