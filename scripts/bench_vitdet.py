@@ -21,7 +21,11 @@ ap.add_argument("--cast", default="none")
 ap.add_argument("--frames", type=int, default=12)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the first / incremental frame (graphs.py)")
+ap.add_argument("--fuse-dense-norm-rows", type=int, default=None, help="A/B: blocks.FUSE_DENSE_NORM_ROWS (0 = the windowed blocks' attention always emits the projection gate's norm)")
 a = ap.parse_args()
+if a.fuse_dense_norm_rows is not None:
+    from eventful_transformer import blocks as _EB
+    _EB.FUSE_DENSE_NORM_ROWS = a.fuse_dense_norm_rows
 cast = None if a.cast == "none" else a.cast
 from eventful_transformer import policies
 rel_for = lambda i: (14, 14) if i in H.VITDET_WINDOWED else (64, 64)
