@@ -521,6 +521,10 @@ class EventfulTokenwiseBlock(Block):
         idx = index.reshape(B, -1).to(torch.int32).contiguous()
         if tag == "qkv":
             self._rest = None
+        if idx.shape[1] == 0:
+            # an empty selection (e.g. a threshold nothing exceeds): the kernels address index lists of at least one slot, so it
+            # travels as a device-side count of 0 over a one-slot list -- the route of the built-in policies (policies.py)
+            return torch.zeros((B, 1), dtype=torch.int32, device=c.device), torch.zeros((B,), dtype=torch.int32, device=c.device), 1
         return idx, None, idx.shape[1]
 
     def _count_gate(self, gate, n):

@@ -518,3 +518,97 @@ def test_results_do_not_depend_on_uninitialised_memory():
         again = fn()
         for a, b in zip(clean, again):
             assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+class _Forced(torch.nn.Module):
+    """Teacher-forced decisions: records what the product's own policy selects, hands the block the oracle's set."""
+
+    def __init__(self, real):
+        super().__init__()
+        self.real, self.force, self.mine = real, None, None
+
+    def forward(self, e, dim=-1):
+        self.mine = self.real(e, dim=dim)
+        return self.force
+
+
+def test_random_block_configurations_match_the_oracle():
+    """Randomised differential test (fixed seed, 160 configurations; scripts/probes/random_differential_probe.py ran 550): block kind,
+    width (head dims 16 / 32 / 48 / 64 / 80 x 2..6 heads), token grid up to 24 x 24, batch 1..3, k, policy kind (top-k / fraction /
+    threshold), class token, rel-pos, pooled keys, windows (+ padding), gate_before_ln, STGT gate, fp16 cast -- first frame + 3 gated
+    frames against the CPU oracle with the DECISIONS teacher-forced (a free-running fork at a near-tie would hide what comes after it).
+    Bars: outputs 3e-4 (fp32) / 5e-3 (fp16 cast); a selection of the product's own policy may differ from the oracle's only where the
+    oracle's top-k margin is below 1e-3."""
+    import random
+    import eventful_oracle as O
+    from eventful_transformer import policies
+    rng = random.Random(20260)
+    gates = ("qkv_gate", "projection_gate", "mlp_gate")
+    keys = ("qkv_index", "projection_index", "mlp_index")
+    forks = 0
+    for case in range(160):
+        dh = rng.choice([64, 64, 64, 16, 32, 48, 80])
+        heads = rng.choice([2, 2, 3, 4, 6])          # (one head: the reference asserts, blocks.py:341)
+        dim = dh * heads
+        kind = rng.choice(["EventfulTokenwiseBlock", "EventfulMatmul1Block", "EventfulBlock", "EventfulBlock"])
+        gh, gw = rng.randint(1, 24), rng.randint(2, 24)
+        kw = {}
+        opt = rng.choice(["plain", "plain", "cls", "rel", "pool", "win", "gbl", "stgt"])
+        cls = opt == "cls"
+        if opt == "rel":
+            kw["relative_embedding_size"] = (gh, gw)
+        if opt == "pool" and kind != "EventfulTokenwiseBlock":
+            p0, p1 = rng.choice([1, 2, 3]), rng.choice([1, 2, 3])
+            gh, gw = max(p0, gh - gh % p0), max(p1, gw - gw % p1)
+            kw["pool_size"] = (p0, p1)
+        if opt == "win" and kind == "EventfulTokenwiseBlock":
+            kw["window_size"] = (rng.randint(2, 8), rng.randint(2, 8))
+            if rng.random() < 0.5:
+                kw["relative_embedding_size"] = kw["window_size"]
+        if opt == "gbl" and kind == "EventfulBlock":
+            kw["gate_before_ln"] = True
+        if opt == "stgt" and kind == "EventfulTokenwiseBlock":
+            kw["stgt"] = True
+        cast = rng.choice([None, None, None, "float16"]) if kind != "EventfulTokenwiseBlock" else None
+        if cast:
+            kw["matmul_2_cast"] = cast
+        n = gh * gw + int(cls)
+        pk = rng.choice(["topk", "topk", "topk", "thr", "frac"])
+        b = 1 if ("pool_size" in kw or pk == "thr") else rng.choice([1, 1, 2, 3])   # (pooled clips of a batch: DESIGN section 2; threshold: batch 1)
+        k = rng.randint(1, n)
+        desc = (case, kind, dim, dh, (gh, gw), cls, b, kw, pk, k)
+        params = O.make_block_params(dim, 4, seed=case, std=0.05, rel_sizes=kw.get("relative_embedding_size"), head_dim=dh)
+        ob = O.BlockOracle(kind, params, dim, heads, (gh, gw), **kw)
+        blk = H.product_block(kind, params, dim, heads, (gh, gw), **kw)
+        if pk == "topk":
+            ob.set_policy(lambda: O.TopK(k))
+            H.set_policies(blk, policies.TokenNormTopK, k=k)
+        elif pk == "frac":
+            ob.set_policy(lambda: O.TopFraction(k / n))
+            H.set_policies(blk, policies.TokenNormTopFraction, fraction=k / n)
+        else:
+            ob.set_policy(lambda: O.Threshold(0.3))
+            H.set_policies(blk, policies.TokenNormThreshold, threshold=0.3)
+        for gn in gates:
+            getattr(blk, gn).policy = _Forced(getattr(blk, gn).policy)
+        xs = O.make_token_stream(b, n, dim, 4, k, seed=case + 1000, small=0.01)
+        tol = 3e-4 if cast is None else 5e-3
+        with torch.inference_mode():
+            for t in range(4):
+                y_ref = ob.forward(xs[t])
+                if t:
+                    for gn, tk in zip(gates, keys):
+                        getattr(blk, gn).policy.force = ob.trace[tk].sort(dim=-1)[0].to(DEV)
+                y = blk(xs[t].to(DEV)).cpu()
+                err = float((y - y_ref).abs().max())
+                assert torch.isfinite(y).all() and err <= tol, (desc, t, err)
+                if t and pk == "topk":
+                    for gn, tk in zip(gates, keys):
+                        mine = getattr(blk, gn).policy.mine
+                        if mine is not None and not torch.equal(mine.sort(dim=-1)[0].cpu(), ob.trace[tk].sort(dim=-1)[0]):
+                            kk = ob.trace[tk].shape[-1]
+                            nrm = torch.linalg.vector_norm(ob.policy[gn].last_input.double(), dim=-1).sort(dim=-1, descending=True)[0]
+                            margin = float(((nrm[..., kk - 1] - nrm[..., kk]) / nrm[..., kk - 1]).min()) if 0 < kk < nrm.shape[-1] else 0.0
+                            assert margin < 1e-3, (desc, t, gn, margin)
+                            forks += 1
+    H.report(f"random block configurations: 160 configurations x 4 frames within tolerance of the oracle (decisions teacher-forced); {forks} own selections differed, all at oracle margins < 1e-3")
