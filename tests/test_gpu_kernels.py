@@ -593,7 +593,9 @@ def test_fused_attention_in_kernel_qk(cast, N, k, rel, qk_split):
         err = float((out.cpu() - ref).abs().max())
         # cast modes: the output IS the store-type state, so a flipped rounding shows as one ulp of the store type at
         # the output's magnitude (bf16 2^-8, fp16 2^-11 relative)
-        bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        # (the store-type state PERSISTS: a rounding flipped in an earlier frame stays, so from the first gated frame on an element may be
+        # off by two ulps -- scripts/probes/random_attention_probe.py met 1.5 ulps of the top binade at t = 2 on random shapes)
+        bar = tol if cast is None else max(tol, (1 if t == 0 else 2) * float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
         assert err <= bar, (cast, N, k, t, err, bar)
         assert torch.equal(out.cpu(), pv.float().cpu())
     with pytest.raises(RuntimeError, match="in-kernel"):
@@ -995,7 +997,7 @@ def test_attention_stream_pooled_keys_matches_oracle(cast, qh, qw, pool, k, rel,
         got_p = apT.float().cpu().transpose(-1, -2)
         assert torch.allclose(got_p, ag.t.float(), atol=atol_p), (cast, t, float((got_p - ag.t.float()).abs().max()))
         err = float((out.cpu() - ref).abs().max())
-        bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        bar = tol if cast is None else max(tol, (1 if t == 0 else 2) * float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))   # (persisting roundings: see above)
         assert err <= bar, (cast, N, Nk, k, t, err, bar)
         assert torch.equal(out.cpu(), pv.float().cpu())
 
@@ -1247,7 +1249,9 @@ def test_attention_stream_matches_oracle(cast, N, gw, k, rel, qk_split):
         got_p = apT.float().cpu().transpose(-1, -2)
         assert torch.allclose(got_p, ag.t.float(), atol=atol_p), (cast, t, float((got_p - ag.t.float()).abs().max()))
         err = float((out.cpu() - ref).abs().max())
-        bar = tol if cast is None else max(tol, float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
+        # (the store-type state PERSISTS: a rounding flipped in an earlier frame stays, so from the first gated frame on an element may be
+        # off by two ulps -- scripts/probes/random_attention_probe.py met 1.5 ulps of the top binade at t = 2 on random shapes)
+        bar = tol if cast is None else max(tol, (1 if t == 0 else 2) * float(ref.abs().max()) * (2.0 ** -7 if cast == "bfloat16" else 2.0 ** -10))
         assert err <= bar, (cast, N, k, t, err, bar)
         assert torch.equal(out.cpu(), pv.float().cpu())
     if cast is not None:   # 16-bit store: the fp32 output may be omitted (the caller reads the A.v state)
