@@ -266,14 +266,19 @@ def _p(t):
 
 def _need_f32(who, **tensors):
     """The C ABI takes these operands as float32 (include/evt_abi.h): weights, biases, LayerNorm / rel-pos parameters, fp32 activations.
-    A model converted with .half() / .bfloat16() / .double() would hand over pointers to other element sizes -- an out-of-bounds read
-    on the device (found as a GPU memory fault by scripts/probes/weight_dtype_probe.py), so it is an error here."""
+    A model converted with .half() / .bfloat16() / .double() would hand over pointers to other element sizes, a model left on the CPU host
+    pointers -- an out-of-bounds access on the device (found as GPU memory faults by scripts/probes/weight_dtype_probe.py), so both are
+    errors here.  (The per-launch wrappers call `_f32dev` on the operands that can come from a user's module; this form names several.)"""
     for name, t in tensors.items():
-        if t is not None and not t.is_cuda:   # e.g. a model left on the CPU fed device tensors: a host pointer in a device kernel
+        _f32dev(t, who, name)
+
+
+def _f32dev(t, who, name):
+    if t is not None and (t.dtype is not torch.float32 or not t.is_cuda):
+        if not t.is_cuda:   # e.g. a model left on the CPU fed device tensors: a host pointer in a device kernel
             raise RuntimeError(f"{who}: `{name}` lives on {t.device}, not on a HIP device: move the model with .to('cuda') (there is no CPU path)")
-        if t is not None and t.dtype != torch.float32:
-            raise RuntimeError(f"{who}: `{name}` must be float32, got {t.dtype} (the MI355X path keeps parameters and the residual stream in "
-                               f"fp32, like the reference's default; `matmul_2_cast` selects the 16-bit stage)")
+        raise RuntimeError(f"{who}: `{name}` must be float32, got {t.dtype} (the MI355X path keeps parameters and the residual stream in "
+                           f"fp32, like the reference's default; `matmul_2_cast` selects the 16-bit stage)")
 
 
 def store_code(dtype):
@@ -350,7 +355,9 @@ def norm_order(order):
 def row_pass(x, rows, D, res=None, res_rows=0, sum_out=None, ln_w=None, ln_b=None, eps=1e-6, c_out=None, p=None,
              norms=None, order=2):
     # "rows" family (bench.py): algorithmic bytes = every (rows, D) fp32 tensor the pass reads or writes, once (+ the norms)
-    _need_f32("evt_row_pass", x=x, res=res, sum_out=sum_out, ln_w=ln_w, ln_b=ln_b, c_out=c_out, p=p, norms=norms)
+    _f32dev(ln_w, "evt_row_pass", "ln_w")   # (parameters of the caller's module; the other operands are this package's own buffers or
+    _f32dev(ln_b, "evt_row_pass", "ln_b")   #  inputs the block / PositionEncoding entry points have checked)
+    _f32dev(res, "evt_row_pass", "res")
     tensors = 1 + (res is not None) + (sum_out is not None) + (c_out is not None) + (p is not None)
     _timed("rows", 4.0 * rows * D * tensors + (4.0 * rows if norms is not None else 0.0),
            lambda: _check(load().evt_row_pass_ord(_p(x), _p(res), res_rows, _p(sum_out), _p(ln_w), _p(ln_b), eps, _p(c_out), _p(p),
@@ -473,7 +480,11 @@ def gated_linear_big_tile(lda, gathered, a_rows, ldo, scattered, o_rows, has_cou
 def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count, p_upd, B, kcap, K, Nout, act=ACT_NONE,
                  W_split=None, a_bf16=False):
     """a_bf16: A is a bfloat16 tensor of exactly representable activations (the A.v state; see evt_abi.h)."""
-    _need_f32("evt_gated_linear", A=None if a_bf16 else A, weight=W, bias=bias, out=out, p=p_upd)
+    _f32dev(bias, "evt_gated_linear", "bias")
+    if W_split is None:   # (the split planes were built from a weight that evt_split_weights' wrapper checked)
+        _f32dev(W, "evt_gated_linear", "weight")
+    if not a_bf16:
+        _f32dev(A, "evt_gated_linear", "A")
     ws, ws_bytes = _splitk_workspace(out.device, count is not None, (B, kcap, K, Nout)) if W_split is not None else (None, 0)
     d = LinearDesc(_p(A), lda, _p(a_idx), a_rows, _p(W), _p(bias), _p(out), ldo, _p(o_idx), o_rows, _p(count),
                    _p(p_upd), B, kcap, K, Nout, act, _p(W_split), _p(ws), ws_bytes, int(a_bf16))
@@ -484,7 +495,12 @@ def gated_linear(A, lda, a_idx, a_rows, W, bias, out, ldo, o_idx, o_rows, count,
 
 def gated_mlp(A, lda, idx, rows, W1, b1, W2, b2, hidden, out, ldo, count, p_upd, B, kcap, D, Dh, W1_split=None,
               W2_split=None):
-    _need_f32("evt_gated_mlp", A=A, weight_1=W1, bias_1=b1, weight_2=W2, bias_2=b2, out=out, p=p_upd)
+    _f32dev(b1, "evt_gated_mlp", "bias_1")
+    _f32dev(b2, "evt_gated_mlp", "bias_2")
+    _f32dev(A, "evt_gated_mlp", "A")
+    if W1_split is None or W2_split is None:
+        _f32dev(W1, "evt_gated_mlp", "weight_1")
+        _f32dev(W2, "evt_gated_mlp", "weight_2")
     s1, s2 = W1_split, W2_split
     if s1 is None or s2 is None:
         s1 = s2 = None

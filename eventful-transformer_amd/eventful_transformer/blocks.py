@@ -478,16 +478,17 @@ class EventfulTokenwiseBlock(Block):
         self.mlp_accumulator = TokenBuffer()
         self._wants_rest = False   # set by subclasses that keep a q.k^T product state
         self._rest = None
+        self._clip_shape = None    # (batch, tokens) of the clip's first frame: what the state tensors were created for
 
     def _check_clip_shape(self, bn):
         """The per-clip state (gate references, token buffers, attention states) has the first frame's (batch, tokens): the kernels
         address it with those sizes.  The reference fails in its scatter / gather with a shape error when they change without
         reset() (modules.py:90-96, 154-164); here it would be an out-of-bounds access, so it is an error up front."""
-        if self.qkv_gate.first:
-            self.__dict__["_clip_shape"] = bn
-        elif self.__dict__.get("_clip_shape", bn) != bn:
+        if self.qkv_gate.first or self._clip_shape is None:   # (the gates' `first` flags are what reset() clears)
+            self._clip_shape = bn
+        elif self._clip_shape != bn:
             raise RuntimeError(f"{type(self).__name__}: frame of (batch, tokens) = {bn} but this clip's state was created for "
-                               f"{self.__dict__['_clip_shape']}; call reset() between clips")
+                               f"{self._clip_shape}; call reset() between clips")
 
     # ---------------------------------------------------------------------------------------------
     # one gate -> linear(s) -> buffer group
