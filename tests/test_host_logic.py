@@ -25,6 +25,10 @@ def test_abi_header_symbols_are_exported():
     lib.evt_version.restype = ctypes.c_int
     lib.evt_target_arch.restype = ctypes.c_char_p
     assert lib.evt_version() == _native.ABI_VERSION == 9 and lib.evt_target_arch() == b"gfx950"
+    # the boundary's documentation names every entry point: the binding guide, and a header comment citing the reference lines it replaces
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert [n for n in declared if n not in guide] == []
+    assert header.count("modules.py:") + header.count("blocks.py:") + header.count("policies.py:") + header.count("utils.py:") >= 40
 
 
 def test_abi_argument_errors_without_gpu():
