@@ -312,11 +312,11 @@ class BlockOracle:
 
     @staticmethod
     def _merge(x):
-        # blocks.py:328-344 -- incl. its assertion that the reshape COPIED (with one head it is a view: a gate would be handed a raw
+        # blocks.py:328-344 -- incl. its assertion that the reshape COPIED (with one head, or one token, it is a view: a gate would be handed a raw
         # reference to an accumulator state and see a delta of zero for ever; the reference refuses, blocks.py:341)
         x = x.permute(0, 2, 1, 3)
         y = x.reshape(x.shape[:-2] + (-1,))
-        assert x.data_ptr() != y.data_ptr(), "blocks.py:341: recombining the heads must copy (heads == 1 is not supported by the reference)"
+        assert x.data_ptr() != y.data_ptr(), "blocks.py:341: recombining the heads must copy (one head, or one token, is not supported by the reference)"
         return y
 
     def _window_pad(self):
