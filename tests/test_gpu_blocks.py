@@ -412,7 +412,7 @@ def test_vivit_b_sharp_bf16_projection_gates(golden_dir):
     other = [0, 0]
     worst_all, worst_differing = 0.0, 0.0
     # the projection gates with a large margin are rare (~3 %): replay the clips that hold one, until 70 of them have been seen
-    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:32]   # (all 70: the table in DESIGN.md section 3; 32 keep the test near a minute)
+    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:32]   # (all 70: the table in DESIGN.md section 3; 32: 474 checked / 372 equal = 78 %; 16 clips: 237 / 172 = 73 %, too close to the bar)
     seen = 0
     for c in want:
         model.backbone.reset()
@@ -468,7 +468,7 @@ def test_vivit_b_sharp_bf16_projection_gates_state_forced(golden_dir):
     gold = {b_: [0, 0] for b_ in bars}     # the in-situ oracle vs the golden reference run (another machine), by the golden margin
     hip_gold = {b_: [0, 0] for b_ in bars}
     other = [0, 0]
-    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:14]   # (24 clips: 554 / 554; 14 keep the test near 100 s)
+    want = [c for c in range(int(g["clips"])) if (margins_all[c, :, :, 1] >= 7e-3).any()][:10]   # (24 clips: 554 / 554; 14: 320 / 320; 10 keep the test near a minute)
     for c in want:
         model.backbone.reset()
         bb.reset()
@@ -497,10 +497,10 @@ def test_vivit_b_sharp_bf16_projection_gates_state_forced(golden_dir):
              f"accumulation (same rounding points, other summation order) vs the oracle in situ: {tw}; the oracle in situ vs the golden reference run "
              f"(same arithmetic on two machines, free-running): {gold}; HIP vs the golden run: {hip_gold}; qkv + mlp gates at margin >= 1e-3 (HIP vs "
              f"in situ): {other[1]}/{other[0]}")
-    assert other[0] >= 300 and other[1] == other[0], other
+    assert other[0] >= 200 and other[1] == other[0], other
     # observed: 554 / 554 at margin >= 1e-4 (573 / 574 at >= 1e-5) for the HIP path AND for the twin; the in-situ oracle agrees with the
     # golden run (another machine's BLAS summation order, free-running) on 381 / 548 -- the "79 %" of the test above is that drift
-    assert hip[1e-4][0] >= 300 and hip[1e-4][1] == hip[1e-4][0], hip
+    assert hip[1e-4][0] >= 200 and hip[1e-4][1] == hip[1e-4][0], hip
     assert hip[1e-5][1] >= tw[1e-5][1] - 2, (hip, tw)
 
 
