@@ -1773,14 +1773,14 @@ def main():
             release_workload(w)
             legs = {}
             for name, kw in (("vivit16_B1_graphs", dict(workload="vivit16", clips=1, total_clips=1, graphs=True, steps=20)),
-                             ("vivit_dense", dict(clips=64, total_clips=64, steps=2)),
+                             ("vivit_dense", dict(clips=128, total_clips=128, steps=2)),
                              ("vivit32", dict(clips=128, total_clips=128, steps=2)),
                              ("vitdet672", dict(steps=5, graphs=True)),
                              ("vitdet672_S8", dict(workload="vitdet672", streams=8, steps=3)),
                              ("vitdet1024", dict(steps=3, graphs=True)),
                              # the reference's own GPU timing / evaluation settings at full size (float16 cast)
-                             ("vivit16_fp16", dict(clips=64, total_clips=64, steps=2)),
-                             ("vivit401_fp16", dict(clips=32, total_clips=32, steps=2)),
+                             ("vivit16_fp16", dict(clips=128, total_clips=128, steps=2)),
+                             ("vivit401_fp16", dict(clips=64, total_clips=64, steps=2)),
                              ("vitdet672_fp16", dict(steps=5, graphs=True)),
                              ("vitdet1024_k512", dict(steps=3, graphs=True)),
                              ("vitdet672_pool2", dict(steps=3, graphs=True))):
